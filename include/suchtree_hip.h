@@ -1,0 +1,137 @@
+/*
+ * suchtree_hip.h -- C ABI of libsuchtree_hip.so, the MI355X (gfx950) bulk
+ * patristic-distance / MRCA engine behind suchtree_amd.SuchTree.
+ *
+ * The reference (ryneches/SuchTree) has no FFI layer for this path: the
+ * boundary is its Cython class surface and the two cdef methods behind it.
+ * Each entry point below names the reference interface it stands in for
+ * (paths relative to /root/reference).  Signatures are plain C: pointers and
+ * sizes only, no torch / numpy types.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns ST_OK (0) or an ST_ERR_* code; the message for
+ *     the calling thread's last failure is st_last_error().
+ *   - node ids are the reference's ids: positions in the in-order traversal
+ *     of the strictly binary tree (SuchTree/MuchTree.pyx:171-180).
+ *   - pairs are int64 (n,2) views given as a base pointer and two ELEMENT
+ *     strides (the reference takes any `long[:,:]` memoryview,
+ *     MuchTree.pyx:913); C order is stride0=2, stride1=1.
+ *   - distances come back as float64 holding the float32 value the
+ *     reference accumulates (MuchTree.pyx:922,943); MRCA ids as int32.
+ *   - "_host" entry points take host buffers and do the transfers; "_device"
+ *     entry points take device buffers on the tree's GPU, enqueue on the
+ *     caller's hipStream_t (passed as void*, NULL = default stream) and do
+ *     not synchronise.
+ */
+#ifndef SUCHTREE_HIP_H
+#define SUCHTREE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_OK          0
+#define ST_ERR_ARG     1   /* bad argument (NULL, negative size, bad strategy) */
+#define ST_ERR_HIP     2   /* a HIP runtime call failed / no usable GPU */
+#define ST_ERR_BOUNDS  3   /* a node id in `pairs` is outside [0, n_nodes) */
+#define ST_ERR_NOMEM   4   /* host allocation failed */
+#define ST_ERR_TREE    5   /* parent array is not a single rooted binary tree */
+
+/* kernel families (st_tree_create `strategy`, st_tree_info.strategy) */
+#define ST_STRATEGY_AUTO    0  /* canopy when the tree admits it, else walk */
+#define ST_STRATEGY_WALK    1  /* pointer chase over the {parent,dist} table */
+#define ST_STRATEGY_CANOPY  2  /* top of tree in LDS + per-node understory records */
+
+typedef struct st_tree st_tree;   /* opaque: device-resident tree */
+
+typedef struct st_tree_info {
+    int64_t n_nodes;
+    int64_t n_leaves;
+    int32_t root;
+    int32_t depth;            /* nodes on the longest leaf->root path (MuchTree.pyx:218-225) */
+    int32_t device;
+    int32_t strategy;         /* ST_STRATEGY_WALK or ST_STRATEGY_CANOPY actually in use */
+    int32_t canopy_nodes;     /* nodes staged in LDS (0 for walk) */
+    int32_t understory_max;   /* longest chain below the canopy, in nodes */
+    int32_t record_bytes;     /* stride of one understory record */
+    int32_t reserved;
+    int64_t device_bytes;     /* HBM held by this tree */
+} st_tree_info;
+
+/* Last error message of the calling thread ("" if none). */
+const char *st_last_error(void);
+
+/* Number of visible HIP devices. */
+int st_device_count(int *count);
+
+/*
+ * Upload a tree.  Replaces the reference's in-object `Node* data` filled at
+ * SuchTree/MuchTree.pyx:158-216 (parent / distance columns) and the `depth`
+ * scan at :218-225.  `parent[root] == -1`; `distance` are the float32 branch
+ * lengths exactly as the reference stores them (root entry ignored).
+ * All derived tables (depths, canopy, understory records) are built here,
+ * once, and stay resident in HBM until st_tree_destroy.
+ */
+int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes,
+                   int device, int strategy, st_tree **out);
+
+/* Replaces SuchTree.__dealloc__ (MuchTree.pyx:230-232). */
+void st_tree_destroy(st_tree *tree);
+
+int st_tree_info_get(const st_tree *tree, st_tree_info *info);
+
+/*
+ * Bulk distances (+ MRCA ids) for host-resident pairs.  Replaces
+ * SuchTree._distances (SuchTree/MuchTree.pyx:911-943, which calls _mrca
+ * :999-1030) as invoked by distances_bulk (:872-909).
+ * out_dist and out_mrca may each be NULL (not both).  On ST_ERR_BOUNDS
+ * *bad_id (if non-NULL) receives the id the reference would report
+ * (max id if it is >= n_nodes, else the min id; MuchTree.pyx:897-903) and the
+ * outputs are unspecified.
+ */
+int st_distances_host(st_tree *tree, const int64_t *pairs, int64_t n,
+                      int64_t stride0, int64_t stride1,
+                      double *out_dist, int32_t *out_mrca, int64_t *bad_id);
+
+/*
+ * Same computation on device-resident buffers, enqueued on `stream`
+ * (a hipStream_t; NULL = default stream).  Does not synchronise.  Out-of-range
+ * ids never dereference the tree: such pairs produce NaN / -1 and are
+ * recorded in the tree's fault word, read back by st_fault_check.
+ */
+int st_distances_device(st_tree *tree, const int64_t *d_pairs, int64_t n,
+                        int64_t stride0, int64_t stride1,
+                        double *d_out_dist, int32_t *d_out_mrca, void *stream);
+
+/*
+ * Synchronise `stream`, then report and clear the fault word written by
+ * earlier st_distances_device calls: ST_OK, or ST_ERR_BOUNDS with *bad_id set
+ * as for st_distances_host.
+ */
+int st_fault_check(st_tree *tree, void *stream, int64_t *bad_id);
+
+/* Select the kernel family for subsequent calls (tests / benchmarking).
+ * ST_ERR_ARG if the tree was built without that family's tables. */
+int st_tree_set_strategy(st_tree *tree, int strategy);
+
+/*
+ * Host-only helper, no GPU needed: edges-to-root for every node and the
+ * reference's `depth` (MuchTree.pyx:218-225).  out_depths may be NULL.
+ */
+int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths,
+                   int32_t *out_tree_depth);
+
+/* Thin device-memory helpers so callers without torch can stage buffers. */
+int st_device_malloc(int device, int64_t bytes, void **out);
+int st_device_free(int device, void *ptr);
+int st_memcpy_h2d(int device, void *dst, const void *src, int64_t bytes);
+int st_memcpy_d2h(int device, void *dst, const void *src, int64_t bytes);
+int st_device_synchronize(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUCHTREE_HIP_H */

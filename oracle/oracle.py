@@ -1,0 +1,205 @@
+"""ctypes front-end of the CPU oracle (oracle/suchtree_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of suchtree_oracle.c.  Importable
+from tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg;
+never from ``suchtree_amd``.
+
+Also carries ``py_mrca`` / ``py_distances``: a pure-Python restatement of the
+same reference lines (MuchTree.pyx:911-943, 999-1030) used on tiny inputs to
+cross-check the C file itself.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+NODE_DTYPE = np.dtype(
+    [
+        ("parent", np.int32),
+        ("left_child", np.int32),
+        ("right_child", np.int32),
+        ("support", np.float32),
+        ("distance", np.float32),
+    ],
+    align=False,
+)
+assert NODE_DTYPE.itemsize == 20  # MuchTree.pyx:55-60
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "suchtree_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        L.oracle_fill_nodes.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+        L.oracle_fill_nodes.restype = None
+        L.oracle_depth.argtypes = [vp, i64]
+        L.oracle_depth.restype = ctypes.c_uint
+        L.oracle_mrca.argtypes = [vp, vp, i32, i32]
+        L.oracle_mrca.restype = i32
+        L.oracle_distances_n.argtypes = [vp, i64, vp, vp, i64, i64, vp]
+        L.oracle_distances_n.restype = None
+        L.oracle_distance.argtypes = [vp, vp, i32, i32]
+        L.oracle_distance.restype = ctypes.c_float
+        L.oracle_mrca_bulk.argtypes = [vp, i64, vp, vp, i64, i64, vp]
+        L.oracle_mrca_bulk.restype = None
+        L.oracle_linked_pairs.argtypes = [vp, i64, vp, vp]
+        L.oracle_linked_pairs.restype = None
+        L.oracle_distances_mt.argtypes = [vp, i64, i64, vp, i64, i64, vp, i32]
+        L.oracle_distances_mt.restype = i32
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleTree:
+    """The reference's in-memory tree (20-byte AoS) plus its ``depth``."""
+
+    def __init__(self, parent, distance, left=None, right=None, support=None):
+        parent = np.ascontiguousarray(parent, dtype=np.int32)
+        distance = np.ascontiguousarray(distance, dtype=np.float32)
+        n = parent.shape[0]
+        if left is None or right is None:
+            left, right = children_from_parent(parent)
+        left = np.ascontiguousarray(left, dtype=np.int32)
+        right = np.ascontiguousarray(right, dtype=np.int32)
+        sup = None if support is None else np.ascontiguousarray(support, dtype=np.float32)
+        self.size = n
+        self.nodes = np.zeros(n, dtype=NODE_DTYPE)
+        lib().oracle_fill_nodes(_p(self.nodes), n, _p(parent), _p(left), _p(right),
+                                None if sup is None else _p(sup), _p(distance))
+        self.depth = int(lib().oracle_depth(_p(self.nodes), n))
+        roots = np.flatnonzero(parent == -1)
+        self.root = int(roots[0]) if len(roots) else -1
+
+    def _visited(self):
+        return np.zeros(max(self.depth, 1) + 1, dtype=np.int64)
+
+    @staticmethod
+    def _ids(pairs):
+        ids = np.asarray(pairs)
+        if ids.dtype != np.int64:
+            ids = ids.astype(np.int64)
+        assert ids.ndim == 2 and ids.shape[1] == 2
+        assert ids.strides[0] % 8 == 0 and ids.strides[1] % 8 == 0
+        return ids, ids.strides[0] // 8, ids.strides[1] // 8
+
+    def mrca(self, a, b):
+        return int(lib().oracle_mrca(_p(self.nodes), _p(self._visited()), int(a), int(b)))
+
+    def distance(self, a, b):
+        return float(lib().oracle_distance(_p(self.nodes), _p(self._visited()), int(a), int(b)))
+
+    def distances(self, pairs):
+        ids, s0, s1 = self._ids(pairs)
+        out = np.zeros(ids.shape[0], dtype=np.float64)
+        if ids.shape[0]:
+            lib().oracle_distances_n(_p(self.nodes), ids.shape[0], _p(self._visited()),
+                                     _p(ids), s0, s1, _p(out))
+        return out
+
+    def mrca_bulk(self, pairs):
+        ids, s0, s1 = self._ids(pairs)
+        out = np.zeros(ids.shape[0], dtype=np.int32)
+        if ids.shape[0]:
+            lib().oracle_mrca_bulk(_p(self.nodes), ids.shape[0], _p(self._visited()),
+                                   _p(ids), s0, s1, _p(out))
+        return out
+
+    def distances_mt(self, pairs, n_threads):
+        ids, s0, s1 = self._ids(pairs)
+        out = np.zeros(ids.shape[0], dtype=np.float64)
+        rc = lib().oracle_distances_mt(_p(self.nodes), ids.shape[0], self.depth, _p(ids),
+                                       s0, s1, _p(out), int(n_threads))
+        if rc != 0:
+            raise RuntimeError("oracle_distances_mt failed rc=%d" % rc)
+        return out
+
+
+def linked_pairs(linklist):
+    """(ids_a, ids_b) of linked_distances(), MuchTree.pyx:2909-2925."""
+    ll = np.ascontiguousarray(linklist, dtype=np.int64)
+    L = ll.shape[0]
+    size = L * (L - 1) // 2
+    ids_a = np.zeros((size, 2), dtype=np.int64)
+    ids_b = np.zeros((size, 2), dtype=np.int64)
+    lib().oracle_linked_pairs(_p(ll), L, _p(ids_a), _p(ids_b))
+    return ids_a, ids_b
+
+
+def children_from_parent(parent):
+    """left/right child arrays for an in-order-numbered strictly binary tree:
+    the left child has the smaller id (in-order puts the left subtree first)."""
+    n = len(parent)
+    left = np.full(n, -1, dtype=np.int32)
+    right = np.full(n, -1, dtype=np.int32)
+    for c in range(n):
+        p = int(parent[c])
+        if p < 0:
+            continue
+        if c < p:
+            left[p] = c
+        else:
+            right[p] = c
+    return left, right
+
+
+# ---- pure-Python restatement (tiny inputs only) -----------------------------
+
+def py_mrca(parent, a, b):
+    """MuchTree.pyx:999-1030 in plain Python."""
+    visited = []
+    n = a
+    while True:
+        visited.append(n)
+        n = int(parent[n])
+        if n == -1:
+            break
+    n = b
+    while True:
+        for v in visited:
+            if v == n:
+                return v
+        n = int(parent[n])
+        if n == -1:
+            return -1
+
+
+def py_distances(parent, distance, pairs):
+    """MuchTree.pyx:911-943 in plain Python (float32 accumulator)."""
+    out = np.zeros(len(pairs), dtype=np.float64)
+    dist32 = np.asarray(distance, dtype=np.float32)
+    for i, (a, b) in enumerate(pairs):
+        a, b = int(a), int(b)
+        m = py_mrca(parent, a, b)
+        d = np.float32(0)
+        n = a
+        while n != m:
+            d = np.float32(d + dist32[n])
+            n = int(parent[n])
+        n = b
+        while n != m:
+            d = np.float32(d + dist32[n])
+            n = int(parent[n])
+        out[i] = float(d)
+    return out

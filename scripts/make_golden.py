@@ -1,0 +1,105 @@
+"""Regenerate tests/golden/ from the reference checkout (build container only).
+
+    python scripts/make_golden.py            # needs /root/reference
+
+What is written (all of it DATA -- inputs and expected outputs -- never source):
+  test.tree, test.matrix   verbatim copies of the reference's own test fixtures
+                           (SuchTree/tests/test.tree, SuchTree/tests/test.matrix;
+                           the matrix is the only numeric known-answer file the
+                           reference holds for this path)
+  host.tree                data/bigtrees/host.tree, the tree behind the known
+                           answers printed in docs/examples/SuchTree_examples.md
+  known_answers.json       the values printed in the reference docs, with citations
+  ml_tree.npz / nj_tree.npz  flat arrays (parent:int32, distance:float32, leaf ids)
+                           of data/bigtrees/{ml,nj}.tree produced by
+                           suchtree_amd.newick -- BASELINE config 2's tree, shipped as
+                           arrays because /root/reference does not exist on the GPU box
+  oracle_digests.json      sha256 of oracle outputs on seeded pair batches, so the
+                           oracle built on another machine can be checked against
+                           the oracle built here
+
+The reference extension itself is NOT imported: MuchTree.pyx:3 needs dendropy,
+which this image lacks, and writing a stand-in for it is not allowed.  The
+oracle (oracle/suchtree_oracle.c) is therefore pinned by the reference's own
+known answers above, not by outputs of the reference.
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from suchtree_amd.newick import flat_tree_from_newick  # noqa: E402
+from oracle.oracle import OracleTree  # noqa: E402
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    shutil.copyfile(os.path.join(REF, "SuchTree/tests/test.tree"), os.path.join(OUT, "test.tree"))
+    shutil.copyfile(os.path.join(REF, "SuchTree/tests/test.matrix"), os.path.join(OUT, "test.matrix"))
+    shutil.copyfile(os.path.join(REF, "data/bigtrees/host.tree"), os.path.join(OUT, "host.tree"))
+    for f in ("test.tree", "test.matrix", "host.tree"):
+        os.chmod(os.path.join(OUT, f), 0o644)
+
+    known = {
+        "host_tree_leaves": {
+            "cite": "docs/examples/SuchTree_examples.md:99-112 (T.leaves printed by the reference with real dendropy)",
+            "value": {
+                "Tropheus_moorii": 0, "Lobochilotes_labiatus": 2, "Tanganicodus_irsacae": 4,
+                "Cyprichromis_coloratus": 6, "Haplotaxodon_microlepis": 8, "Perissodus_microlepis": 10,
+                "Plecodus_straeleni": 12, "Xenotilapia_flavipinnis": 14, "Triglachromis_otostigma": 16,
+                "Reganochromis_calliurus": 18, "Trematochromis_benthicola": 20,
+                "Lepidiolamprologus_profundicola": 22, "Neolamprologus_buescheri": 24,
+                "Chalinochromis_brichardi": 26},
+        },
+        "host_tree_distances": [
+            {"cite": "docs/examples/SuchTree_examples.md:136-138", "a": 12, "b": 26, "printed_6dp": "0.388425"},
+            {"cite": "docs/examples/SuchTree_examples.md:156-158", "a": "Reganochromis_calliurus",
+             "b": "Haplotaxodon_microlepis", "printed_6dp": "0.270743"},
+        ],
+        "bigtrees_sizes": {
+            "cite": "docs/benchmarks.md:45-48, data/bigtrees/README.md:5-6",
+            "nodes": 108653, "leaves": 54327,
+        },
+    }
+    with open(os.path.join(OUT, "known_answers.json"), "w") as fh:
+        json.dump(known, fh, indent=1, sort_keys=True)
+
+    digests = {}
+    for name in ("ml", "nj"):
+        t = flat_tree_from_newick(open(os.path.join(REF, "data/bigtrees/%s.tree" % name)).read())
+        leaf_ids = np.array(list(t.leaves.values()), dtype=np.int32)
+        np.savez_compressed(os.path.join(OUT, "%s_tree.npz" % name), parent=t.parent, distance=t.distance,
+                            leaf_ids=leaf_ids, depth=np.int32(t.depth), root=np.int32(t.root))
+        O = OracleTree(t.parent, t.distance)
+        rng = np.random.default_rng(2)
+        pairs = rng.choice(leaf_ids.astype(np.int64), size=(20000, 2))
+        digests[name] = {
+            "pairs": "default_rng(2).choice(leaf_ids.astype(int64), size=(20000, 2))",
+            "size": int(t.size), "depth": int(t.depth), "root": int(t.root),
+            "parent_sha256": digest(t.parent), "distance_sha256": digest(t.distance),
+            "dist_sha256": digest(O.distances(pairs)), "mrca_sha256": digest(O.mrca_bulk(pairs)),
+        }
+    t = flat_tree_from_newick(open(os.path.join(OUT, "test.tree")).read())
+    O = OracleTree(t.parent, t.distance, t.left, t.right, t.support)
+    allp = np.array([(a, b) for a in range(t.size) for b in range(t.size)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "gopher_all_pairs.npz"), parent=t.parent, distance=t.distance,
+                        pairs=allp, dist=O.distances(allp), mrca=O.mrca_bulk(allp))
+    with open(os.path.join(OUT, "oracle_digests.json"), "w") as fh:
+        json.dump(digests, fh, indent=1, sort_keys=True)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

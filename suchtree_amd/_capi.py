@@ -1,0 +1,202 @@
+"""ctypes binding of libsuchtree_hip.so (the C ABI in include/suchtree_hip.h).
+
+Loading fails loudly (``HipBackendError``) when the library has not been built:
+there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from .exceptions import HipBackendError, InvalidNodeError, TreeStructureError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsuchtree_hip.so")
+
+ST_OK, ST_ERR_ARG, ST_ERR_HIP, ST_ERR_BOUNDS, ST_ERR_NOMEM, ST_ERR_TREE = 0, 1, 2, 3, 4, 5
+STRATEGY = {"auto": 0, "walk": 1, "canopy": 2}
+STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
+
+# every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
+SYMBOLS = (
+    "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
+    "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
+    "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
+    "st_device_synchronize",
+)
+
+
+class TreeInfo(ctypes.Structure):
+    _fields_ = [
+        ("n_nodes", ctypes.c_int64),
+        ("n_leaves", ctypes.c_int64),
+        ("root", ctypes.c_int32),
+        ("depth", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("strategy", ctypes.c_int32),
+        ("canopy_nodes", ctypes.c_int32),
+        ("understory_max", ctypes.c_int32),
+        ("record_bytes", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("device_bytes", ctypes.c_int64),
+    ]
+
+    def as_dict(self):
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d["strategy"] = STRATEGY_NAME.get(d["strategy"], str(d["strategy"]))
+        return d
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load the HIP library once; raise HipBackendError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                "libsuchtree_hip.so is not built (%s). Build it with `python -m suchtree_amd.build` "
+                "(hipcc, gfx950); this package has no CPU fallback." % LIB_PATH)
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise HipBackendError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        L.st_last_error.argtypes = []
+        L.st_last_error.restype = ctypes.c_char_p
+        L.st_device_count.argtypes = [ctypes.POINTER(i32)]
+        L.st_tree_create.argtypes = [vp, vp, i64, i32, i32, ctypes.POINTER(vp)]
+        L.st_tree_destroy.argtypes = [vp]
+        L.st_tree_destroy.restype = None
+        L.st_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
+        L.st_distances_host.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
+        L.st_distances_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+        L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
+        L.st_tree_set_strategy.argtypes = [vp, i32]
+        L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
+        L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
+        L.st_device_free.argtypes = [i32, vp]
+        L.st_memcpy_h2d.argtypes = [i32, vp, vp, i64]
+        L.st_memcpy_d2h.argtypes = [i32, vp, vp, i64]
+        L.st_device_synchronize.argtypes = [i32]
+        for name in SYMBOLS:
+            if name not in ("st_last_error", "st_tree_destroy"):
+                getattr(L, name).restype = i32
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return load().st_last_error().decode("utf-8", "replace")
+
+
+def check(rc, tree_size=None, bad_id=None):
+    """Map a C return code onto the package's exceptions."""
+    if rc == ST_OK:
+        return
+    msg = last_error()
+    if rc == ST_ERR_BOUNDS:
+        raise InvalidNodeError(bad_id, tree_size)
+    if rc == ST_ERR_TREE:
+        raise TreeStructureError(msg)
+    if rc == ST_ERR_ARG:
+        raise ValueError(msg)
+    if rc == ST_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise HipBackendError(msg)
+
+
+def device_count():
+    c = ctypes.c_int(0)
+    rc = load().st_device_count(ctypes.byref(c))
+    if rc != ST_OK:
+        return 0
+    return int(c.value)
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class DeviceTree:
+    """Owner of one ``st_tree`` handle (the tree resident in one GPU's HBM)."""
+
+    def __init__(self, parent, distance, device=0, strategy="auto"):
+        L = load()
+        self._lib = L
+        self._h = ctypes.c_void_p()
+        parent = np.ascontiguousarray(parent, dtype=np.int32)
+        distance = np.ascontiguousarray(distance, dtype=np.float32)
+        if parent.ndim != 1 or parent.shape != distance.shape:
+            raise ValueError("parent and distance must be 1-D arrays of equal length")
+        if strategy not in STRATEGY:
+            raise ValueError("strategy must be one of %s" % sorted(STRATEGY))
+        self.size = int(parent.shape[0])
+        rc = L.st_tree_create(_ptr(parent), _ptr(distance), self.size, int(device),
+                              STRATEGY[strategy], ctypes.byref(self._h))
+        check(rc)
+        self.device = int(device)
+
+    def close(self):
+        h, self._h = self._h, ctypes.c_void_p()
+        if h:
+            self._lib.st_tree_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise HipBackendError("tree handle is closed")
+        return self._h
+
+    def info(self):
+        ti = TreeInfo()
+        check(self._lib.st_tree_info_get(self.handle, ctypes.byref(ti)))
+        return ti.as_dict()
+
+    def set_strategy(self, strategy):
+        check(self._lib.st_tree_set_strategy(self.handle, STRATEGY[strategy]))
+
+    def distances_host(self, pairs, want_dist=True, want_mrca=False):
+        """pairs: int64 (n,2) ndarray with any strides (multiples of 8 bytes)."""
+        n = int(pairs.shape[0])
+        out_d = np.zeros(n, dtype=np.float64) if want_dist else None
+        out_m = np.zeros(n, dtype=np.int32) if want_mrca else None
+        if n == 0:
+            return out_d, out_m
+        if pairs.strides[0] % 8 or pairs.strides[1] % 8:
+            pairs = np.ascontiguousarray(pairs)
+        s0, s1 = pairs.strides[0] // 8, pairs.strides[1] // 8
+        if s0 < 0 or s1 < 0:   # negative strides: the base pointer is not the lowest address
+            pairs = np.ascontiguousarray(pairs)
+            s0, s1 = 2, 1
+        bad = ctypes.c_int64(0)
+        rc = self._lib.st_distances_host(self.handle, _ptr(pairs), n, s0, s1, _ptr(out_d), _ptr(out_m),
+                                         ctypes.byref(bad))
+        check(rc, tree_size=self.size, bad_id=int(bad.value))
+        return out_d, out_m
+
+    def distances_device(self, d_pairs, n, d_out_dist=0, d_out_mrca=0, stream=0, stride0=2, stride1=1):
+        """Raw device pointers (ints); enqueues on ``stream`` without synchronising."""
+        rc = self._lib.st_distances_device(self.handle, ctypes.c_void_p(d_pairs), int(n), int(stride0),
+                                           int(stride1), ctypes.c_void_p(d_out_dist or None),
+                                           ctypes.c_void_p(d_out_mrca or None),
+                                           ctypes.c_void_p(stream or None))
+        check(rc)
+
+    def fault_check(self, stream=0):
+        bad = ctypes.c_int64(0)
+        rc = self._lib.st_fault_check(self.handle, ctypes.c_void_p(stream or None), ctypes.byref(bad))
+        check(rc, tree_size=self.size, bad_id=int(bad.value))

@@ -1,0 +1,57 @@
+"""Build libsuchtree_hip.so in-tree with hipcc for gfx950.
+
+    python -m suchtree_amd.build [--force]
+
+The library is git-ignored (history stays source-only) but travels to the GPU
+box with the repo snapshot, so it must be built before a gpurun call.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsuchtree_hip.so")
+SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep.cpp")]
+HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
+           os.path.join(HERE, "..", "include", "suchtree_hip.h")]
+
+FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3", "-std=c++17", "-fPIC", "-shared",
+    # float32 adds must stay single, ordered adds (reference accumulates in C float)
+    "-ffp-contract=off", "-fno-fast-math",
+    "-Wall", "-Wno-unused-result",
+]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; cannot build libsuchtree_hip.so")
+    return exe
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + list(extra) + ["-I", os.path.join(HERE, "..", "include"),
+                                            "-o", LIB] + SOURCES + ["-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=[a for a in sys.argv[1:] if a.startswith("-R") or a.startswith("-save")])
+    print(LIB)

@@ -1,0 +1,167 @@
+// pair_math.h -- the per-pair arithmetic, shared by the gfx950 kernels and by
+// the host-side emulator that the CPU test-suite uses to check the table
+// construction (tests only; the product never computes on the CPU).
+//
+// Contract restated from the reference (/root/reference/SuchTree/MuchTree.pyx):
+//   mrca(a,b)  = first node of b's root-ward lineage that is also on a's
+//                lineage, a and b themselves included (:999-1030)
+//   d(a,b)     = float32 accumulator, 0, += dist[n] for n = a .. below mrca,
+//                then += dist[n] for n = b .. below mrca, in that order
+//                (:930-943); stored as double.
+// Float adds only, strictly left to right: no reassociation, no FMA.
+#pragma once
+#include <cstdint>
+
+#include "tree_prep.h"
+
+namespace st {
+
+struct PairResult {
+    float dist;
+    int32_t mrca;
+};
+
+// ---- walk family -----------------------------------------------------------
+// Depth cut: lift the deeper endpoint to the other's depth, then climb in
+// lock step until the lineages meet.  The a-side sum is accumulated during
+// the climb (it starts from 0, so climbing order == summation order); the
+// b-side continues the same accumulator and therefore needs a second pass
+// over b's lineage once the a-side total is known.
+ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
+                           int32_t a, int32_t b)
+{
+    int32_t x = a, y = b;
+    int32_t dx = depth[x], dy = depth[y];
+    float s = 0.0f;
+    while (dx > dy) {
+        Node8 e = nodes[x];
+        s += e.dist;
+        x = e.parent;
+        dx--;
+    }
+    while (dy > dx) {
+        y = nodes[y].parent;
+        dy--;
+    }
+    while (x != y) {
+        Node8 ex = nodes[x];
+        int32_t py = nodes[y].parent;
+        s += ex.dist;
+        x = ex.parent;
+        y = py;
+    }
+    const int32_t m = x;
+    y = b;
+    while (y != m) {
+        Node8 e = nodes[y];
+        s += e.dist;
+        y = e.parent;
+    }
+    PairResult r;
+    r.dist = s;
+    r.mrca = m;
+    return r;
+}
+
+// MRCA only (no branch-length loads).
+ST_HD int32_t pair_walk_mrca(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
+                             int32_t a, int32_t b)
+{
+    int32_t x = a, y = b;
+    int32_t dx = depth[x], dy = depth[y];
+    while (dx > dy) { x = nodes[x].parent; dx--; }
+    while (dy > dx) { y = nodes[y].parent; dy--; }
+    while (x != y) {
+        int32_t px = nodes[x].parent;
+        int32_t py = nodes[y].parent;
+        x = px;
+        y = py;
+    }
+    return x;
+}
+
+// ---- canopy family ---------------------------------------------------------
+// `can` is the canopy table (LDS on the device), BFS-numbered: parent index <
+// child index, so "move the larger index up" can never step past the meeting
+// point.  `rec_*` are the understory records of a and b (global memory).
+struct RecView {
+    uint32_t portal;
+    uint32_t nb;
+    float pbot;
+    const float *D;      // nb branch lengths, node itself first
+    const int32_t *I;    // nb node ids, node itself first
+};
+
+ST_HD RecView rec_view(const uint8_t *records, int64_t slot, int32_t rec_bytes)
+{
+    const uint8_t *r = records + slot * (int64_t)rec_bytes;
+    const uint8_t *h = r + rec_bytes / 2;
+    RecView v;
+    const uint32_t w0 = *reinterpret_cast<const uint32_t *>(r);
+    v.portal = w0 & 0xFFFFu;
+    v.nb = w0 >> 16;
+    v.pbot = *reinterpret_cast<const float *>(h);
+    v.D = reinterpret_cast<const float *>(r + 4);
+    v.I = reinterpret_cast<const int32_t *>(h + 4);
+    return v;
+}
+
+// Both lineages enter the canopy at different nodes: the MRCA is a canopy
+// node.  s_in = a's understory total (pbot), D_b/nb_b = b's understory.
+// CAP > 0: D_b is a register array of CAP floats (fully unrolled, predicated);
+// CAP == 0: D_b is read through the pointer with a run-time trip count.
+template <int CAP, typename CanPtr>
+ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canopy_id,
+                                   uint32_t pa, float pbot_a, uint32_t pb,
+                                   const float *D_b, uint32_t nb_b)
+{
+    float s = pbot_a;
+    uint32_t u = pa, v = pb;
+    while (u != v) {
+        const bool up_a = u > v;
+        const CanopyEntry e = can[up_a ? u : v];
+        if (up_a) {
+            s += e.dist;
+            u = e.parent;
+        } else {
+            v = e.parent;
+        }
+    }
+    const uint32_t mc = u;
+    if (CAP > 0) {
+#pragma unroll
+        for (int i = 0; i < CAP; i++)
+            if ((uint32_t)i < nb_b) s += D_b[i];
+    } else {
+        for (uint32_t i = 0; i < nb_b; i++) s += D_b[i];
+    }
+    v = pb;
+    while (v != mc) {
+        const CanopyEntry e = can[v];
+        s += e.dist;
+        v = e.parent;
+    }
+    PairResult r;
+    r.dist = s;
+    r.mrca = canopy_id[mc];
+    return r;
+}
+
+// Both lineages enter the canopy at the same node: the MRCA is that portal or
+// lies in the understory.  Align the two chains at the portal end.
+ST_HD PairResult pair_canopy_same_portal(const int32_t *__restrict__ canopy_id,
+                                         const RecView &A, const RecView &B)
+{
+    uint32_t c = 0;
+    while (c < A.nb && c < B.nb && A.I[A.nb - 1 - c] == B.I[B.nb - 1 - c]) c++;
+    const uint32_t ia = A.nb - c, ib = B.nb - c;
+    float s = 0.0f;
+    for (uint32_t i = 0; i < ia; i++) s += A.D[i];
+    for (uint32_t i = 0; i < ib; i++) s += B.D[i];
+    PairResult r;
+    r.dist = s;
+    r.mrca = c ? A.I[ia] : canopy_id[A.portal];
+    return r;
+}
+
+}  // namespace st

@@ -1,0 +1,601 @@
+// suchtree_hip.hip -- gfx950 kernels and the C ABI of libsuchtree_hip.so.
+//
+// Hot path replaced: SuchTree._distances + SuchTree._mrca
+// (/root/reference/SuchTree/MuchTree.pyx:911-943, 999-1030).  One wavefront
+// lane per node pair.  Two kernel families, bit-identical results:
+//
+//   walk    pointer chase over the 8-byte {parent,dist} table with a depth
+//           cut; works for any rooted tree.
+//   canopy  the top of the tree lives in LDS (BFS-numbered, 8 B per node);
+//           everything below it is folded into one fixed-stride understory
+//           record per node, so a pair costs two record reads from HBM plus an
+//           LDS climb instead of ~h dependent global gathers.
+//
+// Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/suchtree_hip.h"
+#include "pair_math.h"
+#include "tree_prep.h"
+
+namespace st {
+
+// --------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define ST_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return fail(ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// --------------------------------------------------------------------------
+// device-side helpers
+// --------------------------------------------------------------------------
+struct Fault {
+    long long max_bad;   // largest offending id seen  (init INT64_MIN)
+    long long min_bad;   // smallest offending id seen (init INT64_MAX)
+};
+
+__device__ __forceinline__ void record_fault(Fault *f, long long a, long long b, long long n_nodes)
+{
+    if (a < 0 || a >= n_nodes) { atomicMax(&f->max_bad, a); atomicMin(&f->min_bad, a); }
+    if (b < 0 || b >= n_nodes) { atomicMax(&f->max_bad, b); atomicMin(&f->min_bad, b); }
+}
+
+template <bool CONTIG>
+__device__ __forceinline__ void load_pair(const long long *__restrict__ pairs, long long i,
+                                          long long s0, long long s1, long long &a, long long &b)
+{
+    if (CONTIG) {
+        const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];   // one 16-byte load per lane
+        a = v.x;
+        b = v.y;
+    } else {
+        a = pairs[i * s0];
+        b = pairs[i * s0 + s1];
+    }
+}
+
+__device__ __forceinline__ void store_result(double *__restrict__ out_d, int *__restrict__ out_m,
+                                             long long i, float d, int m)
+{
+    if (out_d) out_d[i] = (double)d;
+    if (out_m) out_m[i] = m;
+}
+
+// --------------------------------------------------------------------------
+// walk kernel
+// --------------------------------------------------------------------------
+struct WalkParams {
+    const Node8 *nodes;
+    const int32_t *depth;
+    long long n_nodes;
+};
+
+template <bool CONTIG>
+__global__ __launch_bounds__(256) void k_walk(WalkParams P, const long long *__restrict__ pairs,
+                                              long long n, long long s0, long long s1,
+                                              double *__restrict__ out_d, int *__restrict__ out_m,
+                                              Fault *fault)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long a, b;
+        load_pair<CONTIG>(pairs, i, s0, s1, a, b);
+        if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
+            (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+            record_fault(fault, a, b, P.n_nodes);
+            store_result(out_d, out_m, i, __builtin_nanf(""), -1);
+            continue;
+        }
+        if (out_d) {
+            const PairResult r = pair_walk(P.nodes, P.depth, (int32_t)a, (int32_t)b);
+            store_result(out_d, out_m, i, r.dist, r.mrca);
+        } else {
+            out_m[i] = pair_walk_mrca(P.nodes, P.depth, (int32_t)a, (int32_t)b);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
+// canopy kernel
+// --------------------------------------------------------------------------
+struct CanopyParams {
+    const CanopyEntry *canopy;     // [canopy_nodes] global copy, staged to LDS
+    const int32_t *canopy_id;      // [canopy_nodes]
+    const uint8_t *records;        // [n_nodes * rec_bytes]
+    long long n_nodes;
+    long long n_leaves;
+    int32_t canopy_nodes;
+    int32_t rec_bytes;
+    int32_t parity;                // 1: leaf records first (leaves are the even ids)
+};
+
+constexpr int kCanopyBlock = 1024;
+
+// CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 selects the
+// generic form that reads b's chain through a pointer.
+template <int CAP, bool CONTIG>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P,
+                                                         const long long *__restrict__ pairs,
+                                                         long long n, long long s0, long long s1,
+                                                         double *__restrict__ out_d,
+                                                         int *__restrict__ out_m, Fault *fault)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    CanopyEntry *can = reinterpret_cast<CanopyEntry *>(lds_raw);
+
+    // stage the canopy: 16 bytes (two entries) per lane per step, coalesced
+    {
+        const int n16 = (P.canopy_nodes + 1) / 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.canopy);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long a, b;
+        load_pair<CONTIG>(pairs, i, s0, s1, a, b);
+        if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
+            (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+            record_fault(fault, a, b, P.n_nodes);
+            store_result(out_d, out_m, i, __builtin_nanf(""), -1);
+            continue;
+        }
+        const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
+        const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
+        const uint8_t *ra = P.records + sa * rec_bytes;
+        const uint8_t *rb = P.records + sb * rec_bytes;
+
+        // a: word0 and pbot.  b: the whole first half (word0 + chain lengths).
+        const uint32_t wa = *reinterpret_cast<const uint32_t *>(ra);
+        const float pbot_a = *reinterpret_cast<const float *>(ra + rec_bytes / 2);
+        uint32_t wb;
+        float Db[CAP > 0 ? CAP : 1];
+        if (CAP == 1) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(rb);
+            wb = v.x;
+            Db[0] = __uint_as_float(v.y);
+        } else if (CAP > 1) {
+            uint32_t w[CAP + 1];
+#pragma unroll
+            for (int q = 0; q < (CAP + 1) / 4; q++) {
+                const uint4 v = reinterpret_cast<const uint4 *>(rb)[q];
+                w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+            }
+            wb = w[0];
+#pragma unroll
+            for (int q = 0; q < CAP; q++) Db[q] = __uint_as_float(w[q + 1]);
+        } else {
+            wb = *reinterpret_cast<const uint32_t *>(rb);
+            Db[0] = 0.0f;
+        }
+        const uint32_t pa = wa & 0xFFFFu, pb = wb & 0xFFFFu;
+        PairResult r;
+        if (pa != pb) {
+            const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
+            r = pair_canopy_split<CAP>(can, P.canopy_id, pa, pbot_a, pb, dptr, wb >> 16);
+        } else {
+            const RecView A = rec_view(P.records, sa, rec_bytes);
+            const RecView B = rec_view(P.records, sb, rec_bytes);
+            r = pair_canopy_same_portal(P.canopy_id, A, B);
+        }
+        store_result(out_d, out_m, i, r.dist, r.mrca);
+    }
+}
+
+}  // namespace st
+
+// --------------------------------------------------------------------------
+// host side: the tree handle
+// --------------------------------------------------------------------------
+using namespace st;
+
+struct st_tree {
+    int device = 0;
+    int strategy = ST_STRATEGY_WALK;       // family in use
+    bool has_canopy = false;
+    int n_cu = 256;
+    st_tree_info info{};
+    // device tables
+    Node8 *d_nodes = nullptr;
+    int32_t *d_depth = nullptr;
+    CanopyEntry *d_canopy = nullptr;
+    int32_t *d_canopy_id = nullptr;
+    uint8_t *d_records = nullptr;
+    Fault *d_fault = nullptr;
+    // canopy geometry
+    int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
+    int64_t n_nodes = 0, n_leaves = 0;
+    // workspace of the host entry point
+    std::mutex ws_mutex;
+    void *ws_pairs = nullptr;
+    void *ws_dist = nullptr;
+    void *ws_mrca = nullptr;
+    int64_t ws_cap = 0;   // pairs
+    hipStream_t ws_stream = nullptr;
+};
+
+static const Fault kFaultInit = {std::numeric_limits<long long>::min(),
+                                 std::numeric_limits<long long>::max()};
+
+static size_t canopy_lds_bytes(const st_tree *t)
+{
+    return (size_t)((t->canopy_nodes + 1) / 2) * 16;
+}
+
+template <int CAP, bool CONTIG>
+static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const int64_t *pairs,
+                                  int64_t n, int64_t s0, int64_t s1, double *out_d, int32_t *out_m,
+                                  hipStream_t stream)
+{
+    const size_t lds = canopy_lds_bytes(t);
+    auto kern = k_canopy<CAP, CONTIG>;
+    if (lds > 64 * 1024) {
+        // dynamic LDS above 64 KiB has to be granted per kernel (cheap host-side call)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // one or two 1024-lane workgroups per CU, whatever the LDS image allows
+    const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+    int64_t blocks = (n + kCanopyBlock - 1) / kCanopyBlock;
+    blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
+    blocks = std::max<int64_t>(blocks, 1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P,
+                       reinterpret_cast<const long long *>(pairs), (long long)n, (long long)s0,
+                       (long long)s1, out_d, out_m, t->d_fault);
+    return hipGetLastError();
+}
+
+template <bool CONTIG>
+static hipError_t launch_canopy(const st_tree *t, const int64_t *pairs, int64_t n, int64_t s0,
+                                int64_t s1, double *out_d, int32_t *out_m, hipStream_t stream)
+{
+    CanopyParams P;
+    P.canopy = t->d_canopy;
+    P.canopy_id = t->d_canopy_id;
+    P.records = t->d_records;
+    P.n_nodes = t->n_nodes;
+    P.n_leaves = t->n_leaves;
+    P.canopy_nodes = t->canopy_nodes;
+    P.rec_bytes = t->rec_bytes;
+    P.parity = t->parity;
+    switch (t->rec_cap) {
+        case 1: return launch_canopy_t<1, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        case 3: return launch_canopy_t<3, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        case 7: return launch_canopy_t<7, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        case 15: return launch_canopy_t<15, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        default: return launch_canopy_t<0, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
+    }
+}
+
+template <bool CONTIG>
+static hipError_t launch_walk(const st_tree *t, const int64_t *pairs, int64_t n, int64_t s0,
+                              int64_t s1, double *out_d, int32_t *out_m, hipStream_t stream)
+{
+    WalkParams P;
+    P.nodes = t->d_nodes;
+    P.depth = t->d_depth;
+    P.n_nodes = t->n_nodes;
+    int64_t blocks = (n + 255) / 256;
+    blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
+    blocks = std::max<int64_t>(blocks, 1);
+    hipLaunchKernelGGL(k_walk<CONTIG>, dim3((unsigned)blocks), dim3(256), 0, stream, P,
+                       reinterpret_cast<const long long *>(pairs), (long long)n, (long long)s0,
+                       (long long)s1, out_d, out_m, t->d_fault);
+    return hipGetLastError();
+}
+
+// Small batches are not worth staging 128 KiB of canopy per workgroup.
+constexpr int64_t kCanopyMinPairs = 4096;
+
+static int enqueue(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s0, int64_t s1,
+                   double *d_out, int32_t *d_mrca, hipStream_t stream)
+{
+    if (n == 0) return ST_OK;
+    const bool contig = (s0 == 2 && s1 == 1) && ((reinterpret_cast<uintptr_t>(d_pairs) & 15) == 0);
+    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && d_out != nullptr &&
+                        (n >= kCanopyMinPairs || !t->d_nodes);
+    hipError_t e;
+    if (canopy)
+        e = contig ? launch_canopy<true>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream)
+                   : launch_canopy<false>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream);
+    else
+        e = contig ? launch_walk<true>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream)
+                   : launch_walk<false>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream);
+    if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return ST_OK;
+}
+
+static int read_fault(st_tree *t, hipStream_t stream, int64_t *bad_id)
+{
+    Fault f;
+    ST_HIP(hipMemcpyAsync(&f, t->d_fault, sizeof(Fault), hipMemcpyDeviceToHost, stream));
+    ST_HIP(hipStreamSynchronize(stream));
+    if (f.max_bad == kFaultInit.max_bad && f.min_bad == kFaultInit.min_bad) return ST_OK;
+    ST_HIP(hipMemcpyAsync(t->d_fault, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream));
+    ST_HIP(hipStreamSynchronize(stream));
+    // the reference reports max_id when it is too large, else min_id (MuchTree.pyx:897-903)
+    const long long bad = f.max_bad >= t->n_nodes ? f.max_bad : f.min_bad;
+    if (bad_id) *bad_id = bad;
+    return fail(ST_ERR_BOUNDS, "Node ID " + std::to_string(bad) + " out of bounds (tree size: " +
+                                   std::to_string(t->n_nodes) + ")");
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
+{
+    const size_t sz = std::max<size_t>(src.size() * sizeof(T), 16);
+    ST_HIP(hipMalloc(reinterpret_cast<void **>(dst), sz));
+    if (!src.empty()) ST_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes += (int64_t)sz;
+    return ST_OK;
+}
+
+extern "C" {
+
+const char *st_last_error(void) { return g_last_error.c_str(); }
+
+int st_device_count(int *count)
+{
+    if (!count) return fail(ST_ERR_ARG, "count is NULL");
+    *count = 0;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ST_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = c;
+    return ST_OK;
+}
+
+int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths, int32_t *out_tree_depth)
+{
+    if (!parent || n_nodes <= 0) return fail(ST_ERR_ARG, "parent is NULL or n_nodes <= 0");
+    std::vector<float> zeros((size_t)n_nodes, 0.0f);
+    TreeTables T;
+    std::string err;
+    if (!prepare_basic(parent, zeros.data(), n_nodes, T, err)) return fail(ST_ERR_TREE, err);
+    if (out_depths) std::memcpy(out_depths, T.depth.data(), (size_t)n_nodes * 4);
+    if (out_tree_depth) *out_tree_depth = T.tree_depth;
+    return ST_OK;
+}
+
+int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes, int device,
+                   int strategy, st_tree **out)
+{
+    if (!out) return fail(ST_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!parent || !distance || n_nodes <= 0) return fail(ST_ERR_ARG, "parent/distance NULL or n_nodes <= 0");
+    if (strategy != ST_STRATEGY_AUTO && strategy != ST_STRATEGY_WALK && strategy != ST_STRATEGY_CANOPY)
+        return fail(ST_ERR_ARG, "unknown strategy " + std::to_string(strategy));
+
+    TreeTables T;
+    std::string err;
+    if (!prepare_basic(parent, distance, n_nodes, T, err)) return fail(ST_ERR_TREE, err);
+    bool canopy_ok = false;
+    if (strategy != ST_STRATEGY_WALK) canopy_ok = prepare_canopy(parent, distance, T);
+    if (strategy == ST_STRATEGY_CANOPY && !canopy_ok)
+        return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
+
+    int n_dev = 0;
+    ST_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev)
+        return fail(ST_ERR_HIP, "device " + std::to_string(device) + " not available (" +
+                                    std::to_string(n_dev) + " visible)");
+    ST_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ST_HIP(hipGetDeviceProperties(&prop, device));
+
+    st_tree *t = new (std::nothrow) st_tree();
+    if (!t) return fail(ST_ERR_NOMEM, "out of host memory");
+    t->device = device;
+    t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    t->n_nodes = T.n;
+    t->n_leaves = T.n_leaves;
+    int64_t bytes = 0;
+    int rc = upload(&t->d_nodes, T.nodes, &bytes);
+    if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
+    if (rc == ST_OK && canopy_ok) {
+        t->has_canopy = true;
+        t->canopy_nodes = T.canopy_nodes;
+        t->rec_bytes = T.record_bytes;
+        t->rec_cap = T.record_cap;
+        t->parity = T.parity_layout ? 1 : 0;
+        if (T.canopy.size() & 1) T.canopy.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
+        rc = upload(&t->d_canopy, T.canopy, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_records, T.records, &bytes);
+    }
+    if (rc == ST_OK) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), sizeof(Fault));
+        if (e == hipSuccess) e = hipMemcpy(t->d_fault, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->ws_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
+    }
+    if (rc != ST_OK) {
+        std::string keep = g_last_error;
+        st_tree_destroy(t);
+        g_last_error = keep;
+        return rc;
+    }
+    t->strategy = canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
+    t->info.n_nodes = T.n;
+    t->info.n_leaves = T.n_leaves;
+    t->info.root = T.root;
+    t->info.depth = T.tree_depth;
+    t->info.device = device;
+    t->info.canopy_nodes = canopy_ok ? T.canopy_nodes : 0;
+    t->info.understory_max = canopy_ok ? T.understory_max : 0;
+    t->info.record_bytes = canopy_ok ? T.record_bytes : 0;
+    t->info.device_bytes = bytes;
+    *out = t;
+    return ST_OK;
+}
+
+void st_tree_destroy(st_tree *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    (void)hipFree(t->d_nodes);
+    (void)hipFree(t->d_depth);
+    (void)hipFree(t->d_canopy);
+    (void)hipFree(t->d_canopy_id);
+    (void)hipFree(t->d_records);
+    (void)hipFree(t->d_fault);
+    (void)hipFree(t->ws_pairs);
+    (void)hipFree(t->ws_dist);
+    (void)hipFree(t->ws_mrca);
+    if (t->ws_stream) (void)hipStreamDestroy(t->ws_stream);
+    delete t;
+}
+
+int st_tree_info_get(const st_tree *t, st_tree_info *info)
+{
+    if (!t || !info) return fail(ST_ERR_ARG, "tree or info is NULL");
+    *info = t->info;
+    info->strategy = t->strategy;
+    return ST_OK;
+}
+
+int st_tree_set_strategy(st_tree *t, int strategy)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (strategy == ST_STRATEGY_AUTO) strategy = t->has_canopy ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
+    if (strategy == ST_STRATEGY_CANOPY && !t->has_canopy)
+        return fail(ST_ERR_ARG, "tree was built without canopy tables");
+    if (strategy != ST_STRATEGY_CANOPY && strategy != ST_STRATEGY_WALK)
+        return fail(ST_ERR_ARG, "unknown strategy " + std::to_string(strategy));
+    t->strategy = strategy;
+    return ST_OK;
+}
+
+int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0,
+                        int64_t stride1, double *d_out_dist, int32_t *d_out_mrca, void *stream)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n < 0) return fail(ST_ERR_ARG, "n < 0");
+    if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
+    if (!d_out_dist && !d_out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
+    ST_HIP(hipSetDevice(t->device));
+    return enqueue(t, d_pairs, n, stride0, stride1, d_out_dist, d_out_mrca,
+                   reinterpret_cast<hipStream_t>(stream));
+}
+
+int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    ST_HIP(hipSetDevice(t->device));
+    return read_fault(t, reinterpret_cast<hipStream_t>(stream), bad_id);
+}
+
+int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
+                      double *out_dist, int32_t *out_mrca, int64_t *bad_id)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n < 0) return fail(ST_ERR_ARG, "n < 0");
+    if (n > 0 && !pairs) return fail(ST_ERR_ARG, "pairs is NULL");
+    if (!out_dist && !out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
+    if (n == 0) return ST_OK;
+    ST_HIP(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> lock(t->ws_mutex);
+
+    const int64_t chunk = std::min<int64_t>(n, (int64_t)1 << 23);
+    if (t->ws_cap < chunk) {
+        (void)hipFree(t->ws_pairs); (void)hipFree(t->ws_dist); (void)hipFree(t->ws_mrca);
+        t->ws_pairs = t->ws_dist = t->ws_mrca = nullptr;
+        t->ws_cap = 0;
+        ST_HIP(hipMalloc(&t->ws_pairs, (size_t)chunk * 16));
+        ST_HIP(hipMalloc(&t->ws_dist, (size_t)chunk * 8));
+        ST_HIP(hipMalloc(&t->ws_mrca, (size_t)chunk * 4));
+        t->ws_cap = chunk;
+    }
+    hipStream_t s = t->ws_stream;
+    const bool c_order = (stride0 == 2 && stride1 == 1);
+    std::vector<int64_t> gather;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        const int64_t *src = pairs + off * stride0;
+        if (!c_order) {
+            gather.resize((size_t)m * 2);
+            for (int64_t k = 0; k < m; k++) {
+                gather[(size_t)(2 * k)] = src[k * stride0];
+                gather[(size_t)(2 * k + 1)] = src[k * stride0 + stride1];
+            }
+            src = gather.data();
+        }
+        ST_HIP(hipMemcpyAsync(t->ws_pairs, src, (size_t)m * 16, hipMemcpyHostToDevice, s));
+        int rc = enqueue(t, static_cast<const int64_t *>(t->ws_pairs), m, 2, 1,
+                         out_dist ? static_cast<double *>(t->ws_dist) : nullptr,
+                         out_mrca ? static_cast<int32_t *>(t->ws_mrca) : nullptr, s);
+        if (rc != ST_OK) return rc;
+        if (out_dist) ST_HIP(hipMemcpyAsync(out_dist + off, t->ws_dist, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+        if (out_mrca) ST_HIP(hipMemcpyAsync(out_mrca + off, t->ws_mrca, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        ST_HIP(hipStreamSynchronize(s));
+    }
+    return read_fault(t, s, bad_id);
+}
+
+int st_device_malloc(int device, int64_t bytes, void **out)
+{
+    if (!out || bytes < 0) return fail(ST_ERR_ARG, "bad arguments");
+    ST_HIP(hipSetDevice(device));
+    ST_HIP(hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16)));
+    return ST_OK;
+}
+
+int st_device_free(int device, void *ptr)
+{
+    ST_HIP(hipSetDevice(device));
+    ST_HIP(hipFree(ptr));
+    return ST_OK;
+}
+
+int st_memcpy_h2d(int device, void *dst, const void *src, int64_t bytes)
+{
+    ST_HIP(hipSetDevice(device));
+    ST_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return ST_OK;
+}
+
+int st_memcpy_d2h(int device, void *dst, const void *src, int64_t bytes)
+{
+    ST_HIP(hipSetDevice(device));
+    ST_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int st_device_synchronize(int device)
+{
+    ST_HIP(hipSetDevice(device));
+    ST_HIP(hipDeviceSynchronize());
+    return ST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// tree_prep.cpp -- see tree_prep.h.  Host only; built with -ffp-contract=off
+// because pbot must be the same float32 left-to-right sum the reference
+// accumulates (/root/reference/SuchTree/MuchTree.pyx:922,934-938).
+#include "tree_prep.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace st {
+
+bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
+                   TreeTables &T, std::string &err)
+{
+    T = TreeTables();
+    if (n <= 0) { err = "tree has no nodes"; return false; }
+    if (n > INT32_MAX) { err = "tree has more than 2^31-1 nodes"; return false; }
+    T.n = n;
+
+    // child CSR
+    std::vector<int32_t> n_child((size_t)n + 1, 0);
+    int64_t n_roots = 0;
+    for (int64_t c = 0; c < n; c++) {
+        int32_t p = parent[c];
+        if (p < 0) { n_roots++; T.root = (int32_t)c; continue; }
+        if (p >= n || p == c) { err = "parent id out of range at node " + std::to_string(c); return false; }
+        n_child[(size_t)p]++;
+    }
+    if (n_roots != 1) { err = "expected exactly one root, found " + std::to_string(n_roots); return false; }
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) off[(size_t)i + 1] = off[(size_t)i] + n_child[(size_t)i];
+    std::vector<int32_t> child((size_t)(n > 1 ? n - 1 : 1));
+    {
+        std::vector<int64_t> fill(off.begin(), off.end() - 1);
+        for (int64_t c = 0; c < n; c++) {      // increasing id: left child before right
+            int32_t p = parent[c];
+            if (p >= 0) child[(size_t)fill[(size_t)p]++] = (int32_t)c;
+        }
+    }
+
+    // BFS: parents before children; also detects cycles / unreachable nodes
+    T.bfs_order.resize((size_t)n);
+    T.depth.assign((size_t)n, 0);
+    int64_t head = 0, tail = 0;
+    T.bfs_order[(size_t)tail++] = T.root;
+    while (head < tail) {
+        int32_t x = T.bfs_order[(size_t)head++];
+        for (int64_t k = off[(size_t)x]; k < off[(size_t)x + 1]; k++) {
+            int32_t c = child[(size_t)k];
+            T.depth[(size_t)c] = T.depth[(size_t)x] + 1;
+            T.bfs_order[(size_t)tail++] = c;
+        }
+    }
+    if (tail != n) { err = "parent array contains a cycle or unreachable nodes"; return false; }
+
+    // heights (leaf = 1), leaves, parity layout, reference depth
+    T.height.assign((size_t)n, 1);
+    bool parity = true;
+    int32_t max_leaf_depth = 0;
+    for (int64_t k = n - 1; k >= 0; k--) {
+        int32_t x = T.bfs_order[(size_t)k];
+        bool leaf = n_child[(size_t)x] == 0;
+        if (leaf) {
+            T.n_leaves++;
+            max_leaf_depth = std::max(max_leaf_depth, T.depth[(size_t)x]);
+        }
+        if (leaf != ((x & 1) == 0)) parity = false;
+        int32_t p = parent[x];
+        if (p >= 0) T.height[(size_t)p] = std::max(T.height[(size_t)p], T.height[(size_t)x] + 1);
+    }
+    T.parity_layout = parity && (T.n_leaves == (n + 1) / 2);
+    T.tree_depth = max_leaf_depth + 1;   // MuchTree.pyx:218-225 counts nodes
+
+    T.nodes.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        T.nodes[(size_t)i].parent = parent[i];
+        T.nodes[(size_t)i].dist = distance[i];
+    }
+    return true;
+}
+
+static int32_t pow2_ceil(int32_t v) {
+    int32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T)
+{
+    const int64_t n = T.n;
+    T.has_canopy = false;
+
+    // canopy(H) = { x : height(x) > H } is closed under "parent of", and the
+    // longest lineage left below it has exactly H nodes.  Smallest H whose
+    // canopy fits LDS:
+    int32_t hmax = 0;
+    for (int64_t i = 0; i < n; i++) hmax = std::max(hmax, T.height[(size_t)i]);
+    std::vector<int64_t> count_ge((size_t)hmax + 2, 0);   // nodes with height == h, then suffix sums
+    for (int64_t i = 0; i < n; i++) count_ge[(size_t)T.height[(size_t)i]]++;
+    for (int32_t h = hmax - 1; h >= 0; h--) count_ge[(size_t)h] += count_ge[(size_t)h + 1];
+    // count(height > H) = count_ge[H+1]
+    int32_t h_min = 0;
+    while (h_min < hmax && count_ge[(size_t)h_min + 1] > kMaxCanopyNodes) h_min++;
+    if (count_ge[(size_t)h_min + 1] > kMaxCanopyNodes) return false;   // cannot happen (count_ge[hmax+1] = 0)
+    int32_t rec_bytes = std::max(kMinRecordBytes, pow2_ceil(8 + 8 * h_min));
+    if (rec_bytes > kMaxRecordBytes) return false;
+    // use the whole record: a longer understory means a smaller canopy
+    int32_t cap = record_cap_for(rec_bytes);
+    int32_t H = std::min(cap, hmax);
+    // the root must stay in the canopy so that every lineage has a portal
+    if (H >= hmax) H = hmax - 1;
+    if (H < 0) H = 0;
+
+    // BFS-number the canopy: parent index < child index
+    std::vector<int32_t> cidx((size_t)n, -1);
+    T.canopy.clear();
+    T.canopy_id.clear();
+    for (int64_t k = 0; k < n; k++) {
+        int32_t x = T.bfs_order[(size_t)k];
+        if (T.height[(size_t)x] <= H) continue;
+        int32_t p = parent[x];
+        CanopyEntry e;
+        e.dist = distance[x];
+        e.parent = p < 0 ? 0u : (uint32_t)cidx[(size_t)p];
+        cidx[(size_t)x] = (int32_t)T.canopy.size();
+        T.canopy.push_back(e);
+        T.canopy_id.push_back(x);
+    }
+    T.canopy_nodes = (int32_t)T.canopy.size();
+    if (T.canopy_nodes < 1 || T.canopy_nodes > kMaxCanopyNodes || T.canopy_nodes > 65535) return false;
+    T.canopy[0].dist = 0.0f;   // root: never added
+    T.understory_max = H;
+    T.record_bytes = rec_bytes;
+    T.record_cap = cap;
+
+    // records, parents first so a chain is "self + parent's chain"
+    T.records.assign((size_t)n * (size_t)rec_bytes, 0);
+    for (int64_t k = 0; k < n; k++) {
+        int32_t x = T.bfs_order[(size_t)k];
+        uint8_t *rec = T.records.data() + (size_t)record_slot(x, T.parity_layout, T.n_leaves) * (size_t)rec_bytes;
+        uint32_t *w = reinterpret_cast<uint32_t *>(rec);
+        float *D = reinterpret_cast<float *>(rec + 4);
+        int32_t *I = reinterpret_cast<int32_t *>(rec + rec_bytes / 2 + 4);
+        float pbot = 0.0f;
+        if (cidx[(size_t)x] >= 0) {
+            w[0] = (uint32_t)cidx[(size_t)x];   // chain length 0: the node is its own portal
+        } else {
+            int32_t p = parent[x];
+            uint32_t portal, nb;
+            if (cidx[(size_t)p] >= 0) {
+                portal = (uint32_t)cidx[(size_t)p];
+                nb = 1;
+            } else {
+                const uint8_t *prec = T.records.data() + (size_t)record_slot(p, T.parity_layout, T.n_leaves) * (size_t)rec_bytes;
+                const uint32_t *pw = reinterpret_cast<const uint32_t *>(prec);
+                portal = pw[0] & 0xFFFFu;
+                uint32_t pnb = pw[0] >> 16;
+                nb = pnb + 1;
+                std::memcpy(D + 1, prec + 4, 4 * (size_t)pnb);
+                std::memcpy(I + 1, prec + rec_bytes / 2 + 4, 4 * (size_t)pnb);
+            }
+            if ((int32_t)nb > cap) return false;   // cannot happen: nb <= H <= cap
+            D[0] = distance[x];
+            I[0] = x;
+            w[0] = portal | (nb << 16);
+            // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
+            volatile float acc = 0.0f;
+            for (uint32_t i = 0; i < nb; i++) acc = acc + D[i];
+            pbot = acc;
+        }
+        std::memcpy(rec + rec_bytes / 2, &pbot, 4);
+    }
+    T.has_canopy = true;
+    return true;
+}
+
+}  // namespace st

@@ -1,0 +1,92 @@
+// tree_prep.h -- host-side preparation of the device tables (plain C++17).
+//
+// Input is the reference's flat tree (parent:int32[N], distance:float32[N];
+// /root/reference/SuchTree/MuchTree.pyx:55-60,182-216).  Output is everything
+// the gfx950 kernels read:
+//
+//   nodes    {parent,dist} 8-byte table ........ walk kernel
+//   depth    edges to root per node ............ walk kernel (depth cut)
+//   canopy   the top of the tree, BFS-numbered so that parent index < child
+//            index; staged into LDS by every workgroup .... canopy kernel
+//   records  one fixed-stride "understory" record per node: which canopy
+//            node its lineage enters (portal), the float32 running sum of its
+//            own lineage below the canopy (pbot) and that lineage's branch
+//            lengths / node ids ............................ canopy kernel
+//
+// No GPU calls in here: the "not gpu" tests exercise this file on the CPU.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ST_HD __host__ __device__ __forceinline__
+#else
+#define ST_HD inline
+#endif
+
+namespace st {
+
+struct Node8 {
+    int32_t parent;
+    float dist;
+};
+static_assert(sizeof(Node8) == 8, "Node8 must be 8 bytes");
+
+struct CanopyEntry {
+    float dist;        // branch length above this canopy node
+    uint32_t parent;   // canopy index of its parent (root: 0)
+};
+static_assert(sizeof(CanopyEntry) == 8, "CanopyEntry must be 8 bytes");
+
+// Understory record of R bytes, two halves of R/2:
+//   first half : word0 = portal (canopy index, bits 0..15) | chain length << 16,
+//                then cap float32 branch lengths, the node's own first
+//   second half: pbot (float32 running sum of that chain from 0), then the cap
+//                int32 node ids of the same chain
+// with cap = R/8 - 1.  A pair reads word0 + pbot of `a` and the first half of
+// `b`; the second-half ids are only needed when both lineages share a portal.
+constexpr int kMaxCanopyNodes = 16384;   // 16384 * 8 B = 128 KiB of the 160 KiB LDS
+constexpr int kMaxRecordBytes = 512;
+constexpr int kMinRecordBytes = 16;
+inline int record_cap_for(int rec_bytes) { return rec_bytes / 8 - 1; }
+
+struct TreeTables {
+    int64_t n = 0;
+    int64_t n_leaves = 0;
+    int32_t root = -1;
+    int32_t tree_depth = 0;             // nodes on the longest leaf->root path
+    bool parity_layout = false;         // leaves are exactly the even ids
+    std::vector<Node8> nodes;           // [n]
+    std::vector<int32_t> depth;         // [n] edges to root
+    std::vector<int32_t> bfs_order;     // [n] scratch: parents before children
+    std::vector<int32_t> height;        // [n] scratch: nodes down to the deepest leaf (leaf = 1)
+    // canopy family (empty when the tree does not admit it)
+    bool has_canopy = false;
+    int32_t canopy_nodes = 0;
+    int32_t understory_max = 0;         // longest chain below the canopy
+    int32_t record_bytes = 0;
+    int32_t record_cap = 0;             // chain slots per record
+    std::vector<CanopyEntry> canopy;    // [canopy_nodes]
+    std::vector<int32_t> canopy_id;     // [canopy_nodes] canopy index -> node id
+    std::vector<uint8_t> records;       // [n * record_bytes], slot order
+};
+
+// Record slot of node id x.  With the parity layout leaf records come first
+// so that leaf-pair queries touch a dense half of the table.
+ST_HD int64_t record_slot(int64_t x, bool parity, int64_t n_leaves) {
+    return parity ? ((x & 1) ? n_leaves + (x >> 1) : (x >> 1)) : x;
+}
+
+// Validates the parent array and fills nodes/depth; returns false with `err`
+// set when it is not a single rooted tree.
+bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
+                   TreeTables &T, std::string &err);
+
+// Chooses the canopy and builds canopy + records.  Returns false (without
+// error) when the tree does not admit the canopy family (lineages below any
+// 16k-node canopy longer than a record can hold).
+bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T);
+
+}  // namespace st

@@ -1,0 +1,311 @@
+"""The SuchTree class surface for the bulk distance / MRCA path.
+
+Host-side mirror of the reference's extension type
+(/root/reference/SuchTree/MuchTree.pyx:89-2518): same constructor dispatch,
+property names (and deprecated aliases), method names, argument conventions,
+return types, exceptions and warnings for everything on the hot path.  All
+arithmetic happens in libsuchtree_hip.so on the GPU; nothing here computes a
+distance or an MRCA on the CPU, and a missing library or GPU raises
+``HipBackendError``.
+"""
+from numbers import Integral
+from typing import Dict, List, Tuple, Union
+from urllib.parse import urlparse
+from warnings import warn
+
+import numpy as np
+
+from . import _capi
+from .exceptions import InvalidNodeError, NodeNotFoundError
+from .newick import EPSILON, FlatTree, flat_tree_from_arrays, flat_tree_from_newick
+
+
+def _deprecation_warning(old_name: str, new_name: str, version: str = "2.0") -> None:
+    # wording of MuchTree.pyx:33-42
+    warn(
+        f"{old_name} is deprecated and will be removed in SuchTree {version}. "
+        f"Use {new_name} instead.",
+        DeprecationWarning,
+        stacklevel=3,
+    )
+
+
+class SuchTree:
+    """Immutable phylogenetic tree resident in GPU memory.
+
+    ``tree_input`` follows the reference (MuchTree.pyx:138-155): a URL, a Newick
+    string, or a path to a Newick file.  As an extension it may also be a
+    :class:`~suchtree_amd.newick.FlatTree` or a ``(parent, distance[, leaf_names])``
+    tuple of flat arrays in the reference's in-order numbering.
+
+    ``device``: HIP device index the tree is uploaded to (on first use).
+    ``strategy``: ``'auto'`` | ``'canopy'`` | ``'walk'`` kernel family.
+    """
+
+    def __init__(self, tree_input, device: int = 0, strategy: str = "auto"):
+        self._epsilon = EPSILON
+        if isinstance(tree_input, FlatTree):
+            flat = tree_input
+        elif isinstance(tree_input, tuple):
+            flat = flat_tree_from_arrays(*tree_input)
+        elif isinstance(tree_input, str):
+            if urlparse(tree_input).scheme in ("http", "https", "ftp"):
+                from urllib.request import urlopen
+                with urlopen(tree_input) as fh:
+                    text = fh.read().decode("utf-8")
+            elif all(["(" in tree_input,
+                      ")" in tree_input,
+                      tree_input.count("(") == tree_input.count(")"),
+                      tree_input.endswith(";")]):
+                text = tree_input
+            else:
+                with open(tree_input) as fh:
+                    text = fh.read()
+            flat = flat_tree_from_newick(text)
+        else:
+            raise TypeError("tree_input must be a str, FlatTree or (parent, distance) tuple")
+        self._flat = flat
+        self._device = int(device)
+        if strategy not in _capi.STRATEGY:
+            raise ValueError("strategy must be one of %s" % sorted(_capi.STRATEGY))
+        self._strategy = strategy
+        self._dev_tree = None
+
+    # ------------------------------------------------------------------ device
+    def _device_tree(self) -> "_capi.DeviceTree":
+        """Upload on first use; raises HipBackendError without a usable GPU."""
+        if self._dev_tree is None:
+            self._dev_tree = _capi.DeviceTree(self._flat.parent, self._flat.distance,
+                                              device=self._device, strategy=self._strategy)
+        return self._dev_tree
+
+    def to_device(self) -> "SuchTree":
+        """Force the upload now (otherwise it happens at the first query)."""
+        self._device_tree()
+        return self
+
+    def device_info(self) -> dict:
+        """Kernel family, canopy / understory geometry and HBM footprint."""
+        return self._device_tree().info()
+
+    def close(self) -> None:
+        """Release the GPU copy (it is re-created on the next query)."""
+        if self._dev_tree is not None:
+            self._dev_tree.close()
+            self._dev_tree = None
+
+    # -------------------------------------------------------------- properties
+    @property
+    def size(self) -> int:
+        """The number of nodes in the tree."""
+        return self._flat.size
+
+    @property
+    def depth(self) -> int:
+        """The maximum depth of the tree (nodes on the longest leaf-to-root path)."""
+        return self._flat.depth
+
+    @property
+    def num_leaves(self) -> int:
+        return self._flat.num_leaves
+
+    @property
+    def leaves(self) -> Dict[str, int]:
+        """Dictionary mapping leaf names to node IDs."""
+        return self._flat.leaves
+
+    @property
+    def leaf_nodes(self) -> Dict[int, str]:
+        """Dictionary mapping leaf node IDs to names."""
+        return self._flat.leaf_nodes
+
+    @property
+    def root_node(self) -> int:
+        return self._flat.root
+
+    @property
+    def internal_nodes(self) -> np.ndarray:
+        return self._flat.internal_nodes
+
+    @property
+    def all_nodes(self) -> np.ndarray:
+        return np.concatenate((np.array(list(self.leaves.values())),
+                               np.array(list(self.internal_nodes))))
+
+    @property
+    def leaf_node_ids(self) -> np.ndarray:
+        return np.array(list(self.leaves.values()))
+
+    @property
+    def leaf_names(self) -> list:
+        return list(self.leaves.keys())
+
+    @property
+    def polytomy_epsilon(self) -> float:
+        return self._epsilon
+
+    @polytomy_epsilon.setter
+    def polytomy_epsilon(self, new_epsilon: float) -> None:
+        # like the reference (MuchTree.pyx:298-301) this does not rewrite stored lengths
+        self._epsilon = new_epsilon
+
+    # deprecated aliases (MuchTree.pyx:2374-2414)
+    @property
+    def length(self) -> int:
+        _deprecation_warning("length property", "size")
+        return self.size
+
+    @property
+    def leafs(self) -> dict:
+        _deprecation_warning("leafs property", "leaves")
+        return self.leaves
+
+    @property
+    def leafnodes(self) -> dict:
+        _deprecation_warning("leafnodes property", "leaf_nodes")
+        return self.leaf_nodes
+
+    @property
+    def n_leafs(self) -> int:
+        _deprecation_warning("n_leafs property", "num_leaves")
+        return self.num_leaves
+
+    @property
+    def root(self) -> int:
+        _deprecation_warning("root property", "root_node")
+        return self.root_node
+
+    @property
+    def polytomy_distance(self) -> float:
+        _deprecation_warning("polytomy_distance property", "polytomy_epsilon")
+        return self.polytomy_epsilon
+
+    @polytomy_distance.setter
+    def polytomy_distance(self, value: float) -> None:
+        _deprecation_warning("polytomy_distance property", "polytomy_epsilon")
+        self.polytomy_epsilon = value
+
+    # ------------------------------------------------------------- validation
+    def _validate_node(self, node: Union[int, str]) -> int:
+        """MuchTree.pyx:2255-2284."""
+        if isinstance(node, str):
+            if node not in self.leaves:
+                raise NodeNotFoundError(node)
+            return self.leaves[node]
+        if not isinstance(node, Integral):
+            raise TypeError("Node must be int or str, got {t}".format(t=str(type(node))))
+        node_id = int(node)
+        if node_id < 0 or node_id >= self.size:
+            raise InvalidNodeError(node_id, self.size)
+        return node_id
+
+    def _validate_node_pair(self, a, b) -> Tuple[int, int]:
+        return self._validate_node(a), self._validate_node(b)
+
+    # -------------------------------------------------- cheap harness lookups
+    def get_parent(self, node: Union[int, str]) -> int:
+        return int(self._flat.parent[self._validate_node(node)])
+
+    def get_children(self, node: Union[int, str]) -> Tuple[int, int]:
+        i = self._validate_node(node)
+        return int(self._flat.left[i]), int(self._flat.right[i])
+
+    def get_support(self, node: Union[int, str]) -> float:
+        return float(self._flat.support[self._validate_node(node)])
+
+    def is_leaf(self, node: Union[int, str]) -> bool:
+        return bool(self._flat.left[self._validate_node(node)] == -1)
+
+    def get_ancestors(self, node: Union[int, str]):
+        i = self._validate_node(node)
+        parent = self._flat.parent
+        while True:
+            p = int(parent[i])
+            if p == -1:
+                break
+            yield p
+            i = p
+
+    # ----------------------------------------------------------- the hot path
+    def _coerce_pairs(self, pairs) -> np.ndarray:
+        """Input conventions of distances_bulk (MuchTree.pyx:889-894)."""
+        if not isinstance(pairs, np.ndarray):
+            pairs = np.array(pairs, dtype=np.int64)
+        if pairs.ndim != 2 or pairs.shape[1] != 2:
+            # (a 1-D array raises IndexError here, exactly like the reference's formatting)
+            shape = str((pairs.shape[0], pairs.shape[1]))
+            raise ValueError("Expected (n, 2) array, got shape {shape}".format(shape=shape))
+        if pairs.dtype != np.int64:
+            if not np.issubdtype(pairs.dtype, np.integer):
+                raise ValueError("Buffer dtype mismatch, expected 'long' but got '%s'" % pairs.dtype.name)
+            pairs = pairs.astype(np.int64)   # more permissive than the reference: other int widths are widened
+        if pairs.shape[0] == 0:
+            pairs.max()   # the reference fails here: ValueError (zero-size array to reduction ...)
+        return pairs
+
+    def distances_bulk(self, pairs) -> np.ndarray:
+        """Patristic distances for an (n, 2) array of node-id pairs.
+
+        Stands in for MuchTree.pyx:872-909 + ``_distances`` (:911-943): float64
+        array holding the reference's float32 ordered sums.
+        Raises ValueError for a wrong shape, InvalidNodeError for an id outside
+        ``[0, size)`` (the id reported follows MuchTree.pyx:897-903).
+        """
+        pairs = self._coerce_pairs(pairs)
+        dist, _ = self._device_tree().distances_host(pairs, want_dist=True, want_mrca=False)
+        return dist
+
+    def common_ancestors_bulk(self, pairs) -> np.ndarray:
+        """MRCA node ids (int32) for an (n, 2) array of node-id pairs.
+
+        The reference has no bulk MRCA call; this equals a loop over
+        ``common_ancestor`` (MuchTree.pyx:1128-1149) and uses the same kernels.
+        """
+        pairs = self._coerce_pairs(pairs)
+        _, mrca = self._device_tree().distances_host(pairs, want_dist=False, want_mrca=True)
+        return mrca
+
+    def distances_and_ancestors_bulk(self, pairs) -> Tuple[np.ndarray, np.ndarray]:
+        """(distances float64[n], MRCA ids int32[n]) from one kernel launch."""
+        pairs = self._coerce_pairs(pairs)
+        return self._device_tree().distances_host(pairs, want_dist=True, want_mrca=True)
+
+    def distance(self, a: Union[int, str], b: Union[int, str]) -> float:
+        """Patristic distance between two nodes (MuchTree.pyx:852-870, 981-997)."""
+        node_a, node_b = self._validate_node_pair(a, b)
+        pairs = np.array([[node_a, node_b]], dtype=np.int64)
+        dist, _ = self._device_tree().distances_host(pairs, want_dist=True, want_mrca=False)
+        return float(dist[0])
+
+    def distances_by_name(self, pairs: List[Tuple[str, str]]) -> List[float]:
+        """Distances for (leaf_name, leaf_name) tuples (MuchTree.pyx:945-979)."""
+        if not isinstance(pairs, list):
+            raise TypeError("pairs must be a list of tuples")
+        leaves = self.leaves
+        node_pairs = []
+        for i, (name_a, name_b) in enumerate(pairs):
+            if not isinstance(name_a, str) or not isinstance(name_b, str):
+                raise TypeError("Pair {i}: both elements must be strings".format(i=str(i)))
+            if name_a not in leaves:
+                raise NodeNotFoundError(name_a)
+            if name_b not in leaves:
+                raise NodeNotFoundError(name_b)
+            node_pairs.append((leaves[name_a], leaves[name_b]))
+        pairs_array = np.array(node_pairs, dtype=np.int64)
+        return self.distances_bulk(pairs_array).tolist()
+
+    def common_ancestor(self, a: Union[int, str], b: Union[int, str]) -> int:
+        """Most recent common ancestor of two nodes (MuchTree.pyx:1128-1149)."""
+        node_a, node_b = self._validate_node_pair(a, b)
+        pairs = np.array([[node_a, node_b]], dtype=np.int64)
+        _, mrca = self._device_tree().distances_host(pairs, want_dist=False, want_mrca=True)
+        return int(mrca[0])
+
+    # deprecated wrappers (MuchTree.pyx:2447-2459)
+    def distances(self, pairs):
+        _deprecation_warning("distances()", "distances_bulk()")
+        return self.distances_bulk(pairs)
+
+    def mrca(self, a: Union[int, str], b: Union[int, str]) -> int:
+        _deprecation_warning("mrca()", "common_ancestor()")
+        return self.common_ancestor(a, b)

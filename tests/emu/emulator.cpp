@@ -1,0 +1,73 @@
+// emulator.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Runs the product's host-side table construction (suchtree_amd/csrc/tree_prep.cpp)
+// and the product's per-pair device functions (suchtree_amd/csrc/pair_math.h),
+// compiled for the host, one pair at a time with a plain array standing in for
+// LDS.  The CPU test-suite uses it to check the canopy / understory tables and
+// the pair arithmetic against the oracle without a GPU.  It is never loaded by
+// suchtree_amd: the product computes on the GPU or fails.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../suchtree_amd/csrc/pair_math.h"
+#include "../../suchtree_amd/csrc/tree_prep.h"
+
+using namespace st;
+
+extern "C" {
+
+struct emu_info {
+    int64_t n_leaves;
+    int32_t root, depth, has_canopy, canopy_nodes, understory_max, record_bytes, parity, pad;
+};
+
+static std::string g_err;
+const char *emu_last_error() { return g_err.c_str(); }
+
+// strategy: 1 walk, 2 canopy.  Returns 0 ok, 1 bad tree, 2 canopy not admitted.
+int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy,
+                  const int64_t *pairs, int64_t n, double *out_d, int32_t *out_m, emu_info *info)
+{
+    TreeTables T;
+    if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
+    bool canopy = false;
+    if (strategy == 2) {
+        canopy = prepare_canopy(parent, distance, T);
+        if (!canopy) { g_err = "canopy not admitted"; return 2; }
+    }
+    if (info) {
+        info->n_leaves = T.n_leaves;
+        info->root = T.root;
+        info->depth = T.tree_depth;
+        info->has_canopy = canopy;
+        info->canopy_nodes = T.canopy_nodes;
+        info->understory_max = T.understory_max;
+        info->record_bytes = T.record_bytes;
+        info->parity = T.parity_layout;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t a = pairs[2 * i], b = pairs[2 * i + 1];
+        PairResult r;
+        if (!canopy) {
+            r = pair_walk(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
+            if (out_m && !out_d) r.mrca = pair_walk_mrca(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
+        } else {
+            const int64_t sa = record_slot(a, T.parity_layout, T.n_leaves);
+            const int64_t sb = record_slot(b, T.parity_layout, T.n_leaves);
+            const RecView A = rec_view(T.records.data(), sa, T.record_bytes);
+            const RecView B = rec_view(T.records.data(), sb, T.record_bytes);
+            if (A.portal != B.portal)
+                r = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), A.portal, A.pbot,
+                                         B.portal, B.D, B.nb);
+            else
+                r = pair_canopy_same_portal(T.canopy_id.data(), A, B);
+        }
+        if (out_d) out_d[i] = (double)r.dist;
+        if (out_m) out_m[i] = r.mrca;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+"""Host logic of the SuchTree facade: constructor dispatch, properties,
+deprecated aliases, input validation and the error contract -- everything the
+reference does in Python before its kernel runs (MuchTree.pyx:872-909, 945-979,
+2255-2300, 2374-2459; tests/test_new_api.py:139-158, 810-861).
+No distance or MRCA is computed here: without a GPU the product refuses to.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from suchtree_amd import (HipBackendError, InvalidNodeError, NodeNotFoundError, SuchTree,
+                          SuchTreeError, _capi)
+from suchtree_amd import synth
+
+TEST_TREE = golden_path("test.tree")
+
+
+@pytest.fixture(scope="module")
+def T():
+    return SuchTree(TEST_TREE)
+
+
+def test_constructor_dispatch(T):
+    assert T.size == 29 and T.num_leaves == 15 and T.depth == 9 and T.root_node == 25
+    S = SuchTree("(A,B,(C,D));")
+    assert S.leaves == {"C": 0, "D": 2, "A": 4, "B": 6}
+    parent, dist = synth.balanced_tree(4)
+    F = SuchTree((parent, dist))
+    assert F.size == 31 and F.leaf_names[:2] == ["L0", "L1"] and F.leaves["L1"] == 2
+    with pytest.raises(FileNotFoundError):
+        SuchTree("no/such/file.tree")
+    with pytest.raises(TypeError):
+        SuchTree(42)
+
+
+def test_properties(T):
+    assert isinstance(T.size, int) and isinstance(T.depth, int)
+    assert all(isinstance(k, str) and isinstance(v, int) for k, v in T.leaves.items())
+    assert T.leaf_nodes == {v: k for k, v in T.leaves.items()}
+    assert sorted(T.all_nodes.tolist()) == list(range(T.size))
+    assert T.leaf_node_ids.tolist() == list(T.leaves.values())
+    assert T.leaf_names == list(T.leaves.keys())
+    assert len(T.internal_nodes) == T.size - T.num_leaves
+    assert T.polytomy_epsilon == np.finfo(np.float64).eps
+    assert T.get_parent(T.root_node) == -1 and T.get_children("Ttal") == (-1, -1)
+    assert T.get_children(27) == (26, 28) and T.is_leaf(26) and not T.is_leaf(27)
+    assert list(T.get_ancestors("Ttal")) == [27, 25]
+
+
+@pytest.mark.parametrize("old,new", [("length", "size"), ("leafs", "leaves"), ("leafnodes", "leaf_nodes"),
+                                     ("n_leafs", "num_leaves"), ("root", "root_node")])
+def test_deprecated_properties_warn_and_forward(T, old, new):
+    with pytest.warns(DeprecationWarning, match="%s property is deprecated and will be removed in SuchTree 2.0. "
+                                                "Use %s instead." % (old, new)):
+        assert getattr(T, old) == getattr(T, new)
+
+
+def test_validate_node(T):
+    assert T._validate_node("Ttal") == 26 and T._validate_node(np.int32(3)) == 3
+    with pytest.raises(NodeNotFoundError, match="Leaf name not found: nope."):
+        T._validate_node("nope")
+    for bad in (-1, T.size, T.size + 100):
+        with pytest.raises(InvalidNodeError) as e:
+            T._validate_node(bad)
+        assert str(e.value) == "Node ID %d out of bounds (tree size: 29)" % bad
+        assert e.value.node_id == bad and e.value.tree_size == 29
+    for bad in (1.5, [1], None):
+        with pytest.raises(TypeError, match="Node must be int or str"):
+            T._validate_node(bad)
+    assert issubclass(InvalidNodeError, SuchTreeError) and issubclass(NodeNotFoundError, SuchTreeError)
+
+
+def test_pair_array_conventions(T):
+    with pytest.raises(ValueError, match=r"Expected \(n, 2\) array, got shape \(1, 3\)"):
+        T.distances_bulk(np.array([[0, 1, 2]]))
+    with pytest.raises(IndexError):
+        T.distances_bulk(np.array([0, 1, 2]))                 # 1-D: the reference's message formatting fails
+    with pytest.raises(ValueError):
+        T.distances_bulk(np.zeros((0, 2), dtype=np.int64))    # empty: pairs.max() has no identity
+    with pytest.raises(ValueError, match="Buffer dtype mismatch"):
+        T.distances_bulk(np.zeros((3, 2), dtype=np.float64))
+    c = T._coerce_pairs([(0, 2), (4, 6)])
+    assert c.dtype == np.int64 and c.shape == (2, 2)
+    assert T._coerce_pairs(np.array([[0, 2]], dtype=np.int32)).dtype == np.int64
+
+
+def test_by_name_errors_come_before_any_device_work(T):
+    with pytest.raises(TypeError, match="pairs must be a list of tuples"):
+        T.distances_by_name((("Ttal", "Tbot"),))
+    with pytest.raises(TypeError, match="Pair 1: both elements must be strings"):
+        T.distances_by_name([("Ttal", "Tbot"), ("Ttal", 3)])
+    with pytest.raises(NodeNotFoundError, match="Leaf name not found: Nope."):
+        T.distances_by_name([("Ttal", "Nope")])
+    with pytest.raises(NodeNotFoundError):
+        T.distance("Nope", "Ttal")
+    with pytest.raises(InvalidNodeError):
+        T.common_ancestor(0, 1000)
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_answer(T):
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    for call in (lambda: T.distances_bulk(np.array([[0, 2]])), lambda: T.distance(0, 2),
+                 lambda: T.common_ancestor(0, 2), lambda: T.distances_by_name([("Ttal", "Tbot")]),
+                 lambda: T.common_ancestors_bulk(np.array([[0, 2]]))):
+        with pytest.raises(HipBackendError):
+            call()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        with pytest.raises(HipBackendError):
+            T.distances(np.array([[0, 2]]))
+
+
+def test_missing_library_is_reported(monkeypatch, tmp_path):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "libsuchtree_hip.so"))
+    with pytest.raises(HipBackendError, match="not built"):
+        _capi.load()

@@ -1,0 +1,270 @@
+"""Parity of the HIP path (through the C ABI) with the oracle -- needs an MI355X.
+
+Bar (BASELINE.json north_star): MRCA ids bit-exact; distances within 1e-6
+relative.  Because the kernels reproduce the reference's float32 summation
+order the tests demand more: the float64 outputs must be bit-identical.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, golden_path
+from oracle.oracle import OracleTree
+from suchtree_amd import InvalidNodeError, SuchTree, _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6   # the stated tolerance; bit-equality below is stricter
+
+
+def _both(dev, pairs):
+    out = {}
+    for strategy in ("walk", "canopy"):
+        try:
+            dev.set_strategy(strategy)
+        except ValueError:
+            continue
+        out[strategy] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+    dev.set_strategy("auto")
+    return out
+
+
+def _check(parent, dist, pairs, strategy="auto"):
+    O = OracleTree(parent, dist)
+    want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
+    dev = _capi.DeviceTree(parent, dist, strategy=strategy)
+    res = _both(dev, pairs)
+    assert res, "no kernel family ran"
+    for name, (d, m) in res.items():
+        assert np.array_equal(m, want_m), "%s mrca" % name
+        assert np.all(np.abs(d - want_d) <= REL_TOL * np.abs(want_d)), "%s outside 1e-6" % name
+        assert_bits_equal(d, want_d, "%s distances" % name)
+    d_only, none = dev.distances_host(pairs, want_dist=True, want_mrca=False)
+    assert none is None
+    assert_bits_equal(d_only, want_d)
+    none, m_only = dev.distances_host(pairs, want_dist=False, want_mrca=True)
+    assert none is None and np.array_equal(m_only, want_m)
+    info = dev.info()
+    dev.close()
+    return info
+
+
+def test_gopher_every_pair_against_golden():
+    z = np.load(golden_path("gopher_all_pairs.npz"))
+    info = _check(z["parent"], z["distance"], z["pairs"])
+    dev = _capi.DeviceTree(z["parent"], z["distance"])
+    for strategy in ("walk", "canopy"):
+        dev.set_strategy(strategy)
+        d, m = dev.distances_host(z["pairs"], True, True)
+        assert_bits_equal(d, z["dist"])
+        assert np.array_equal(m, z["mrca"])
+    assert info["depth"] == 9 and info["n_nodes"] == 29
+
+
+def test_config1_gopher_1000_random_leaf_pairs(gopher_flat):
+    leaf_ids = np.array(list(gopher_flat.leaves.values()))
+    pairs = np.random.default_rng(1).choice(leaf_ids, size=(1000, 2)).astype(np.int64)
+    _check(gopher_flat.parent, gopher_flat.distance, pairs)
+
+
+@pytest.mark.parametrize("which", ["ml", "nj"])
+def test_config2_bigtrees(which, ml_arrays, nj_arrays):
+    parent, dist, leaf_ids = ml_arrays if which == "ml" else nj_arrays
+    rng = np.random.default_rng(2)
+    info = _check(parent, dist, rng.choice(leaf_ids, size=(300_000, 2)))
+    assert info["strategy"] == "canopy" and info["record_bytes"] == 64
+    _check(parent, dist, rng.integers(0, len(parent), (100_000, 2)))      # internal nodes too
+    a = np.arange(0, 60_000)
+    _check(parent, dist, np.stack([a, a + rng.integers(0, 7, a.size)], 1))   # shared portals / understory MRCAs
+
+
+@pytest.mark.parametrize("levels", [3, 10, 14, 17])
+def test_balanced_trees(levels):
+    parent, dist = synth.balanced_tree(levels)
+    n = len(parent)
+    rng = np.random.default_rng(levels)
+    _check(parent, dist, rng.integers(0, n, (200_000, 2)))
+    a = np.arange(0, min(n - 9, 100_000))
+    _check(parent, dist, np.stack([a, a + rng.integers(0, 9, a.size)], 1))
+
+
+def test_config3_balanced_2_20_sample_and_full_size_properties():
+    levels, n_leaves = 20, 1 << 20
+    parent, dist = synth.balanced_tree(levels)
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert (info["strategy"], info["canopy_nodes"], info["understory_max"], info["record_bytes"]) == \
+        ("canopy", 16383, 7, 64)
+    # oracle on a sample the CPU finishes in seconds
+    O = OracleTree(parent, dist)
+    sample = synth.random_leaf_pairs(n_leaves, 1_000_000, seed=3)
+    want_d, want_m = O.distances(sample), O.mrca_bulk(sample)
+    for name, (d, m) in _both(dev, sample).items():
+        assert_bits_equal(d, want_d, name)
+        assert np.array_equal(m, want_m), name
+    # full batch size of the bench step: size-independent properties
+    big = synth.random_leaf_pairs(n_leaves, 20_000_000, seed=11)
+    res = _both(dev, big)
+    (dw, mw), (dc, mc) = res["walk"], res["canopy"]
+    assert_bits_equal(dc, dw, "canopy vs walk at 2e7 pairs")
+    assert np.array_equal(mc, mw)
+    # mrca(a,b) == mrca(b,a); |d(a,b) - d(b,a)| within float32 rounding of the sum
+    d_rev, m_rev = dev.distances_host(big[:, ::-1], True, True)     # negative-stride view
+    assert np.array_equal(m_rev, mc)
+    assert np.all(np.abs(d_rev - dc) <= 4e-6 * dc + 1e-12)
+    # the MRCA of two leaves of a complete tree: leaves differ first at bit k of the leaf index
+    la, lb = big[:, 0] >> 1, big[:, 1] >> 1
+    same = la == lb
+    x = la ^ lb
+    k = np.zeros(len(x), dtype=np.int64)
+    nz = ~same
+    k[nz] = np.floor(np.log2(x[nz].astype(np.float64))).astype(np.int64) + 1
+    expect = np.where(same, big[:, 0], (((la >> k) << 1 | 1) << k) - 1)
+    assert np.array_equal(mc.astype(np.int64), expect)
+    assert np.all(dc[same] == 0.0)
+    dev.close()
+
+
+def test_deep_and_random_and_tiny_trees():
+    rng = np.random.default_rng(9)
+    parent, dist = synth.caterpillar_tree(3000)
+    _check(parent, dist, rng.integers(0, len(parent), (20_000, 2)))
+    parent, dist = synth.random_binary_tree(50_000, seed=1, zero_fraction=0.1)
+    _check(parent, dist, rng.integers(0, len(parent), (200_000, 2)))
+    parent, dist = synth.random_binary_tree(1, seed=1)
+    _check(parent, dist, np.array([[0, 0]]))
+    parent, dist = synth.random_binary_tree(2, seed=1)
+    _check(parent, dist, np.array([[0, 0], [0, 2], [2, 0], [1, 2], [0, 1], [1, 1]]))
+
+
+def test_tree_too_deep_for_the_canopy_falls_back_to_walk():
+    parent, dist = synth.caterpillar_tree(40_000)
+    with pytest.raises(_capi.TreeStructureError):
+        _capi.DeviceTree(parent, dist, strategy="canopy")
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, len(parent), (3000, 2))
+    info = _check(parent, dist, pairs, strategy="auto")
+    assert info["strategy"] == "walk" and info["depth"] == 40_000
+
+
+def test_special_float_values():
+    parent, dist = synth.random_binary_tree(3000, seed=4)
+    rng = np.random.default_rng(4)
+    dist = dist.copy()
+    k = rng.integers(0, len(dist), 600)
+    dist[k[:100]] = np.float32(1e-42)          # denormal: must not be flushed
+    dist[k[100:200]] = np.float32(-0.0)
+    dist[k[200:300]] = np.float32(3e38)        # overflows to inf in long sums
+    dist[k[300:400]] = np.float32(-1.5)        # NJ trees carry negative lengths
+    dist[k[400:500]] = np.float32(2.220446e-16)
+    dist[k[500:]] = np.float32(1.17549435e-38)
+    _check(parent, dist, rng.integers(0, len(parent), (100_000, 2)))
+
+
+def test_strides_and_dtypes_through_the_facade(ml_arrays):
+    parent, dist, leaf_ids = ml_arrays
+    T = SuchTree((parent, dist))
+    O = OracleTree(parent, dist)
+    pairs = np.random.default_rng(7).choice(leaf_ids, size=(50_000, 2))
+    want = O.distances(pairs)
+    assert_bits_equal(T.distances_bulk(pairs), want)
+    assert_bits_equal(T.distances_bulk(np.asfortranarray(pairs)), want)
+    wide = np.zeros((50_000, 6), dtype=np.int64)
+    wide[:, 1::3] = pairs
+    assert_bits_equal(T.distances_bulk(wide[:, 1::3]), want)
+    assert_bits_equal(T.distances_bulk(pairs[::-1])[::-1], want)
+    assert_bits_equal(T.distances_bulk(pairs.astype(np.int32)), want)
+    assert_bits_equal(T.distances_bulk(pairs[:100].tolist()), want[:100])
+    d, m = T.distances_and_ancestors_bulk(pairs)
+    assert_bits_equal(d, want)
+    assert np.array_equal(m, O.mrca_bulk(pairs))
+    assert np.array_equal(T.common_ancestors_bulk(pairs), m)
+
+
+def test_out_of_range_ids_raise_like_the_reference(gopher_flat):
+    T = SuchTree(golden_path("test.tree"))
+    n = T.size
+    cases = [
+        (np.array([[0, 2], [n, 4]]), n),                 # max too large -> max reported
+        (np.array([[0, 2], [-3, 4]]), -3),               # only negative -> min reported
+        (np.array([[-7, n + 5], [1, 2]]), n + 5),        # both -> max reported (MuchTree.pyx:897-903)
+        (np.array([[0, 2**40]]), 2**40),
+    ]
+    for pairs, bad in cases:
+        with pytest.raises(InvalidNodeError) as e:
+            T.distances_bulk(pairs)
+        assert e.value.node_id == bad and e.value.tree_size == n
+        assert str(e.value) == "Node ID %d out of bounds (tree size: %d)" % (bad, n)
+    # the handle is still usable and the fault word was cleared
+    assert T.distance(0, 2) == OracleTree(gopher_flat.parent, gopher_flat.distance).distance(0, 2)
+    big = np.random.default_rng(0).integers(0, n, (10_000, 2))
+    big[7777, 1] = n
+    with pytest.raises(InvalidNodeError):
+        T.distances_bulk(big)                             # canopy-sized batch
+
+
+def test_device_resident_buffers_and_fault_word(ml_arrays):
+    import ctypes
+    parent, dist, leaf_ids = ml_arrays
+    L = _capi.load()
+    dev = _capi.DeviceTree(parent, dist)
+    O = OracleTree(parent, dist)
+    n = 400_000
+    pairs = np.random.default_rng(3).choice(leaf_ids, size=(n, 2))
+    ptrs = []
+    for nbytes in (n * 16, n * 8, n * 4):
+        p = ctypes.c_void_p()
+        assert L.st_device_malloc(0, nbytes, ctypes.byref(p)) == 0
+        ptrs.append(p)
+    d_pairs, d_dist, d_mrca = ptrs
+    assert L.st_memcpy_h2d(0, d_pairs, pairs.ctypes.data_as(ctypes.c_void_p), n * 16) == 0
+    for strategy in ("walk", "canopy"):
+        dev.set_strategy(strategy)
+        dev.distances_device(d_pairs.value, n, d_dist.value, d_mrca.value)
+        dev.fault_check()
+        out_d = np.zeros(n)
+        out_m = np.zeros(n, dtype=np.int32)
+        assert L.st_memcpy_d2h(0, out_d.ctypes.data_as(ctypes.c_void_p), d_dist, n * 8) == 0
+        assert L.st_memcpy_d2h(0, out_m.ctypes.data_as(ctypes.c_void_p), d_mrca, n * 4) == 0
+        assert_bits_equal(out_d, O.distances(pairs), strategy)
+        assert np.array_equal(out_m, O.mrca_bulk(pairs))
+    # column-major device layout: stride0 = 1, stride1 = n
+    cols = np.ascontiguousarray(pairs.T)
+    assert L.st_memcpy_h2d(0, d_pairs, cols.ctypes.data_as(ctypes.c_void_p), n * 16) == 0
+    dev.distances_device(d_pairs.value, n, d_dist.value, 0, stride0=1, stride1=n)
+    dev.fault_check()
+    out_d = np.zeros(n)
+    assert L.st_memcpy_d2h(0, out_d.ctypes.data_as(ctypes.c_void_p), d_dist, n * 8) == 0
+    assert_bits_equal(out_d, O.distances(pairs))
+    # a bad id is reported by the fault word, never dereferenced
+    bad = pairs.copy()
+    bad[123, 0] = len(parent) + 9
+    assert L.st_memcpy_h2d(0, d_pairs, bad.ctypes.data_as(ctypes.c_void_p), n * 16) == 0
+    dev.distances_device(d_pairs.value, n, d_dist.value, d_mrca.value)
+    with pytest.raises(InvalidNodeError) as e:
+        dev.fault_check()
+    assert e.value.node_id == len(parent) + 9
+    dev.fault_check()   # cleared
+    for p in ptrs:
+        assert L.st_device_free(0, p) == 0
+    dev.close()
+
+
+def test_concurrent_callers_share_one_handle(ml_arrays):
+    parent, dist, leaf_ids = ml_arrays
+    T = SuchTree((parent, dist)).to_device()
+    O = OracleTree(parent, dist)
+    rng = np.random.default_rng(5)
+    batches = [rng.choice(leaf_ids, size=(60_000, 2)) for _ in range(4)]
+    want = [O.distances(b) for b in batches]
+    got = [None] * 4
+
+    def work(i):
+        got[i] = T.distances_bulk(batches[i])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for g, w in zip(got, want):
+        assert_bits_equal(g, w)

@@ -1,0 +1,125 @@
+"""Newick ingest: node ids, epsilon rule, support, errors.
+
+Pinned against dendropy-produced outputs printed in the reference's docs and
+against the structural facts the reference's tests assert
+(tests/test_SuchTree.py:35-44 children ids, :22-24 polytomy resolution).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from suchtree_amd import synth
+from suchtree_amd.exceptions import TreeStructureError
+from suchtree_amd.newick import (EPSILON, flat_tree_from_arrays, flat_tree_from_newick, node_depths)
+
+
+def test_host_tree_leaf_ids_match_docs():
+    known = json.load(open(golden_path("known_answers.json")))
+    t = flat_tree_from_newick(open(golden_path("host.tree")).read())
+    assert t.leaves == known["host_tree_leaves"]["value"]
+    assert list(t.leaves.values()) == sorted(t.leaves.values())   # dict order = in-order
+
+
+def test_simple_polytomy_string():
+    # test_tree_str of the reference's tests: '(A,B,(C,D));'
+    t = flat_tree_from_newick("(A,B,(C,D));")
+    assert t.leaves == {"C": 0, "D": 2, "A": 4, "B": 6}
+    assert (t.root, t.size, t.depth, t.num_leaves) == (3, 7, 3, 4)
+    eps32 = np.float32(EPSILON)
+    assert np.all(t.distance[[0, 1, 2, 4, 5, 6]] == eps32)     # missing lengths -> epsilon (pyx:188-189)
+    assert t.distance[3] == -1.0 and t.parent[3] == -1
+    assert t.left[5] == 4 and t.right[5] == 6 and t.parent[5] == 3   # new node joins the first two children
+
+
+def test_gopher_tree_structure(gopher_flat):
+    t = gopher_flat
+    assert (t.size, t.num_leaves, t.depth, t.root) == (29, 15, 9, 25)
+    # trifurcating root: (Ttal, Tbot, X) -> node 27 = (Ttal=26, Tbot=28), epsilon above it
+    assert t.leaves["Ttal"] == 26 and t.leaves["Tbot"] == 28
+    assert (t.left[27], t.right[27], t.parent[27]) == (26, 28, 25)
+    assert t.distance[27] == np.float32(EPSILON)
+    assert t.distance[26] == np.float32(0.07713)
+    # children ids are consistent with in-order numbering (left < node < right)
+    for i in t.internal_nodes:
+        assert t.left[i] < i < t.right[i]
+        assert t.parent[t.left[i]] == i and t.parent[t.right[i]] == i
+    assert sorted(t.leaf_nodes) == list(range(0, 29, 2))
+
+
+def test_published_sizes_of_bigtrees(ml_arrays, nj_arrays):
+    known = json.load(open(golden_path("known_answers.json")))["bigtrees_sizes"]
+    for parent, dist, leaf_ids in (ml_arrays, nj_arrays):
+        assert len(parent) == known["nodes"] and len(leaf_ids) == known["leaves"]
+        assert np.array_equal(leaf_ids, np.arange(0, len(parent), 2))
+
+
+def test_four_way_polytomy_and_zero_lengths():
+    t = flat_tree_from_newick("(A:1,B:2,C:0,D:4)R:9;")
+    # [A,B,C,D] -> [C,D,(A,B)] -> [(A,B),(C,D)]
+    assert t.leaves == {"A": 0, "B": 2, "C": 4, "D": 6}
+    assert t.root == 3
+    assert t.distance[4] == np.float32(EPSILON)        # explicit zero -> epsilon (pyx:191-192)
+    assert t.distance[1] == np.float32(EPSILON) and t.distance[5] == np.float32(EPSILON)
+    assert t.distance[3] == -1.0                        # root length ignored
+
+
+def test_labels_comments_quotes_support():
+    t = flat_tree_from_newick("[&R] ((a_b:1,'c d''e':2)0.95:3,(x:1,y:1)boot:2)[note];\n")
+    assert list(t.leaves) == ["a_b", "c d'e", "x", "y"]
+    assert t.support[1] == np.float32(0.95)
+    assert t.support[5] == -1.0                          # non-numeric label
+    assert all(t.support[i] == -1.0 for i in t.leaf_nodes)
+    assert t.distance[t.leaves["c d'e"]] == 2.0
+
+
+def test_negative_lengths_pass_through():
+    t = flat_tree_from_newick("((A:-0.5,B:1):1,C:2);")
+    assert t.distance[t.leaves["A"]] == np.float32(-0.5)
+
+
+def test_single_leaf_and_errors():
+    t = flat_tree_from_newick("A;")
+    assert (t.size, t.root, t.depth) == (1, 0, 1) and t.leaves == {"A": 0}
+    with pytest.raises(TypeError):
+        flat_tree_from_newick("((A:1,B:1):1);")          # unifurcation: no in-order traversal
+    with pytest.raises(TreeStructureError):
+        flat_tree_from_newick("((A,B);")
+    with pytest.raises(TreeStructureError):
+        flat_tree_from_newick("(A:x,B);")
+    with pytest.raises(TreeStructureError):
+        flat_tree_from_newick("")
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: synth.balanced_tree(6),
+    lambda: synth.caterpillar_tree(40),
+    lambda: synth.random_binary_tree(200, seed=3),
+])
+def test_synthetic_arrays_survive_a_newick_round_trip(maker):
+    parent, dist = maker()
+    text = synth.to_newick(parent, dist)
+    t = flat_tree_from_newick(text)
+    assert np.array_equal(t.parent, parent)
+    assert np.array_equal(t.distance, dist)
+    f = flat_tree_from_arrays(parent, dist)
+    assert np.array_equal(f.left, t.left) and np.array_equal(f.right, t.right)
+    assert f.depth == t.depth and f.root == t.root and f.leaves == t.leaves
+
+
+def test_balanced_tree_shape():
+    parent, dist = synth.balanced_tree(10)
+    assert len(parent) == 2047 and parent[1023] == -1
+    d = node_depths(parent)
+    assert d.max() == 10 and np.all(d[0::2] == 10)
+    assert dist.dtype == np.float32 and dist[1023] == -1.0
+
+
+def test_flat_arrays_validation():
+    with pytest.raises(TreeStructureError):
+        flat_tree_from_arrays(np.array([-1, -1, 1]), np.zeros(3))
+    with pytest.raises(TreeStructureError):
+        flat_tree_from_arrays(np.array([1, 2, 1]), np.zeros(3))       # cycle, no root
+    with pytest.raises(TreeStructureError):
+        flat_tree_from_arrays(np.array([1, -1, 1, 1, 1]), np.zeros(5))  # not binary

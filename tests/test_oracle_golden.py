@@ -1,0 +1,142 @@
+"""The oracle against every known answer the reference holds for this path.
+
+The reference extension cannot be imported here (dendropy is absent and no
+stand-in is written), so the oracle is pinned by:
+  * SuchTree/tests/test.matrix -- all 225 rows (the reference's own tests use
+    rel=1e-3: tests/test_SuchTree.py:56-88; here the bar is the 5 printed digits)
+  * the distances and leaf ids printed in docs/examples/SuchTree_examples.md
+and cross-checked against an independent pure-Python restatement of the same
+reference lines.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal, golden_path
+from oracle.oracle import OracleTree, py_distances, py_mrca, linked_pairs
+from suchtree_amd.newick import flat_tree_from_newick
+
+
+def _matrix(flat):
+    names, want = [], []
+    for line in open(golden_path("test.matrix")):
+        a, b, d = line.split()
+        names.append((a, b))
+        want.append(float(d))
+    ids = np.array([(flat.leaves[a], flat.leaves[b]) for a, b in names], dtype=np.int64)
+    return names, ids, np.array(want)
+
+
+def test_test_matrix_all_rows(gopher_flat):
+    O = OracleTree(gopher_flat.parent, gopher_flat.distance)
+    names, ids, want = _matrix(gopher_flat)
+    assert len(want) == 225
+    got = O.distances(ids)
+    # the file carries 5 significant digits of a float32 sum
+    assert np.all(np.abs(got - want) <= 5.1e-6 * np.maximum(want, 1e-3) + 1e-7)
+    # scalar form (MuchTree.pyx:981-997) agrees with the bulk form bit for bit
+    for (a, b), g in zip(ids[:40], got[:40]):
+        assert O.distance(int(a), int(b)) == g
+
+
+def test_docs_known_answers():
+    known = json.load(open(golden_path("known_answers.json")))
+    flat = flat_tree_from_newick(open(golden_path("host.tree")).read())
+    assert flat.leaves == known["host_tree_leaves"]["value"]
+    O = OracleTree(flat.parent, flat.distance)
+    for row in known["host_tree_distances"]:
+        a = flat.leaves[row["a"]] if isinstance(row["a"], str) else row["a"]
+        b = flat.leaves[row["b"]] if isinstance(row["b"], str) else row["b"]
+        assert "%f" % O.distance(a, b) == row["printed_6dp"]
+
+
+def test_depth_matches_reference_definition(gopher_flat):
+    O = OracleTree(gopher_flat.parent, gopher_flat.distance)
+    assert O.depth == gopher_flat.depth == 9
+
+
+def test_c_equals_pure_python_restatement(gopher_flat):
+    O = OracleTree(gopher_flat.parent, gopher_flat.distance)
+    n = gopher_flat.size
+    pairs = np.array([(a, b) for a in range(n) for b in range(n)], dtype=np.int64)
+    assert_bits_equal(O.distances(pairs), py_distances(gopher_flat.parent, gopher_flat.distance, pairs))
+    want_m = np.array([py_mrca(gopher_flat.parent, int(a), int(b)) for a, b in pairs])
+    assert np.array_equal(O.mrca_bulk(pairs), want_m)
+    z = np.load(golden_path("gopher_all_pairs.npz"))   # oracle outputs captured at fixture time
+    assert_bits_equal(O.distances(z["pairs"]), z["dist"])
+    assert np.array_equal(O.mrca_bulk(z["pairs"]), z["mrca"])
+
+
+def test_mrca_properties(gopher_flat):
+    """The reference's MRCA tests are property tests (tests/test_SuchTree.py:163-183,
+    tests/test_new_api.py:454-468): symmetric, an ancestor-or-self of both, and the
+    deepest such node (which makes the id unique)."""
+    O = OracleTree(gopher_flat.parent, gopher_flat.distance)
+    parent = gopher_flat.parent
+
+    def lineage(x):
+        out = [x]
+        while parent[x] != -1:
+            x = int(parent[x])
+            out.append(x)
+        return out
+
+    for a in range(gopher_flat.size):
+        for b in range(gopher_flat.size):
+            m = O.mrca(a, b)
+            assert m == O.mrca(b, a)
+            la, lb = lineage(a), lineage(b)
+            assert m in la and m in lb
+            common = [x for x in la if x in lb]
+            assert common[0] == m
+
+
+def test_order_of_summation_is_observable():
+    """d(a,b) and d(b,a) may differ in the last ulp: the a-side is summed first."""
+    from suchtree_amd import synth
+    parent, dist = synth.random_binary_tree(400, seed=5)
+    O = OracleTree(parent, dist)
+    rng = np.random.default_rng(0)
+    pairs = rng.integers(0, len(parent), (4000, 2))
+    d_ab = O.distances(pairs)
+    d_ba = O.distances(pairs[:, ::-1])
+    assert np.allclose(d_ab, d_ba, rtol=1e-5)
+    assert (d_ab != d_ba).any()
+
+
+def test_strided_views_and_threads(ml_arrays):
+    parent, dist, leaf_ids = ml_arrays
+    O = OracleTree(parent, dist)
+    rng = np.random.default_rng(1)
+    pairs = rng.choice(leaf_ids, size=(3000, 2))
+    want = O.distances(pairs)
+    assert_bits_equal(O.distances(np.asfortranarray(pairs)), want)
+    wide = np.zeros((3000, 4), dtype=np.int64)
+    wide[:, ::2] = pairs
+    assert_bits_equal(O.distances(wide[:, ::2]), want)
+    assert_bits_equal(O.distances_mt(pairs, 3), want)
+
+
+def test_digests_of_big_trees(ml_arrays, nj_arrays):
+    """The oracle built on this machine reproduces the outputs captured when the
+    fixtures were made (guards against a miscompiled oracle on another box)."""
+    import hashlib
+    dig = json.load(open(golden_path("oracle_digests.json")))
+    for name, (parent, dist, leaf_ids) in (("ml", ml_arrays), ("nj", nj_arrays)):
+        h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+        assert h(parent) == dig[name]["parent_sha256"]
+        assert h(dist) == dig[name]["distance_sha256"]
+        O = OracleTree(parent, dist)
+        assert O.depth == dig[name]["depth"]
+        pairs = np.random.default_rng(2).choice(leaf_ids, size=(20000, 2))
+        assert h(O.distances(pairs)) == dig[name]["dist_sha256"]
+        assert h(O.mrca_bulk(pairs)) == dig[name]["mrca_sha256"]
+
+
+def test_linked_pairs_order():
+    """MuchTree.pyx:2918-2925: k = i(i-1)/2 + j, ids_a = (ll[j,1], ll[i,1]), ids_b = (ll[j,0], ll[i,0])."""
+    ll = np.array([[10, 0], [11, 2], [12, 4], [13, 6]], dtype=np.int64)
+    a, b = linked_pairs(ll)
+    assert a.tolist() == [[0, 2], [0, 4], [2, 4], [0, 6], [2, 6], [4, 6]]
+    assert b.tolist() == [[10, 11], [10, 12], [11, 12], [10, 13], [11, 13], [12, 13]]
