@@ -38,7 +38,8 @@ def _check(parent, dist, pairs, strategy="auto"):
     assert res, "no kernel family ran"
     for name, (d, m) in res.items():
         assert np.array_equal(m, want_m), "%s mrca" % name
-        assert np.all(np.abs(d - want_d) <= REL_TOL * np.abs(want_d)), "%s outside 1e-6" % name
+        fin = np.isfinite(want_d)       # sums that overflow to inf are covered by the bit test below
+        assert np.all(np.abs(d[fin] - want_d[fin]) <= REL_TOL * np.abs(want_d[fin])), "%s outside 1e-6" % name
         assert_bits_equal(d, want_d, "%s distances" % name)
     d_only, none = dev.distances_host(pairs, want_dist=True, want_mrca=False)
     assert none is None
@@ -73,7 +74,7 @@ def test_config2_bigtrees(which, ml_arrays, nj_arrays):
     parent, dist, leaf_ids = ml_arrays if which == "ml" else nj_arrays
     rng = np.random.default_rng(2)
     info = _check(parent, dist, rng.choice(leaf_ids, size=(300_000, 2)))
-    assert info["strategy"] == "canopy" and info["record_bytes"] == 64
+    assert info["strategy"] == "canopy" and info["record_bytes"] == (64 if which == "ml" else 128)
     _check(parent, dist, rng.integers(0, len(parent), (100_000, 2)))      # internal nodes too
     a = np.arange(0, 60_000)
     _check(parent, dist, np.stack([a, a + rng.integers(0, 7, a.size)], 1))   # shared portals / understory MRCAs
