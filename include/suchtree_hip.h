@@ -117,6 +117,10 @@ int st_fault_check(st_tree *tree, void *stream, int64_t *bad_id);
  * ST_ERR_ARG if the tree was built without that family's tables. */
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
+/* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the
+ * canopy kernel keeps in flight: 1, 2 or 4 (default 2); 0 = scalar form. */
+int st_tree_set_option(st_tree *tree, const char *name, int64_t value);
+
 /*
  * Host-only helper, no GPU needed: edges-to-root for every node and the
  * reference's `depth` (MuchTree.pyx:218-225).  out_depths may be NULL.

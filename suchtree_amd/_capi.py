@@ -22,6 +22,7 @@ STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
 SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
+    "st_tree_set_option",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
@@ -80,6 +81,7 @@ def load():
         L.st_distances_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
         L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.st_tree_set_strategy.argtypes = [vp, i32]
+        L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
         L.st_device_free.argtypes = [i32, vp]
@@ -168,6 +170,9 @@ class DeviceTree:
 
     def set_strategy(self, strategy):
         check(self._lib.st_tree_set_strategy(self.handle, STRATEGY[strategy]))
+
+    def set_option(self, name, value):
+        check(self._lib.st_tree_set_option(self.handle, name.encode(), int(value)))
 
     def distances_host(self, pairs, want_dist=True, want_mrca=False):
         """pairs: int64 (n,2) ndarray with any strides (multiples of 8 bytes)."""

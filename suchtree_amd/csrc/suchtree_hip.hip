@@ -208,6 +208,162 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P,
     }
 }
 
+
+// Same computation with PPL pairs in flight per lane.  The kernel is bound by
+// latency (an HBM round for the pair, one for the two records, then a chain of
+// dependent LDS reads), not by LDS or VALU throughput, so every lane carries
+// PPL independent pairs: their record loads are issued together and their
+// canopy climbs advance in the same loop iteration as independent LDS reads.
+// All updates are predicated selects (a finished climb keeps re-reading its
+// meeting node), so the PPL chains never serialise behind a branch.
+template <int CAP, int PPL, bool CONTIG>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P,
+                                                             const long long *__restrict__ pairs,
+                                                             long long n, long long s0, long long s1,
+                                                             double *__restrict__ out_d,
+                                                             int *__restrict__ out_m, Fault *fault)
+{
+    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    // one ds_read_b64 per climb step: low word = dist bits, high word = parent index
+    const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
+    {
+        const int n16 = (P.canopy_nodes + 1) / 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(P.canopy);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+
+    constexpr int rec_bytes = 8 * (CAP + 1);
+    const bool parity = P.parity != 0;
+    const long long tile = (long long)blockDim.x * PPL;
+    for (long long base = (long long)blockIdx.x * tile; base < n; base += (long long)gridDim.x * tile) {
+        long long idx[PPL], sa[PPL], sb[PPL], ida[PPL], idb[PPL];
+        bool live[PPL], valid[PPL];
+        // all PPL pair loads are issued before anything looks at them
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
+            live[j] = i < n;
+            idx[j] = live[j] ? i : n - 1;
+            load_pair<CONTIG>(pairs, idx[j], s0, s1, ida[j], idb[j]);
+        }
+        bool any_bad = false;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            valid[j] = (unsigned long long)ida[j] < (unsigned long long)P.n_nodes &&
+                       (unsigned long long)idb[j] < (unsigned long long)P.n_nodes;
+            any_bad |= !valid[j] && live[j];
+            const long long a = valid[j] ? ida[j] : 0, b = valid[j] ? idb[j] : 0;
+            sa[j] = record_slot(a, parity, P.n_leaves);
+            sb[j] = record_slot(b, parity, P.n_leaves);
+        }
+        if (any_bad) {
+#pragma unroll
+            for (int j = 0; j < PPL; j++)
+                if (!valid[j] && live[j]) record_fault(fault, ida[j], idb[j], P.n_nodes);
+        }
+        uint32_t u[PPL], v[PPL], pa[PPL], pb[PPL], nb[PPL];
+        float s[PPL], Db[PPL][CAP];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            const uint8_t *ra = P.records + sa[j] * rec_bytes;
+            const uint8_t *rb = P.records + sb[j] * rec_bytes;
+            const uint32_t wa = *reinterpret_cast<const uint32_t *>(ra);
+            s[j] = *reinterpret_cast<const float *>(ra + rec_bytes / 2);
+            uint32_t wb;
+            if (CAP == 1) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(rb);
+                wb = q.x;
+                Db[j][0] = __uint_as_float(q.y);
+            } else {
+                uint32_t w[CAP + 1];
+#pragma unroll
+                for (int q = 0; q < (CAP + 1) / 4; q++) {
+                    const uint4 x = reinterpret_cast<const uint4 *>(rb)[q];
+                    w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+                }
+                wb = w[0];
+#pragma unroll
+                for (int q = 0; q < CAP; q++) Db[j][q] = __uint_as_float(w[q + 1]);
+            }
+            u[j] = wa & 0xFFFFu;
+            v[j] = wb & 0xFFFFu;
+            pa[j] = u[j];
+            pb[j] = v[j];
+            nb[j] = wb >> 16;
+        }
+
+        // climb 1: find the meeting node; the a-side sum rides along
+        bool go = false;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) go |= u[j] != v[j];
+        while (go) {
+            go = false;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const bool act = u[j] != v[j];
+                const bool up_a = u[j] > v[j];
+                const unsigned long long e = can[up_a ? u[j] : v[j]];
+                const float e_dist = __uint_as_float((uint32_t)e);
+                const uint32_t e_parent = (uint32_t)(e >> 32);
+                const float s_next = s[j] + e_dist;
+                s[j] = up_a ? s_next : s[j];
+                u[j] = up_a ? e_parent : u[j];
+                v[j] = (act && !up_a) ? e_parent : v[j];
+                go |= u[j] != v[j];
+            }
+        }
+        // b's understory, then climb 2 over b's canopy lineage
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+#pragma unroll
+            for (int q = 0; q < CAP; q++) {
+                const float s_next = s[j] + Db[j][q];
+                s[j] = (uint32_t)q < nb[j] ? s_next : s[j];
+            }
+            v[j] = pb[j];
+        }
+        go = false;
+#pragma unroll
+        for (int j = 0; j < PPL; j++) go |= v[j] != u[j];
+        while (go) {
+            go = false;
+#pragma unroll
+            for (int j = 0; j < PPL; j++) {
+                const bool act = v[j] != u[j];
+                const unsigned long long e = can[v[j]];
+                const float s_next = s[j] + __uint_as_float((uint32_t)e);
+                s[j] = act ? s_next : s[j];
+                v[j] = act ? (uint32_t)(e >> 32) : v[j];
+                go |= v[j] != u[j];
+            }
+        }
+        int m[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) m[j] = P.canopy_id[u[j]];
+        // shared portal (rare for random pairs): the MRCA is the portal or below it
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            if (pa[j] == pb[j]) {
+                const RecView A = rec_view(P.records, sa[j], rec_bytes);
+                const RecView B = rec_view(P.records, sb[j], rec_bytes);
+                const PairResult r = pair_canopy_same_portal(P.canopy_id, A, B);
+                s[j] = r.dist;
+                m[j] = r.mrca;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            if (live[j]) {
+                if (valid[j]) store_result(out_d, out_m, idx[j], s[j], m[j]);
+                else store_result(out_d, out_m, idx[j], __builtin_nanf(""), -1);
+            }
+        }
+    }
+}
+
 }  // namespace st
 
 // --------------------------------------------------------------------------
@@ -231,6 +387,7 @@ struct st_tree {
     // canopy geometry
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
+    int pairs_per_lane = 2;   // tuning: 0 = scalar reference kernel, 1/2/4 = ILP kernel
     // workspace of the host entry point
     std::mutex ws_mutex;
     void *ws_pairs = nullptr;
@@ -248,13 +405,12 @@ static size_t canopy_lds_bytes(const st_tree *t)
     return (size_t)((t->canopy_nodes + 1) / 2) * 16;
 }
 
-template <int CAP, bool CONTIG>
-static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const int64_t *pairs,
-                                  int64_t n, int64_t s0, int64_t s1, double *out_d, int32_t *out_m,
-                                  hipStream_t stream)
+template <typename Kern>
+static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
+                                  const int64_t *pairs, int64_t n, int64_t s0, int64_t s1,
+                                  double *out_d, int32_t *out_m, hipStream_t stream)
 {
     const size_t lds = canopy_lds_bytes(t);
-    auto kern = k_canopy<CAP, CONTIG>;
     if (lds > 64 * 1024) {
         // dynamic LDS above 64 KiB has to be granted per kernel (cheap host-side call)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -263,13 +419,35 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     }
     // one or two 1024-lane workgroups per CU, whatever the LDS image allows
     const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
-    int64_t blocks = (n + kCanopyBlock - 1) / kCanopyBlock;
+    const int64_t tile = (int64_t)kCanopyBlock * ppl;
+    int64_t blocks = (n + tile - 1) / tile;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P,
                        reinterpret_cast<const long long *>(pairs), (long long)n, (long long)s0,
                        (long long)s1, out_d, out_m, t->d_fault);
     return hipGetLastError();
+}
+
+template <int CAP, bool CONTIG>
+static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const int64_t *pairs,
+                                  int64_t n, int64_t s0, int64_t s1, double *out_d, int32_t *out_m,
+                                  hipStream_t stream)
+{
+    if constexpr (CAP == 0) {
+        return launch_canopy_k(k_canopy<0, CONTIG>, 1, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+    } else {
+        switch (t->pairs_per_lane) {
+            case 0: return launch_canopy_k(k_canopy<CAP, CONTIG>, 1, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+            case 1: return launch_canopy_k(k_canopy_ilp<CAP, 1, CONTIG>, 1, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+            case 2: return launch_canopy_k(k_canopy_ilp<CAP, 2, CONTIG>, 2, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+            default:
+                if constexpr (CAP >= 15)   // 4 x 15 chain registers would spill
+                    return launch_canopy_k(k_canopy_ilp<CAP, 2, CONTIG>, 2, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+                else
+                    return launch_canopy_k(k_canopy_ilp<CAP, 4, CONTIG>, 4, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        }
+    }
 }
 
 template <bool CONTIG>
@@ -494,6 +672,18 @@ int st_tree_set_strategy(st_tree *t, int strategy)
         return fail(ST_ERR_ARG, "unknown strategy " + std::to_string(strategy));
     t->strategy = strategy;
     return ST_OK;
+}
+
+int st_tree_set_option(st_tree *t, const char *name, int64_t value)
+{
+    if (!t || !name) return fail(ST_ERR_ARG, "tree or name is NULL");
+    if (std::strcmp(name, "pairs_per_lane") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1, 2 or 4");
+        t->pairs_per_lane = (int)value;
+        return ST_OK;
+    }
+    return fail(ST_ERR_ARG, std::string("unknown option ") + name);
 }
 
 int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0,

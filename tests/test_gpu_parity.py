@@ -19,13 +19,19 @@ REL_TOL = 1e-6   # the stated tolerance; bit-equality below is stricter
 
 
 def _both(dev, pairs):
+    """Every kernel variant: the walk family and the canopy family at each pairs-per-lane setting."""
     out = {}
     for strategy in ("walk", "canopy"):
         try:
             dev.set_strategy(strategy)
         except ValueError:
             continue
-        out[strategy] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+        if strategy == "walk":
+            out["walk"] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+            continue
+        for ppl in (0, 1, 2, 4):
+            dev.set_option("pairs_per_lane", ppl)
+            out["canopy/ppl%d" % ppl] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
     dev.set_strategy("auto")
     return out
 
@@ -55,11 +61,13 @@ def test_gopher_every_pair_against_golden():
     z = np.load(golden_path("gopher_all_pairs.npz"))
     info = _check(z["parent"], z["distance"], z["pairs"])
     dev = _capi.DeviceTree(z["parent"], z["distance"])
-    for strategy in ("walk", "canopy"):
-        dev.set_strategy(strategy)
-        d, m = dev.distances_host(z["pairs"], True, True)
-        assert_bits_equal(d, z["dist"])
-        assert np.array_equal(m, z["mrca"])
+    for name, (d, m) in _both(dev, z["pairs"]).items():
+        assert_bits_equal(d, z["dist"], name)
+        assert np.array_equal(m, z["mrca"]), name
+    big = np.tile(z["pairs"], (8, 1))           # > kCanopyMinPairs: the canopy kernels really run
+    for name, (d, m) in _both(dev, big).items():
+        assert_bits_equal(d, np.tile(z["dist"], 8), name)
+        assert np.array_equal(m, np.tile(z["mrca"], 8)), name
     assert info["depth"] == 9 and info["n_nodes"] == 29
 
 
@@ -107,7 +115,10 @@ def test_config3_balanced_2_20_sample_and_full_size_properties():
     # full batch size of the bench step: size-independent properties
     big = synth.random_leaf_pairs(n_leaves, 20_000_000, seed=11)
     res = _both(dev, big)
-    (dw, mw), (dc, mc) = res["walk"], res["canopy"]
+    (dw, mw), (dc, mc) = res["walk"], res["canopy/ppl4"]
+    for name, (d, m) in res.items():
+        assert_bits_equal(d, dw, name + " vs walk at 2e7 pairs")
+        assert np.array_equal(m, mw), name
     assert_bits_equal(dc, dw, "canopy vs walk at 2e7 pairs")
     assert np.array_equal(mc, mw)
     # mrca(a,b) == mrca(b,a); |d(a,b) - d(b,a)| within float32 rounding of the sum

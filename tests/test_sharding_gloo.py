@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: world_size-2 gloo process group, pairs sharded across
+ranks, result slices all-gathered.  The compute step is the oracle (a checker,
+injected) because the product path refuses to run without a GPU; what is under
+test is the partitioning and the gather, which are the same code on RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from suchtree_amd import sharding
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 100, 12345):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_triangle_rows():
+    m = 2000
+    k = np.arange(m * (m - 1) // 2)
+    i = sharding.triangle_row_of(k)
+    j = k - i * (i - 1) // 2
+    assert np.all((j >= 0) & (j < i)) and i.max() == m - 1 and i.min() == 1
+    big = np.array([4_999_949_999, 4_999_850_001, 4_999_850_000], dtype=np.int64)   # 100k-leaf triangle
+    assert sharding.triangle_row_of(big).tolist() == [99_999, 99_999, 99_998]
+    lo, hi = sharding.triangle_shard_bounds(100_000, 8, 7)
+    assert hi == 4_999_950_000 and hi - lo in (624_993_750, 624_993_749)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, q):
+    import torch.distributed as dist
+    from oracle.oracle import OracleTree
+    from suchtree_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        parent, dist_ = synth.balanced_tree(9)
+        O = OracleTree(parent, dist_)
+        pairs = np.random.default_rng(0).integers(0, len(parent), (n_pairs, 2))
+        compute = lambda p: (O.distances(p), O.mrca_bulk(p))   # noqa: E731
+        d, m = sharding.distances_sharded(None, pairs, compute=compute)
+        ds, ms, (lo, hi) = sharding.distances_sharded(None, pairs, gather=False, compute=compute)
+        ok = (np.array_equal(d.view(np.int64), O.distances(pairs).view(np.int64))
+              and np.array_equal(m, O.mrca_bulk(pairs))
+              and np.array_equal(ds, d[lo:hi]) and np.array_equal(ms, m[lo:hi])
+              and (lo, hi) == sharding.shard_bounds(n_pairs, world, rank))
+        q.put((rank, bool(ok), hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [1001, 4])
+def test_world_size_2_gloo(n_pairs):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert [r[1] for r in res] == [True, True]
+    assert sum(r[2] for r in res) == n_pairs
+    assert all(p.exitcode == 0 for p in procs)
