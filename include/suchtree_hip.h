@@ -113,6 +113,23 @@ int st_distances_device(st_tree *tree, const int64_t *d_pairs, int64_t n,
  */
 int st_fault_check(st_tree *tree, void *stream, int64_t *bad_id);
 
+/*
+ * All-pairs generator: for an id list ids[0..m) (element stride id_stride) computes
+ * pair k = (ids[j], ids[i]), k = i(i-1)/2 + j, 0 <= j < i < m, for k in
+ * [k_begin, k_begin + k_count); out[k - k_begin] receives the result.  No pair array
+ * exists anywhere: the kernel derives (i, j) from k.  Replaces the nested pair loops of
+ * SuchLinkedTrees.linked_distances (SuchTree/MuchTree.pyx:2918-2925, ids = a linklist
+ * column) and, up to enumeration order, of SuchTree.pairwise_distances (:1106-1114),
+ * followed by _distances (:911-943).  The k-range lets callers shard the triangle by
+ * equal pair counts across GPUs and stream it in tiles.
+ */
+int st_triangle_device(st_tree *tree, const int64_t *d_ids, int64_t m, int64_t id_stride,
+                       int64_t k_begin, int64_t k_count,
+                       double *d_out_dist, int32_t *d_out_mrca, void *stream);
+int st_triangle_host(st_tree *tree, const int64_t *ids, int64_t m, int64_t id_stride,
+                     int64_t k_begin, int64_t k_count,
+                     double *out_dist, int32_t *out_mrca, int64_t *bad_id);
+
 /* Select the kernel family for subsequent calls (tests / benchmarking).
  * ST_ERR_ARG if the tree was built without that family's tables. */
 int st_tree_set_strategy(st_tree *tree, int strategy);

@@ -10,6 +10,8 @@ What is written (all of it DATA -- inputs and expected outputs -- never source):
   host.tree                data/bigtrees/host.tree, the tree behind the known
                            answers printed in docs/examples/SuchTree_examples.md
   known_answers.json       the values printed in the reference docs, with citations
+  gopher_louse/, fish_worm/  the two-tree co-phylogeny data sets of BASELINE config 5 and
+                           the notebooks' printed answers (data/gopher-louse, data/fish-worm)
   ml_tree.npz / nj_tree.npz  flat arrays (parent:int32, distance:float32, leaf ids)
                            of data/bigtrees/{ml,nj}.tree produced by
                            suchtree_amd.newick -- BASELINE config 2's tree, shipped as
@@ -73,6 +75,24 @@ def main():
             "nodes": 108653, "leaves": 54327,
         },
     }
+    known["gopher_louse_linklist"] = {
+        "cite": "data/gopher-louse/Gopher-Louse.ipynb cell 18 (SLT.linklist printed by the reference; compare as a "
+                "set: the 2016 build listed columns in another order)",
+        "value": [[10, 4], [16, 10], [32, 28], [22, 18], [26, 22], [0, 26], [30, 26], [20, 14], [2, 28], [4, 12],
+                  [8, 2], [28, 24], [12, 6], [24, 20], [14, 8], [18, 16], [6, 0]]}
+    known["gopher_louse_linked_distances"] = {
+        "cite": "data/gopher-louse/Gopher-Louse.ipynb cell 9: pearsonr / kendalltau of result['TreeA'] vs "
+                "result['TreeB'] from SLT.linked_distances() (136 link pairs)",
+        "pearson_r": 0.49018498968585178, "kendall_tau": 0.20975684102929301}
+    known["fish_worm_sizes"] = {"cite": "data/fish-worm/fish-worm.ipynb cell 24",
+                                "links": 191, "hosts": 21, "guests": 191}
+    for sub, names in (("gopher-louse", ("gopher.tree", "lice.tree", "links.csv")),
+                       ("fish-worm", ("host.tree", "guest.tree", "links.csv"))):
+        dst = os.path.join(OUT, sub.replace("-", "_"))
+        os.makedirs(dst, exist_ok=True)
+        for f in names:
+            shutil.copyfile(os.path.join(REF, "data", sub, f), os.path.join(dst, f))
+            os.chmod(os.path.join(dst, f), 0o644)
     with open(os.path.join(OUT, "known_answers.json"), "w") as fh:
         json.dump(known, fh, indent=1, sort_keys=True)
 

@@ -22,7 +22,7 @@ STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
 SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
-    "st_tree_set_option",
+    "st_tree_set_option", "st_triangle_device", "st_triangle_host",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
@@ -82,6 +82,8 @@ def load():
         L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.st_tree_set_strategy.argtypes = [vp, i32]
         L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+        L.st_triangle_device.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, vp]
+        L.st_triangle_host.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
         L.st_device_free.argtypes = [i32, vp]
@@ -192,6 +194,33 @@ class DeviceTree:
                                          ctypes.byref(bad))
         check(rc, tree_size=self.size, bad_id=int(bad.value))
         return out_d, out_m
+
+    def triangle_host(self, ids, k_begin=0, k_count=None, want_dist=True, want_mrca=False):
+        """Lower-triangle all-pairs over ``ids`` (1-D int64): pair k = (ids[j], ids[i]),
+        k = i(i-1)/2 + j; returns the slice [k_begin, k_begin + k_count)."""
+        ids = np.asarray(ids)
+        if ids.ndim != 1:
+            raise ValueError("ids must be 1-D")
+        if ids.dtype != np.int64 or ids.strides[0] % 8 or ids.strides[0] < 0:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+        m = int(ids.shape[0])
+        total = m * (m - 1) // 2
+        if k_count is None:
+            k_count = total - k_begin
+        out_d = np.zeros(k_count, dtype=np.float64) if want_dist else None
+        out_m = np.zeros(k_count, dtype=np.int32) if want_mrca else None
+        bad = ctypes.c_int64(0)
+        rc = self._lib.st_triangle_host(self.handle, _ptr(ids) if m else None, m,
+                                        ids.strides[0] // 8 if m else 1, int(k_begin), int(k_count),
+                                        _ptr(out_d), _ptr(out_m), ctypes.byref(bad))
+        check(rc, tree_size=self.size, bad_id=int(bad.value))
+        return out_d, out_m
+
+    def triangle_device(self, d_ids, m, k_begin, k_count, d_out_dist=0, d_out_mrca=0, stream=0, id_stride=1):
+        rc = self._lib.st_triangle_device(self.handle, ctypes.c_void_p(d_ids), int(m), int(id_stride),
+                                          int(k_begin), int(k_count), ctypes.c_void_p(d_out_dist or None),
+                                          ctypes.c_void_p(d_out_mrca or None), ctypes.c_void_p(stream or None))
+        check(rc)
 
     def distances_device(self, d_pairs, n, d_out_dist=0, d_out_mrca=0, stream=0, stride0=2, stride1=1):
         """Raw device pointers (ints); enqueues on ``stream`` without synchronising."""

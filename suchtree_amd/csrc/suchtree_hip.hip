@@ -63,19 +63,49 @@ __device__ __forceinline__ void record_fault(Fault *f, long long a, long long b,
     if (b < 0 || b >= n_nodes) { atomicMax(&f->max_bad, b); atomicMin(&f->min_bad, b); }
 }
 
-template <bool CONTIG>
-__device__ __forceinline__ void load_pair(const long long *__restrict__ pairs, long long i,
-                                          long long s0, long long s1, long long &a, long long &b)
-{
-    if (CONTIG) {
-        const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];   // one 16-byte load per lane
+// ---- pair sources: where pair number i of a launch comes from ----------------
+// C-order int64 (n,2): one 16-byte load per lane, fully coalesced.
+struct SrcContig {
+    const long long *pairs;
+    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
+    {
+        const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];
         a = v.x;
         b = v.y;
-    } else {
+    }
+};
+
+// Any other (n,2) view: element strides s0 (rows) and s1 (columns).
+struct SrcStrided {
+    const long long *pairs;
+    long long s0, s1;
+    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
+    {
         a = pairs[i * s0];
         b = pairs[i * s0 + s1];
     }
-}
+};
+
+// All-pairs generator: pair k = (ids[j], ids[i]) with k = i(i-1)/2 + j, 0 <= j < i,
+// the enumeration of SuchLinkedTrees.linked_distances (MuchTree.pyx:2918-2925) and, up to
+// order, of pairwise_distances (:1111-1114).  Nothing is read but the id list: within a
+// wave b = ids[i] is (nearly) uniform and a = ids[j] walks the list, so the record reads
+// of consecutive lanes fall on consecutive sectors.
+struct SrcTriangle {
+    const long long *ids;
+    long long stride;   // element stride of ids
+    long long k0;       // first pair index of this launch
+    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
+    {
+        const long long k = k0 + i;
+        long long row = (long long)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
+        if (row * (row - 1) / 2 > k) row--;
+        if ((row + 1) * row / 2 <= k) row++;
+        const long long col = k - row * (row - 1) / 2;
+        a = ids[col * stride];
+        b = ids[row * stride];
+    }
+};
 
 __device__ __forceinline__ void store_result(double *__restrict__ out_d, int *__restrict__ out_m,
                                              long long i, float d, int m)
@@ -93,16 +123,15 @@ struct WalkParams {
     long long n_nodes;
 };
 
-template <bool CONTIG>
-__global__ __launch_bounds__(256) void k_walk(WalkParams P, const long long *__restrict__ pairs,
-                                              long long n, long long s0, long long s1,
+template <typename Src>
+__global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n,
                                               double *__restrict__ out_d, int *__restrict__ out_m,
                                               Fault *fault)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         long long a, b;
-        load_pair<CONTIG>(pairs, i, s0, s1, a, b);
+        src.load(i, a, b);
         if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
             (unsigned long long)b >= (unsigned long long)P.n_nodes) {
             record_fault(fault, a, b, P.n_nodes);
@@ -119,7 +148,7 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, const long long *__r
 }
 
 // --------------------------------------------------------------------------
-// canopy kernel
+// canopy kernels
 // --------------------------------------------------------------------------
 struct CanopyParams {
     const CanopyEntry *canopy;     // [canopy_nodes] global copy, staged to LDS
@@ -134,32 +163,33 @@ struct CanopyParams {
 
 constexpr int kCanopyBlock = 1024;
 
-// CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 selects the
-// generic form that reads b's chain through a pointer.
-template <int CAP, bool CONTIG>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P,
-                                                         const long long *__restrict__ pairs,
-                                                         long long n, long long s0, long long s1,
+// stage the canopy image into LDS: 16 bytes (two entries) per lane per step, coalesced
+__device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned char *lds_raw)
+{
+    const int n16 = (P.canopy_nodes + 1) / 2;
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.canopy);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+    for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+}
+
+// Scalar form (one pair per lane).  CAP = chain slots per record (rec_bytes = 8*(CAP+1));
+// CAP == 0 is the generic form for records longer than 128 bytes, which reads b's chain
+// through a pointer.
+template <int CAP, typename Src>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src, long long n,
                                                          double *__restrict__ out_d,
                                                          int *__restrict__ out_m, Fault *fault)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     CanopyEntry *can = reinterpret_cast<CanopyEntry *>(lds_raw);
-
-    // stage the canopy: 16 bytes (two entries) per lane per step, coalesced
-    {
-        const int n16 = (P.canopy_nodes + 1) / 2;
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.canopy);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
-    }
-    __syncthreads();
+    stage_canopy(P, lds_raw);
 
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         long long a, b;
-        load_pair<CONTIG>(pairs, i, s0, s1, a, b);
+        src.load(i, a, b);
         if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
             (unsigned long long)b >= (unsigned long long)P.n_nodes) {
             record_fault(fault, a, b, P.n_nodes);
@@ -208,32 +238,20 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P,
     }
 }
 
-
-// Same computation with PPL pairs in flight per lane.  The kernel is bound by
-// latency (an HBM round for the pair, one for the two records, then a chain of
-// dependent LDS reads), not by LDS or VALU throughput, so every lane carries
-// PPL independent pairs: their record loads are issued together and their
-// canopy climbs advance in the same loop iteration as independent LDS reads.
-// All updates are predicated selects (a finished climb keeps re-reading its
+// Same computation with PPL pairs in flight per lane.  Every lane carries PPL independent
+// pairs: their pair and record loads are issued together and their canopy climbs advance in
+// the same loop iteration as independent ds_read_b64 (low word = dist bits, high word =
+// parent index).  All updates are predicated selects (a finished climb keeps re-reading its
 // meeting node), so the PPL chains never serialise behind a branch.
-template <int CAP, int PPL, bool CONTIG>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P,
-                                                             const long long *__restrict__ pairs,
-                                                             long long n, long long s0, long long s1,
+template <int CAP, int PPL, typename Src>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              double *__restrict__ out_d,
                                                              int *__restrict__ out_m, Fault *fault)
 {
     static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    // one ds_read_b64 per climb step: low word = dist bits, high word = parent index
     const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
-    {
-        const int n16 = (P.canopy_nodes + 1) / 2;
-        const uint4 *src = reinterpret_cast<const uint4 *>(P.canopy);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
-    }
-    __syncthreads();
+    stage_canopy(P, lds_raw);
 
     constexpr int rec_bytes = 8 * (CAP + 1);
     const bool parity = P.parity != 0;
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P,
             const long long i = base + (long long)j * blockDim.x + threadIdx.x;
             live[j] = i < n;
             idx[j] = live[j] ? i : n - 1;
-            load_pair<CONTIG>(pairs, idx[j], s0, s1, ida[j], idb[j]);
+            src.load(idx[j], ida[j], idb[j]);
         }
         bool any_bad = false;
 #pragma unroll
@@ -393,7 +411,9 @@ struct st_tree {
     void *ws_pairs = nullptr;
     void *ws_dist = nullptr;
     void *ws_mrca = nullptr;
-    int64_t ws_cap = 0;   // pairs
+    void *ws_ids = nullptr;
+    int64_t ws_cap = 0;       // pairs
+    int64_t ws_ids_cap = 0;   // ids
     hipStream_t ws_stream = nullptr;
 };
 
@@ -405,10 +425,10 @@ static size_t canopy_lds_bytes(const st_tree *t)
     return (size_t)((t->canopy_nodes + 1) / 2) * 16;
 }
 
-template <typename Kern>
+template <typename Kern, typename Src>
 static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
-                                  const int64_t *pairs, int64_t n, int64_t s0, int64_t s1,
-                                  double *out_d, int32_t *out_m, hipStream_t stream)
+                                  const Src &src, int64_t n, double *out_d, int32_t *out_m,
+                                  hipStream_t stream)
 {
     const size_t lds = canopy_lds_bytes(t);
     if (lds > 64 * 1024) {
@@ -423,36 +443,34 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     int64_t blocks = (n + tile - 1) / tile;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
     blocks = std::max<int64_t>(blocks, 1);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P,
-                       reinterpret_cast<const long long *>(pairs), (long long)n, (long long)s0,
-                       (long long)s1, out_d, out_m, t->d_fault);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
+                       (long long)n, out_d, out_m, t->d_fault);
     return hipGetLastError();
 }
 
-template <int CAP, bool CONTIG>
-static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const int64_t *pairs,
-                                  int64_t n, int64_t s0, int64_t s1, double *out_d, int32_t *out_m,
-                                  hipStream_t stream)
+template <int CAP, typename Src>
+static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
+                                  double *out_d, int32_t *out_m, hipStream_t stream)
 {
     if constexpr (CAP == 0) {
-        return launch_canopy_k(k_canopy<0, CONTIG>, 1, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, stream);
     } else {
         switch (t->pairs_per_lane) {
-            case 0: return launch_canopy_k(k_canopy<CAP, CONTIG>, 1, t, P, pairs, n, s0, s1, out_d, out_m, stream);
-            case 1: return launch_canopy_k(k_canopy_ilp<CAP, 1, CONTIG>, 1, t, P, pairs, n, s0, s1, out_d, out_m, stream);
-            case 2: return launch_canopy_k(k_canopy_ilp<CAP, 2, CONTIG>, 2, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+            case 0: return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, stream);
+            case 1: return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, stream);
+            case 2: return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, stream);
             default:
                 if constexpr (CAP >= 15)   // 4 x 15 chain registers would spill
-                    return launch_canopy_k(k_canopy_ilp<CAP, 2, CONTIG>, 2, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+                    return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, stream);
                 else
-                    return launch_canopy_k(k_canopy_ilp<CAP, 4, CONTIG>, 4, t, P, pairs, n, s0, s1, out_d, out_m, stream);
+                    return launch_canopy_k(k_canopy_ilp<CAP, 4, Src>, 4, t, P, src, n, out_d, out_m, stream);
         }
     }
 }
 
-template <bool CONTIG>
-static hipError_t launch_canopy(const st_tree *t, const int64_t *pairs, int64_t n, int64_t s0,
-                                int64_t s1, double *out_d, int32_t *out_m, hipStream_t stream)
+template <typename Src>
+static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, double *out_d,
+                                int32_t *out_m, hipStream_t stream)
 {
     CanopyParams P;
     P.canopy = t->d_canopy;
@@ -464,17 +482,17 @@ static hipError_t launch_canopy(const st_tree *t, const int64_t *pairs, int64_t 
     P.rec_bytes = t->rec_bytes;
     P.parity = t->parity;
     switch (t->rec_cap) {
-        case 1: return launch_canopy_t<1, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
-        case 3: return launch_canopy_t<3, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
-        case 7: return launch_canopy_t<7, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
-        case 15: return launch_canopy_t<15, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
-        default: return launch_canopy_t<0, CONTIG>(t, P, pairs, n, s0, s1, out_d, out_m, stream);
+        case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, stream);
+        case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, stream);
+        case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, stream);
+        case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, stream);
+        default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, stream);
     }
 }
 
-template <bool CONTIG>
-static hipError_t launch_walk(const st_tree *t, const int64_t *pairs, int64_t n, int64_t s0,
-                              int64_t s1, double *out_d, int32_t *out_m, hipStream_t stream)
+template <typename Src>
+static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, double *out_d,
+                              int32_t *out_m, hipStream_t stream)
 {
     WalkParams P;
     P.nodes = t->d_nodes;
@@ -483,31 +501,33 @@ static hipError_t launch_walk(const st_tree *t, const int64_t *pairs, int64_t n,
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
     blocks = std::max<int64_t>(blocks, 1);
-    hipLaunchKernelGGL(k_walk<CONTIG>, dim3((unsigned)blocks), dim3(256), 0, stream, P,
-                       reinterpret_cast<const long long *>(pairs), (long long)n, (long long)s0,
-                       (long long)s1, out_d, out_m, t->d_fault);
+    hipLaunchKernelGGL(k_walk<Src>, dim3((unsigned)blocks), dim3(256), 0, stream, P, src,
+                       (long long)n, out_d, out_m, t->d_fault);
     return hipGetLastError();
 }
 
 // Small batches are not worth staging 128 KiB of canopy per workgroup.
 constexpr int64_t kCanopyMinPairs = 4096;
 
+template <typename Src>
+static int enqueue_src(st_tree *t, const Src &src, int64_t n, double *d_out, int32_t *d_mrca,
+                       hipStream_t stream)
+{
+    if (n == 0) return ST_OK;
+    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && d_out != nullptr && n >= kCanopyMinPairs;
+    const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, stream)
+                                : launch_walk(t, src, n, d_out, d_mrca, stream);
+    if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    return ST_OK;
+}
+
 static int enqueue(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s0, int64_t s1,
                    double *d_out, int32_t *d_mrca, hipStream_t stream)
 {
-    if (n == 0) return ST_OK;
-    const bool contig = (s0 == 2 && s1 == 1) && ((reinterpret_cast<uintptr_t>(d_pairs) & 15) == 0);
-    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && d_out != nullptr &&
-                        (n >= kCanopyMinPairs || !t->d_nodes);
-    hipError_t e;
-    if (canopy)
-        e = contig ? launch_canopy<true>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream)
-                   : launch_canopy<false>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream);
-    else
-        e = contig ? launch_walk<true>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream)
-                   : launch_walk<false>(t, d_pairs, n, s0, s1, d_out, d_mrca, stream);
-    if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    return ST_OK;
+    const long long *p = reinterpret_cast<const long long *>(d_pairs);
+    if (s0 == 2 && s1 == 1 && (reinterpret_cast<uintptr_t>(d_pairs) & 15) == 0)
+        return enqueue_src(t, SrcContig{p}, n, d_out, d_mrca, stream);
+    return enqueue_src(t, SrcStrided{p, (long long)s0, (long long)s1}, n, d_out, d_mrca, stream);
 }
 
 static int read_fault(st_tree *t, hipStream_t stream, int64_t *bad_id)
@@ -532,6 +552,30 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
     ST_HIP(hipMalloc(reinterpret_cast<void **>(dst), sz));
     if (!src.empty()) ST_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     *bytes += (int64_t)sz;
+    return ST_OK;
+}
+
+constexpr int64_t kHostChunk = (int64_t)1 << 23;   // pairs per host-path chunk
+
+// Per-handle device workspace of the host entry points (caller holds ws_mutex).
+static int ensure_workspace(st_tree *t, int64_t pairs, int64_t ids)
+{
+    if (t->ws_cap < pairs) {
+        (void)hipFree(t->ws_pairs); (void)hipFree(t->ws_dist); (void)hipFree(t->ws_mrca);
+        t->ws_pairs = t->ws_dist = t->ws_mrca = nullptr;
+        t->ws_cap = 0;
+        ST_HIP(hipMalloc(&t->ws_pairs, (size_t)pairs * 16));
+        ST_HIP(hipMalloc(&t->ws_dist, (size_t)pairs * 8));
+        ST_HIP(hipMalloc(&t->ws_mrca, (size_t)pairs * 4));
+        t->ws_cap = pairs;
+    }
+    if (t->ws_ids_cap < ids) {
+        (void)hipFree(t->ws_ids);
+        t->ws_ids = nullptr;
+        t->ws_ids_cap = 0;
+        ST_HIP(hipMalloc(&t->ws_ids, (size_t)std::max<int64_t>(ids, 2) * 8));
+        t->ws_ids_cap = ids;
+    }
     return ST_OK;
 }
 
@@ -650,6 +694,7 @@ void st_tree_destroy(st_tree *t)
     (void)hipFree(t->ws_pairs);
     (void)hipFree(t->ws_dist);
     (void)hipFree(t->ws_mrca);
+    (void)hipFree(t->ws_ids);
     if (t->ws_stream) (void)hipStreamDestroy(t->ws_stream);
     delete t;
 }
@@ -716,15 +761,10 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
     ST_HIP(hipSetDevice(t->device));
     std::lock_guard<std::mutex> lock(t->ws_mutex);
 
-    const int64_t chunk = std::min<int64_t>(n, (int64_t)1 << 23);
-    if (t->ws_cap < chunk) {
-        (void)hipFree(t->ws_pairs); (void)hipFree(t->ws_dist); (void)hipFree(t->ws_mrca);
-        t->ws_pairs = t->ws_dist = t->ws_mrca = nullptr;
-        t->ws_cap = 0;
-        ST_HIP(hipMalloc(&t->ws_pairs, (size_t)chunk * 16));
-        ST_HIP(hipMalloc(&t->ws_dist, (size_t)chunk * 8));
-        ST_HIP(hipMalloc(&t->ws_mrca, (size_t)chunk * 4));
-        t->ws_cap = chunk;
+    const int64_t chunk = std::min<int64_t>(n, kHostChunk);
+    {
+        const int rc = ensure_workspace(t, chunk, 0);
+        if (rc != ST_OK) return rc;
     }
     hipStream_t s = t->ws_stream;
     const bool c_order = (stride0 == 2 && stride1 == 1);
@@ -747,6 +787,63 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
         if (rc != ST_OK) return rc;
         if (out_dist) ST_HIP(hipMemcpyAsync(out_dist + off, t->ws_dist, (size_t)m * 8, hipMemcpyDeviceToHost, s));
         if (out_mrca) ST_HIP(hipMemcpyAsync(out_mrca + off, t->ws_mrca, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        ST_HIP(hipStreamSynchronize(s));
+    }
+    return read_fault(t, s, bad_id);
+}
+
+static int triangle_args(st_tree *t, const int64_t *ids, int64_t m, int64_t k_begin, int64_t k_count,
+                         const void *out_d, const void *out_m)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (m < 0 || k_begin < 0 || k_count < 0) return fail(ST_ERR_ARG, "negative size");
+    if (m > 3000000000LL) return fail(ST_ERR_ARG, "m too large");
+    const int64_t total = m * (m - 1) / 2;
+    if (k_begin + k_count > total) return fail(ST_ERR_ARG, "pair range exceeds m(m-1)/2");
+    if (k_count > 0 && !ids) return fail(ST_ERR_ARG, "ids is NULL");
+    if (!out_d && !out_m) return fail(ST_ERR_ARG, "both outputs are NULL");
+    return ST_OK;
+}
+
+int st_triangle_device(st_tree *t, const int64_t *d_ids, int64_t m, int64_t id_stride,
+                       int64_t k_begin, int64_t k_count, double *d_out_dist, int32_t *d_out_mrca,
+                       void *stream)
+{
+    int rc = triangle_args(t, d_ids, m, k_begin, k_count, d_out_dist, d_out_mrca);
+    if (rc != ST_OK) return rc;
+    ST_HIP(hipSetDevice(t->device));
+    const SrcTriangle src{reinterpret_cast<const long long *>(d_ids), (long long)id_stride, (long long)k_begin};
+    return enqueue_src(t, src, k_count, d_out_dist, d_out_mrca, reinterpret_cast<hipStream_t>(stream));
+}
+
+int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_stride, int64_t k_begin,
+                     int64_t k_count, double *out_dist, int32_t *out_mrca, int64_t *bad_id)
+{
+    int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
+    if (rc != ST_OK) return rc;
+    if (k_count == 0) return ST_OK;
+    ST_HIP(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> lock(t->ws_mutex);
+    rc = ensure_workspace(t, std::min<int64_t>(k_count, kHostChunk), m);
+    if (rc != ST_OK) return rc;
+    hipStream_t s = t->ws_stream;
+    // the id list goes up once (packed), then results stream back chunk by chunk
+    std::vector<int64_t> packed;
+    const int64_t *src_ids = ids;
+    if (id_stride != 1) {
+        packed.resize((size_t)m);
+        for (int64_t i = 0; i < m; i++) packed[(size_t)i] = ids[i * id_stride];
+        src_ids = packed.data();
+    }
+    ST_HIP(hipMemcpyAsync(t->ws_ids, src_ids, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    for (int64_t off = 0; off < k_count; off += kHostChunk) {
+        const int64_t c = std::min(kHostChunk, k_count - off);
+        const SrcTriangle src{static_cast<const long long *>(t->ws_ids), 1, (long long)(k_begin + off)};
+        rc = enqueue_src(t, src, c, out_dist ? static_cast<double *>(t->ws_dist) : nullptr,
+                         out_mrca ? static_cast<int32_t *>(t->ws_mrca) : nullptr, s);
+        if (rc != ST_OK) return rc;
+        if (out_dist) ST_HIP(hipMemcpyAsync(out_dist + off, t->ws_dist, (size_t)c * 8, hipMemcpyDeviceToHost, s));
+        if (out_mrca) ST_HIP(hipMemcpyAsync(out_mrca + off, t->ws_mrca, (size_t)c * 4, hipMemcpyDeviceToHost, s));
         ST_HIP(hipStreamSynchronize(s));
     }
     return read_fault(t, s, bad_id);

@@ -1,0 +1,261 @@
+"""SuchLinkedTrees: two trees and the links between their leaves.
+
+Host-side mirror of the parts of the reference's ``SuchLinkedTrees``
+(/root/reference/SuchTree/MuchTree.pyx:2525-3208) that feed or call the bulk
+distance path: the link table and link list (:2560-2874), subsetting
+(:2876-2898), ``linked_distances`` (:2900-2934) and the adjacency / Laplacian
+assembly (:3081-3145).  The O(L^2) pair enumeration of ``linked_distances``
+never exists in memory here: the kernels derive each pair from its index
+(``st_triangle_host``).  The stochastic sampler (``sample_linked_distances``,
+stateful xorshift RNG) and the igraph export are out of scope.
+"""
+from typing import Dict
+
+import numpy as np
+
+from .suchtree import SuchTree
+
+
+class SuchLinkedTrees:
+    def __init__(self, tree_a, tree_b, link_matrix):
+        # trees: Newick path / string / URL, or existing SuchTree objects (pyx:2592-2609)
+        if isinstance(tree_a, str):
+            self._tree_a = SuchTree(tree_a)
+        elif type(tree_a) == SuchTree:
+            self._tree_a = tree_a
+        else:
+            raise Exception("unknown input for tree", type(tree_a))
+        if isinstance(tree_b, str):
+            self._tree_b = SuchTree(tree_b)
+        elif type(tree_b) == SuchTree:
+            self._tree_b = tree_b
+        else:
+            raise Exception("unknown input for tree", type(tree_b))
+        A, B = self._tree_a, self._tree_b
+
+        # the link matrix (a pandas DataFrame: rows = TreeA leaves, columns = TreeB leaves)
+        if not link_matrix.shape == (A.num_leaves, B.num_leaves):
+            raise Exception("link_matrix shape must match tree leaf counts")
+        if not set(link_matrix.axes[0]) == set(A.leaves.keys()):
+            raise Exception("axis[0] does not match TreeA leaf names")
+        if not set(link_matrix.axes[1]) == set(B.leaves.keys()):
+            raise Exception("axis[1] does not match TreeB leaf names")
+
+        self._row_ids = np.array(list(A.leaves.values()))
+        self._col_ids = np.array(list(B.leaves.values()))
+        self._row_names = list(A.leaves.keys())
+        self._col_names = list(B.leaves.keys())
+        self._n_rows = A.num_leaves
+        self._n_cols = B.num_leaves
+
+        # reverse map for row ids (pyx:2629-2632)
+        self._row_map = np.zeros(A.size, dtype=int)
+        for n, i in enumerate(self._row_ids):
+            self._row_map[i] = n
+        # leaf id -> link-table column (the reference stores it in the leaf's right_child, pyx:1993-2003)
+        self._col_of_leaf_b = {int(leaf): i for i, leaf in enumerate(self._col_ids)}
+        self._row_of_leaf_a = {int(leaf): i for i, leaf in enumerate(self._row_ids)}
+
+        # the link table: per TreeB column (in TreeB leaf order) the linked TreeA leaf ids, in the
+        # row order of the DataFrame (pyx:2637-2653)
+        values = link_matrix.T.reindex(self._col_names)
+        row_leaf = np.array([A.leaves[name] for name in values.columns], dtype=np.int64)
+        mask = values.to_numpy() > 0
+        self._table = [row_leaf[mask[i]] for i in range(self._n_cols)]
+        self._n_links = int(sum(len(c) for c in self._table))
+
+        # by default, the subset is the whole table (pyx:2655-2666)
+        self._subset_a_root = A.root_node
+        self._subset_b_root = B.root_node
+        self._subset_a_size = len(self._row_ids)
+        self._subset_b_size = len(self._col_ids)
+        self._subset_rows = np.array(range(self._subset_a_size))
+        self._subset_columns = np.array(range(self._subset_b_size))
+        self._subset_a_leafs = self._row_ids
+        self._subset_b_leafs = self._col_ids
+        self._np_linklist = np.ndarray((self._n_links, 2), dtype=int)
+        self._subset_n_links = 0
+        self._build_linklist()
+
+    # ------------------------------------------------------------ properties
+    TreeA = property(lambda self: self._tree_a)
+    TreeB = property(lambda self: self._tree_b)
+    n_links = property(lambda self: self._n_links)
+    n_cols = property(lambda self: self._n_cols)
+    n_rows = property(lambda self: self._n_rows)
+    col_ids = property(lambda self: self._col_ids)
+    row_ids = property(lambda self: self._row_ids)
+    col_names = property(lambda self: self._col_names)
+    row_names = property(lambda self: self._row_names)
+    subset_columns = property(lambda self: self._subset_columns)
+    subset_rows = property(lambda self: self._subset_rows)
+    subset_a_leafs = property(lambda self: self._subset_a_leafs)
+    subset_b_leafs = property(lambda self: self._subset_b_leafs)
+    subset_a_size = property(lambda self: self._subset_a_size)
+    subset_b_size = property(lambda self: self._subset_b_size)
+    subset_a_root = property(lambda self: self._subset_a_root)
+    subset_b_root = property(lambda self: self._subset_b_root)
+    subset_n_links = property(lambda self: self._subset_n_links)
+
+    @property
+    def linklist(self) -> np.ndarray:
+        """(n_links, 2) array: column 0 = TreeB leaf id, column 1 = TreeA leaf id (pyx:2838-2874)."""
+        return self._np_linklist[: self._subset_n_links, :]
+
+    @property
+    def linkmatrix(self) -> np.ndarray:
+        """Boolean link matrix of the current subset (pyx:2812-2836)."""
+        table = np.zeros((self._subset_a_size, self._subset_b_size), dtype=bool)
+        in_a = set(int(x) for x in self._subset_a_leafs)
+        for col in self._subset_columns:
+            for m in self._table[col]:
+                if int(m) in in_a:
+                    table[self._row_map[m], col] = True
+        return table
+
+    def _build_linklist(self) -> None:
+        """pyx:2846-2874: columns in subset order; within a column the table order, kept when the
+        TreeA leaf is in the current row subset."""
+        in_a = set(int(x) for x in self._subset_a_leafs)
+        k = 0
+        for col in self._subset_columns:
+            for m in self._table[col]:
+                if int(m) in in_a:
+                    self._np_linklist[k, 0] = self._col_ids[col]
+                    self._np_linklist[k, 1] = m
+                    k += 1
+        self._subset_n_links = k
+
+    def get_column_leafs(self, col, as_row_ids=False) -> np.ndarray:
+        col_id = self._col_names.index(col) if isinstance(col, str) else col
+        if col_id > self._n_cols:
+            raise Exception("col_id out of bounds", col_id)
+        column = np.array(self._table[col_id], dtype=int)
+        return self._row_map[column] if as_row_ids else column
+
+    def get_column_links(self, col) -> np.ndarray:
+        col_id = self._col_names.index(col) if isinstance(col, str) else col
+        if col_id > self._n_cols:
+            raise Exception("col_id out of bounds", col_id)
+        column = np.zeros(self._n_rows, dtype=bool)
+        column[self._row_map[np.array(self._table[col_id], dtype=int)]] = True
+        return column
+
+    # ------------------------------------------------------------- subsetting
+    @staticmethod
+    def _leaves_below(tree: SuchTree, node_id: int) -> np.ndarray:
+        """Breadth-first leaf order of the reference's get_leaves (pyx:427-462)."""
+        left, right = tree._flat.left, tree._flat.right
+        to_visit = [int(node_id)]
+        out = []
+        for cur in to_visit:
+            if left[cur] == -1:
+                out.append(cur)
+            else:
+                to_visit.append(int(left[cur]))
+                to_visit.append(int(right[cur]))
+        return np.array(out, dtype=int)
+
+    def subset_b(self, node_id) -> None:
+        """Subset the link matrix to leaves descended from node_id in TreeB (pyx:2876-2886)."""
+        if node_id > self._tree_b.size or node_id < 0:
+            raise Exception("Node ID out of bounds.", node_id)
+        self._subset_b_leafs = self._leaves_below(self._tree_b, node_id)
+        self._subset_columns = np.array([self._col_of_leaf_b[int(x)] for x in self._subset_b_leafs], dtype=int)
+        self._subset_b_size = len(self._subset_columns)
+        self._subset_b_root = node_id
+        self._build_linklist()
+
+    def subset_a(self, node_id) -> None:
+        """Subset the link matrix to leaves descended from node_id in TreeA (pyx:2888-2898)."""
+        if node_id > self._tree_a.size or node_id < 0:
+            raise Exception("Node ID out of bounds.", node_id)
+        self._subset_a_leafs = self._leaves_below(self._tree_a, node_id)
+        self._subset_rows = np.array([self._row_of_leaf_a[int(x)] for x in self._subset_a_leafs], dtype=int)
+        self._subset_a_size = len(self._subset_rows)
+        self._subset_a_root = node_id
+        self._build_linklist()
+
+    # ----------------------------------------------------- the distance caller
+    def linked_distances(self) -> Dict[str, object]:
+        """Distances in both trees for all pairs of links (pyx:2900-2934).
+
+        Pair k = i(i-1)/2 + j (j < i) is (link j, link i): in TreeA the leaves
+        ``(linklist[j,1], linklist[i,1])``, in TreeB ``(linklist[j,0], linklist[i,0])``.
+        The id arrays are returned like the reference does, but the distances do not
+        depend on them being materialised: each tree's kernel launch generates its pairs
+        from the link-list column.
+        """
+        ll = np.ascontiguousarray(self.linklist, dtype=np.int64)
+        L = ll.shape[0]
+        size = (L * (L - 1)) // 2
+        d_a, _ = self._tree_a._device_tree().triangle_host(ll[:, 1])
+        d_b, _ = self._tree_b._device_tree().triangle_host(ll[:, 0])
+        rows, cols = np.tril_indices(L, -1)
+        ids_a = np.stack([ll[cols, 1], ll[rows, 1]], axis=1)
+        ids_b = np.stack([ll[cols, 0], ll[rows, 0]], axis=1)
+        return {"TreeA": d_a, "TreeB": d_b, "ids_A": ids_a, "ids_B": ids_b,
+                "n_pairs": size, "n_samples": size, "deviation_a": None, "deviation_b": None}
+
+    # ------------------------------------------- adjacency / Laplacian assembly
+    @staticmethod
+    def _tree_adjacency(tree: SuchTree, from_node):
+        """SuchTree.adjacency_matrix (pyx:1750-1813) for the subtree below from_node."""
+        flat = tree._flat
+        to_visit = [int(from_node)]
+        for cur in to_visit:
+            if flat.left[cur] != -1:
+                to_visit.append(int(flat.left[cur]))
+                to_visit.append(int(flat.right[cur]))
+        node_ids = np.array(to_visit)
+        index = {int(n): i for i, n in enumerate(node_ids)}
+        adj = np.zeros((len(node_ids), len(node_ids)), dtype=float)
+        for i, n in enumerate(node_ids):
+            p = int(flat.parent[n])
+            if p == -1 or p not in index:
+                continue
+            d = float(flat.distance[n])
+            if d == 0:
+                d += tree.polytomy_epsilon
+            adj[i, index[p]] = d
+            adj[index[p], i] = d
+        return adj, node_ids
+
+    def adjacency(self, deletions=0, additions=0, swaps=0) -> np.ndarray:
+        """Graph adjacency matrix of both (subsetted) trees plus the link edges (pyx:3081-3131)."""
+        ta_aj, ta_ids = self._tree_adjacency(self._tree_a, self._subset_a_root)
+        tb_aj, tb_ids = self._tree_adjacency(self._tree_b, self._subset_b_root)
+        ta_node_ids, tb_node_ids = ta_ids.tolist(), tb_ids.tolist()
+        ll = np.array(self.linklist)
+        for _ in range(1, deletions):
+            ll = np.delete(ll, np.random.randint(len(ll)), axis=0)
+        for _ in range(1, swaps):
+            x, y = np.random.choice(range(len(ll)), size=2, replace=False)
+            ll[x, 1], ll[y, 1] = ll[y, 1], ll[x, 1]
+        for _ in range(1, additions):
+            a = np.random.choice(list(self._tree_a.leaves.values()))
+            b = np.random.choice(list(self._tree_b.leaves.values()))
+            ll = np.concatenate((ll, np.array([[b, a]])), axis=0)
+        ta_links = [ta_node_ids.index(x) for x in ll[:, 1]]
+        tb_links = [tb_node_ids.index(x) + ta_aj.shape[0] for x in ll[:, 0]]
+        aj = np.zeros((ta_aj.shape[0] + tb_aj.shape[0], ta_aj.shape[1] + tb_aj.shape[1]))
+        aj[0:ta_aj.shape[0], 0:ta_aj.shape[1]] = ta_aj / ta_aj.max()
+        aj[ta_aj.shape[0]:, ta_aj.shape[1]:] = tb_aj / tb_aj.max()
+        ta_mean = np.mean(ta_aj.flatten()[ta_aj.flatten() > self._tree_a.polytomy_epsilon])
+        tb_mean = np.mean(tb_aj.flatten()[tb_aj.flatten() > self._tree_b.polytomy_epsilon])
+        link_mean = (ta_mean / ta_aj.max() + tb_mean / tb_aj.max()) / 2.0
+        for i, j in zip(tb_links, ta_links):
+            aj[i, j] = link_mean
+            aj[j, i] = link_mean
+        return aj
+
+    def laplacian(self, deletions=0, additions=0, swaps=0) -> np.ndarray:
+        """Graph Laplacian L = D - A of the current subset (pyx:3133-3145)."""
+        aj = self.adjacency(deletions=deletions, additions=additions, swaps=swaps)
+        lp = np.zeros(aj.shape)
+        np.fill_diagonal(lp, aj.sum(axis=0))
+        return lp - aj
+
+    def spectrum(self, deletions=0, additions=0, swaps=0) -> np.ndarray:
+        """Eigenvalues of the Laplacian (the reference calls LAPACK dsyev, pyx:3147-3173)."""
+        return np.linalg.eigvalsh(self.laplacian(deletions=deletions, additions=additions, swaps=swaps))

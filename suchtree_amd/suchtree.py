@@ -301,6 +301,60 @@ class SuchTree:
         _, mrca = self._device_tree().distances_host(pairs, want_dist=False, want_mrca=True)
         return int(mrca[0])
 
+    # ------------------------------------------- callers of the path (all-pairs, kNN)
+    def _node_ids(self, nodes) -> np.ndarray:
+        if nodes is None:
+            return self.leaf_node_ids
+        return np.array([self._validate_node(node) for node in nodes])
+
+    def pairwise_distances(self, nodes: List[Union[int, str]] = None) -> np.ndarray:
+        """Symmetric matrix of all pairwise distances (MuchTree.pyx:1084-1124).
+
+        The reference materialises the n(n-1)/2 pairs as a Python list and calls
+        ``distances_bulk``; here the pairs are generated on the device
+        (``st_triangle_host``).  Entry [i, j] with i < j is d(ids[i], ids[j]) in that
+        argument order, exactly as the reference computes it, mirrored to [j, i].
+        """
+        node_ids = self._node_ids(nodes)
+        n = len(node_ids)
+        distance_matrix = np.zeros((n, n), dtype=float)
+        if n > 1:
+            tri, _ = self._device_tree().triangle_host(np.asarray(node_ids, dtype=np.int64))
+            rows, cols = np.tril_indices(n, -1)       # k = i(i-1)/2 + j order
+            distance_matrix[rows, cols] = tri
+            distance_matrix[cols, rows] = tri
+        return distance_matrix
+
+    def distance_matrix(self, nodes: list = None) -> dict:
+        """MuchTree.pyx:1919-1956."""
+        if nodes is None:
+            node_ids = self.leaf_node_ids
+            node_names = [self.leaf_nodes[nid] for nid in node_ids]
+        else:
+            node_ids = np.array([self._validate_node(node) for node in nodes])
+            node_names = [self.leaf_nodes[int(i)] if self.is_leaf(int(i)) else f"node_{i}" for i in node_ids]
+        return {"distance_matrix": self.pairwise_distances(nodes), "node_ids": node_ids,
+                "node_names": node_names}
+
+    def nearest_neighbors(self, node: Union[int, str], k: int = 1, from_nodes: list = None) -> list:
+        """k nearest neighbours of a node (MuchTree.pyx:1032-1082)."""
+        if k <= 0:
+            raise ValueError("k must be positive")
+        query_node_id = self._validate_node(node)
+        if from_nodes is None:
+            if self.is_leaf(query_node_id):
+                from_node_ids = [nid for nid in self.leaf_node_ids if nid != query_node_id]
+            else:
+                from_node_ids = self.leaf_node_ids
+            from_nodes_orig = [self.leaf_nodes[nid] for nid in from_node_ids]
+        else:
+            from_node_ids = [self._validate_node(n) for n in from_nodes]
+            from_nodes_orig = from_nodes.copy()
+        pairs = [(query_node_id, nid) for nid in from_node_ids]
+        distances = self.distances_bulk(np.array(pairs, dtype=np.int64))
+        sorted_indices = np.argsort(distances)
+        return [(from_nodes_orig[i], distances[i]) for i in sorted_indices[:k]]
+
     # deprecated wrappers (MuchTree.pyx:2447-2459)
     def distances(self, pairs):
         _deprecation_warning("distances()", "distances_bulk()")

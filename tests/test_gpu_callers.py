@@ -1,0 +1,127 @@
+"""Callers either side of the hot path, on the GPU: the all-pairs generator
+(pairwise_distances / distance_matrix / nearest_neighbors; BASELINE config 4 at reduced
+size) and SuchLinkedTrees.linked_distances (config 5)."""
+import json
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy.stats import pearsonr
+
+from conftest import assert_bits_equal, golden_path
+from oracle.oracle import OracleTree, linked_pairs
+from suchtree_amd import InvalidNodeError, SuchTree, _capi, sharding, synth
+from suchtree_amd.linked import SuchLinkedTrees
+
+pytestmark = pytest.mark.gpu
+KNOWN = json.load(open(golden_path("known_answers.json")))
+
+
+def _tri_pairs(ids):
+    rows, cols = np.tril_indices(len(ids), -1)
+    return np.stack([ids[cols], ids[rows]], axis=1).astype(np.int64)
+
+
+@pytest.mark.parametrize("strategy", ["walk", "canopy"])
+def test_triangle_generator_equals_explicit_pairs(strategy, ml_arrays):
+    parent, dist, leaf_ids = ml_arrays
+    dev = _capi.DeviceTree(parent, dist)
+    dev.set_strategy(strategy)
+    O = OracleTree(parent, dist)
+    ids = np.random.default_rng(4).choice(leaf_ids, size=700, replace=False)
+    pairs = _tri_pairs(ids)
+    want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
+    for ppl in (0, 1, 2, 4):
+        dev.set_option("pairs_per_lane", ppl)
+        d, m = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+        assert_bits_equal(d, want_d, "ppl%d" % ppl)
+        assert np.array_equal(m, want_m)
+    # any k-range gives the matching slice (what multi-GPU sharding and tiling rely on)
+    total = len(pairs)
+    for g in range(3):
+        lo, hi = sharding.triangle_shard_bounds(len(ids), 3, g)
+        d, m = dev.triangle_host(ids, k_begin=lo, k_count=hi - lo, want_dist=True, want_mrca=True)
+        assert_bits_equal(d, want_d[lo:hi])
+        assert np.array_equal(m, want_m[lo:hi])
+    assert sharding.triangle_shard_bounds(len(ids), 3, 2)[1] == total
+    # strided id list (a link-list column), empty and single-id lists
+    wide = np.zeros((len(ids), 2), dtype=np.int64)
+    wide[:, 1] = ids
+    assert_bits_equal(dev.triangle_host(wide[:, 1])[0], want_d)
+    assert dev.triangle_host(ids[:1])[0].shape == (0,)
+    assert dev.triangle_host(ids[:0])[0].shape == (0,)
+    with pytest.raises(InvalidNodeError):
+        dev.triangle_host(np.array([0, 2, len(parent) + 1]))
+    dev.close()
+
+
+def test_config4_all_pairs_reduced_size():
+    """Config 4 is the full lower triangle of a 100k-leaf tree (5e9 pairs); here a
+    6000-leaf slice of that workload (1.8e7 pairs) against the oracle on a sample, plus
+    size-independent properties on the whole triangle."""
+    parent, dist = synth.random_binary_tree(100_000, seed=44)
+    dev = _capi.DeviceTree(parent, dist)
+    O = OracleTree(parent, dist)
+    ids = np.arange(0, 12_000, 2, dtype=np.int64) + 40_000          # 6000 consecutive leaves
+    d, m = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+    assert len(d) == 6000 * 5999 // 2
+    pairs = _tri_pairs(ids)
+    pick = np.random.default_rng(0).integers(0, len(pairs), 300_000)
+    assert_bits_equal(d[pick], O.distances(pairs[pick]))
+    assert np.array_equal(m[pick], O.mrca_bulk(pairs[pick]))
+    # in-order ids: the MRCA of leaves a < b lies strictly between them
+    assert np.all((m > pairs[:, 0]) & (m < pairs[:, 1]))
+    dev.set_strategy("walk")
+    d2, m2 = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+    assert_bits_equal(d2, d)
+    assert np.array_equal(m2, m)
+    dev.close()
+
+
+def test_pairwise_distance_matrix_and_neighbors():
+    T = SuchTree(golden_path("test.tree"))
+    O = OracleTree(T._flat.parent, T._flat.distance)
+    D = T.pairwise_distances()
+    n = T.num_leaves
+    assert D.shape == (n, n) and np.array_equal(D, D.T) and np.all(np.diag(D) == 0)
+    ids = T.leaf_node_ids
+    for i in range(n):
+        for j in range(i + 1, n):
+            assert D[i, j] == O.distance(int(ids[i]), int(ids[j]))      # d(ids[i], ids[j]), i < j
+    names = {r[0] + r[1]: float(r[2]) for r in (line.split() for line in open(golden_path("test.matrix")))}
+    leaf_names = T.leaf_names
+    for i in range(n):
+        for j in range(n):
+            assert D[i, j] == pytest.approx(names[leaf_names[i] + leaf_names[j]], rel=1e-3, abs=1e-9)
+    sub = T.pairwise_distances(["Ttal", "Tbot", 27, 3])
+    assert sub.shape == (4, 4) and sub[0, 1] == O.distance(26, 28) and sub[2, 3] == O.distance(27, 3)
+    assert T.pairwise_distances(["Ttal"]).shape == (1, 1)
+    dm = T.distance_matrix(["Ttal", 27])
+    assert dm["node_names"] == ["Ttal", "node_27"] and dm["node_ids"].tolist() == [26, 27]
+    nn = T.nearest_neighbors("Ttal", k=3)
+    want = sorted(((O.distance(26, int(i)), T.leaf_nodes[int(i)]) for i in ids if i != 26))[:3]
+    assert [x[0] for x in nn] == [w[1] for w in want] and [x[1] for x in nn] == [w[0] for w in want]
+    with pytest.raises(ValueError, match="k must be positive"):
+        T.nearest_neighbors("Ttal", k=0)
+
+
+@pytest.mark.parametrize("which", ["gopher_louse", "fish_worm"])
+def test_config5_linked_distances(which):
+    d = golden_path(which)
+    names = ("gopher.tree", "lice.tree") if which == "gopher_louse" else ("host.tree", "guest.tree")
+    links = pd.read_csv(d + "/links.csv", index_col=0)
+    SLT = SuchLinkedTrees(SuchTree(d + "/" + names[0]), SuchTree(d + "/" + names[1]), links)
+    res = SLT.linked_distances()
+    L = SLT.n_links
+    assert res["n_pairs"] == res["n_samples"] == L * (L - 1) // 2 == len(res["TreeA"]) == len(res["TreeB"])
+    ids_a, ids_b = linked_pairs(SLT.linklist)                       # oracle: MuchTree.pyx:2918-2925
+    assert np.array_equal(res["ids_A"], ids_a) and np.array_equal(res["ids_B"], ids_b)
+    OA = OracleTree(SLT.TreeA._flat.parent, SLT.TreeA._flat.distance)
+    OB = OracleTree(SLT.TreeB._flat.parent, SLT.TreeB._flat.distance)
+    assert_bits_equal(res["TreeA"], OA.distances(ids_a))
+    assert_bits_equal(res["TreeB"], OB.distances(ids_b))
+    if which == "gopher_louse":
+        r = pearsonr(res["TreeA"], res["TreeB"])[0]
+        assert abs(r - KNOWN["gopher_louse_linked_distances"]["pearson_r"]) < 1e-6
+    else:
+        assert L == 191 and res["n_pairs"] == 18145

@@ -1,0 +1,98 @@
+"""SuchLinkedTrees host bookkeeping (link table, link list, subsetting, adjacency /
+Laplacian assembly) against the answers printed in the reference's notebooks, with the
+oracle standing in for the distance step (no GPU here)."""
+import json
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy.stats import pearsonr
+
+from conftest import golden_path
+from oracle.oracle import OracleTree, linked_pairs
+from suchtree_amd import SuchTree
+from suchtree_amd.linked import SuchLinkedTrees
+
+KNOWN = json.load(open(golden_path("known_answers.json")))
+
+
+def _gopher_louse():
+    d = golden_path("gopher_louse")
+    links = pd.read_csv(d + "/links.csv", index_col=0)
+    return SuchLinkedTrees(SuchTree(d + "/gopher.tree"), SuchTree(d + "/lice.tree"), links), links
+
+
+def _fish_worm():
+    d = golden_path("fish_worm")
+    links = pd.read_csv(d + "/links.csv", index_col=0)
+    return SuchLinkedTrees(SuchTree(d + "/host.tree"), SuchTree(d + "/guest.tree"), links), links
+
+
+def test_gopher_louse_linklist_matches_notebook():
+    SLT, links = _gopher_louse()
+    assert SLT.n_links == 17 and (SLT.n_rows, SLT.n_cols) == (15, 17)
+    got = set(map(tuple, SLT.linklist.tolist()))
+    assert got == set(map(tuple, KNOWN["gopher_louse_linklist"]["value"]))
+    # column 0 = TreeB (louse) leaf ids in TreeB leaf order, column 1 = TreeA (gopher) leaf ids
+    assert SLT.linklist[:, 0].tolist() == sorted(SLT.linklist[:, 0].tolist())
+    assert set(SLT.linklist[:, 1]) <= set(SLT.TreeA.leaves.values())
+    assert SLT.linkmatrix.sum() == 17 and SLT.linkmatrix.shape == (15, 17)
+    lm = links.loc[SLT.row_names, SLT.col_names].to_numpy() > 0
+    assert np.array_equal(SLT.linkmatrix, lm)
+
+
+def test_gopher_louse_linked_distances_statistics_match_notebook():
+    """pearsonr over the 136 link pairs printed by the reference: 0.490184989...  The
+    notebook predates the float32 left-to-right accumulator (its docstring still describes
+    root-distance differences), so the last digits differ; 1e-6 is the stated bar."""
+    SLT, _ = _gopher_louse()
+    ids_a, ids_b = linked_pairs(SLT.linklist)
+    assert len(ids_a) == 136
+    OA = OracleTree(SLT.TreeA._flat.parent, SLT.TreeA._flat.distance)
+    OB = OracleTree(SLT.TreeB._flat.parent, SLT.TreeB._flat.distance)
+    r = pearsonr(OA.distances(ids_a), OB.distances(ids_b))[0]
+    assert abs(r - KNOWN["gopher_louse_linked_distances"]["pearson_r"]) < 1e-6
+
+
+def test_fish_worm_sizes_and_laplacian_shape():
+    SLT, _ = _fish_worm()
+    k = KNOWN["fish_worm_sizes"]
+    assert (SLT.n_links, SLT.TreeA.num_leaves, SLT.TreeB.num_leaves) == (k["links"], k["hosts"], k["guests"])
+    aj = SLT.adjacency()
+    assert aj.shape == (41 + 381, 41 + 381)
+    assert np.allclose(aj, aj.T) and aj.max() == pytest.approx(1.0)
+    lp = SLT.laplacian()
+    assert np.allclose(lp.sum(axis=0), 0) and np.allclose(np.diag(lp), aj.sum(axis=0))
+    # tree blocks carry 40 + 380 edges, the off-diagonal block the 191 links
+    assert (aj[:41, :41] > 0).sum() == 2 * 40 and (aj[41:, 41:] > 0).sum() == 2 * 380
+    assert (aj[41:, :41] > 0).sum() == 191
+    ev = SLT.spectrum()
+    assert ev.shape == (422,) and abs(ev[0]) < 1e-9
+
+
+def test_subsetting():
+    SLT, links = _gopher_louse()
+    A = SLT.TreeA
+    node = A.get_parent(A.leaves["Oche"])
+    node = A.get_parent(node)                      # a clade with several gophers
+    SLT.subset_a(node)
+    leaves = set(SLT.subset_a_leafs.tolist())
+    assert SLT.subset_a_root == node and SLT.subset_a_size == len(leaves) >= 3
+    assert all(int(x) in leaves for x in SLT.linklist[:, 1])
+    assert SLT.subset_n_links == sum(1 for b, a in KNOWN["gopher_louse_linklist"]["value"] if a in leaves)
+    SLT.subset_a(A.root_node)
+    assert SLT.subset_n_links == 17
+    B = SLT.TreeB
+    SLT.subset_b(B.get_parent(B.leaf_node_ids[0]))
+    assert SLT.subset_b_size == 2 and SLT.subset_n_links == 2
+
+
+def test_constructor_checks():
+    SLT, links = _gopher_louse()
+    with pytest.raises(Exception, match="link_matrix shape"):
+        SuchLinkedTrees(SLT.TreeA, SLT.TreeB, links.iloc[:, :5])
+    with pytest.raises(Exception, match="unknown input"):
+        SuchLinkedTrees(3, SLT.TreeB, links)
+    bad = links.rename(index={links.index[0]: "nobody"})
+    with pytest.raises(Exception, match="TreeA leaf names"):
+        SuchLinkedTrees(SLT.TreeA, SLT.TreeB, bad)
