@@ -176,11 +176,23 @@ class DeviceTree:
     def set_option(self, name, value):
         check(self._lib.st_tree_set_option(self.handle, name.encode(), int(value)))
 
-    def distances_host(self, pairs, want_dist=True, want_mrca=False):
-        """pairs: int64 (n,2) ndarray with any strides (multiples of 8 bytes)."""
+    @staticmethod
+    def _out(buf, n, dtype, want):
+        if not want:
+            return None
+        if buf is None:
+            return np.empty(n, dtype=dtype)
+        if buf.dtype != dtype or buf.shape != (n,) or not buf.flags.c_contiguous:
+            raise ValueError("output buffer must be a contiguous %s array of shape (%d,)" % (np.dtype(dtype).name, n))
+        return buf
+
+    def distances_host(self, pairs, want_dist=True, want_mrca=False, out_dist=None, out_mrca=None):
+        """pairs: int64 (n,2) ndarray with any strides (multiples of 8 bytes).
+        ``out_dist`` / ``out_mrca``: optional preallocated result arrays (reused buffers
+        avoid the page-fault cost of fresh memory on every call)."""
         n = int(pairs.shape[0])
-        out_d = np.zeros(n, dtype=np.float64) if want_dist else None
-        out_m = np.zeros(n, dtype=np.int32) if want_mrca else None
+        out_d = self._out(out_dist, n, np.float64, want_dist)
+        out_m = self._out(out_mrca, n, np.int32, want_mrca)
         if n == 0:
             return out_d, out_m
         if pairs.strides[0] % 8 or pairs.strides[1] % 8:
@@ -195,7 +207,8 @@ class DeviceTree:
         check(rc, tree_size=self.size, bad_id=int(bad.value))
         return out_d, out_m
 
-    def triangle_host(self, ids, k_begin=0, k_count=None, want_dist=True, want_mrca=False):
+    def triangle_host(self, ids, k_begin=0, k_count=None, want_dist=True, want_mrca=False,
+                      out_dist=None, out_mrca=None):
         """Lower-triangle all-pairs over ``ids`` (1-D int64): pair k = (ids[j], ids[i]),
         k = i(i-1)/2 + j; returns the slice [k_begin, k_begin + k_count)."""
         ids = np.asarray(ids)
@@ -207,8 +220,8 @@ class DeviceTree:
         total = m * (m - 1) // 2
         if k_count is None:
             k_count = total - k_begin
-        out_d = np.zeros(k_count, dtype=np.float64) if want_dist else None
-        out_m = np.zeros(k_count, dtype=np.int32) if want_mrca else None
+        out_d = self._out(out_dist, k_count, np.float64, want_dist)
+        out_m = self._out(out_mrca, k_count, np.int32, want_mrca)
         bad = ctypes.c_int64(0)
         rc = self._lib.st_triangle_host(self.handle, _ptr(ids) if m else None, m,
                                         ids.strides[0] // 8 if m else 1, int(k_begin), int(k_count),

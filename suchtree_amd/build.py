@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsuchtree_hip.so")
 SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep.cpp")]
 HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
+           os.path.join(CSRC, "host_pipe.h"),
            os.path.join(HERE, "..", "include", "suchtree_hip.h")]
 
 FLAGS = [
@@ -44,7 +45,7 @@ def build(force=False, verbose=False, extra=()):
     if not force and not stale():
         return LIB
     cmd = [hipcc()] + FLAGS + list(extra) + ["-I", os.path.join(HERE, "..", "include"),
-                                            "-o", LIB] + SOURCES + ["-Wl,-rpath,/opt/rocm/lib"]
+                                            "-o", LIB] + SOURCES + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/suchtree_hip.h"
+#include "host_pipe.h"
 #include "pair_math.h"
 #include "tree_prep.h"
 
@@ -406,15 +407,9 @@ struct st_tree {
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 2;   // tuning: 0 = scalar reference kernel, 1/2/4 = ILP kernel
-    // workspace of the host entry point
+    // staging of the host entry points (one caller at a time per handle)
     std::mutex ws_mutex;
-    void *ws_pairs = nullptr;
-    void *ws_dist = nullptr;
-    void *ws_mrca = nullptr;
-    void *ws_ids = nullptr;
-    int64_t ws_cap = 0;       // pairs
-    int64_t ws_ids_cap = 0;   // ids
-    hipStream_t ws_stream = nullptr;
+    HostPipe pipe;
 };
 
 static const Fault kFaultInit = {std::numeric_limits<long long>::min(),
@@ -555,26 +550,69 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
     return ST_OK;
 }
 
-constexpr int64_t kHostChunk = (int64_t)1 << 23;   // pairs per host-path chunk
+constexpr int64_t kHostChunk = (int64_t)1 << 22;   // pairs per pipeline chunk
 
-// Per-handle device workspace of the host entry points (caller holds ws_mutex).
-static int ensure_workspace(st_tree *t, int64_t pairs, int64_t ids)
+// Push n pairs through the two-slot pipe (host_pipe.h).  pack(slot, off, m) fills
+// slot.h_in for chunk [off, off+m) (skipped when has_input is false: generated pairs);
+// launch(slot, off, m) enqueues the kernel on slot.stream reading slot.d_in and writing
+// slot.d_d / slot.d_m.  Caller holds ws_mutex.
+template <typename Pack, typename Launch>
+static int run_pipe(st_tree *t, int64_t n, bool has_input, Pack pack, Launch launch,
+                    double *out_dist, int32_t *out_mrca)
 {
-    if (t->ws_cap < pairs) {
-        (void)hipFree(t->ws_pairs); (void)hipFree(t->ws_dist); (void)hipFree(t->ws_mrca);
-        t->ws_pairs = t->ws_dist = t->ws_mrca = nullptr;
-        t->ws_cap = 0;
-        ST_HIP(hipMalloc(&t->ws_pairs, (size_t)pairs * 16));
-        ST_HIP(hipMalloc(&t->ws_dist, (size_t)pairs * 8));
-        ST_HIP(hipMalloc(&t->ws_mrca, (size_t)pairs * 4));
-        t->ws_cap = pairs;
+    HostPipe &P = t->pipe;
+    const int64_t chunk = std::min<int64_t>(n, kHostChunk);
+    {
+        const hipError_t e = P.ensure(std::max<int64_t>(chunk, 1024));
+        if (e != hipSuccess) {
+            P.release_buffers();
+            return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
+        }
     }
-    if (t->ws_ids_cap < ids) {
-        (void)hipFree(t->ws_ids);
-        t->ws_ids = nullptr;
-        t->ws_ids_cap = 0;
-        ST_HIP(hipMalloc(&t->ws_ids, (size_t)std::max<int64_t>(ids, 2) * 8));
-        t->ws_ids_cap = ids;
+    auto drain = [&](PipeSlot &s) -> hipError_t {
+        if (!s.busy) return hipSuccess;
+        s.busy = false;
+        const hipError_t e = hipEventSynchronize(s.done);
+        if (e != hipSuccess) return e;
+        if (out_dist) P.pool.copy(out_dist + s.off, s.h_d, s.m * 8);
+        if (out_mrca) P.pool.copy(out_mrca + s.off, s.h_m, s.m * 4);
+        return hipSuccess;
+    };
+    auto bail = [&](int code, const std::string &msg) {
+        for (auto &s : P.slot) {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            s.busy = false;
+        }
+        return fail(code, msg);
+    };
+    int64_t c = 0;
+    for (int64_t off = 0; off < n; off += chunk, c++) {
+        const int64_t m = std::min(chunk, n - off);
+        PipeSlot &s = P.slot[c & 1];
+        hipError_t e = drain(s);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
+        if (has_input) {
+            pack(s, off, m);
+            e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * 16, hipMemcpyHostToDevice, s.stream);
+            if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e));
+        }
+        const int rc = launch(s, off, m);
+        if (rc != ST_OK) return bail(rc, g_last_error);
+        if (out_dist && e == hipSuccess)
+            e = hipMemcpyAsync(s.h_d, s.d_d, (size_t)m * 8, hipMemcpyDeviceToHost, s.stream);
+        if (out_mrca && e == hipSuccess)
+            e = hipMemcpyAsync(s.h_m, s.d_m, (size_t)m * 4, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+        s.busy = true;
+        s.off = off;
+        s.m = m;
+        e = drain(P.slot[(c + 1) & 1]);   // unpack the previous chunk while this one is in flight
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
+    }
+    for (auto &s : P.slot) {
+        const hipError_t e = drain(s);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
     return ST_OK;
 }
@@ -658,7 +696,6 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
     if (rc == ST_OK) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), sizeof(Fault));
         if (e == hipSuccess) e = hipMemcpy(t->d_fault, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&t->ws_stream, hipStreamNonBlocking);
         if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
     }
     if (rc != ST_OK) {
@@ -691,11 +728,7 @@ void st_tree_destroy(st_tree *t)
     (void)hipFree(t->d_canopy_id);
     (void)hipFree(t->d_records);
     (void)hipFree(t->d_fault);
-    (void)hipFree(t->ws_pairs);
-    (void)hipFree(t->ws_dist);
-    (void)hipFree(t->ws_mrca);
-    (void)hipFree(t->ws_ids);
-    if (t->ws_stream) (void)hipStreamDestroy(t->ws_stream);
+    t->pipe.destroy();
     delete t;
 }
 
@@ -761,35 +794,30 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
     ST_HIP(hipSetDevice(t->device));
     std::lock_guard<std::mutex> lock(t->ws_mutex);
 
-    const int64_t chunk = std::min<int64_t>(n, kHostChunk);
-    {
-        const int rc = ensure_workspace(t, chunk, 0);
-        if (rc != ST_OK) return rc;
-    }
-    hipStream_t s = t->ws_stream;
     const bool c_order = (stride0 == 2 && stride1 == 1);
-    std::vector<int64_t> gather;
-    for (int64_t off = 0; off < n; off += chunk) {
-        const int64_t m = std::min(chunk, n - off);
+    CopyPool &pool = t->pipe.pool;
+    auto pack = [&](PipeSlot &s, int64_t off, int64_t m) {
         const int64_t *src = pairs + off * stride0;
-        if (!c_order) {
-            gather.resize((size_t)m * 2);
-            for (int64_t k = 0; k < m; k++) {
-                gather[(size_t)(2 * k)] = src[k * stride0];
-                gather[(size_t)(2 * k + 1)] = src[k * stride0 + stride1];
-            }
-            src = gather.data();
+        int64_t *dst = static_cast<int64_t *>(s.h_in);
+        if (c_order) {
+            pool.copy(dst, src, m * 16);
+        } else {
+            pool.parallel_for(m, [=](int64_t b, int64_t e) {
+                for (int64_t k = b; k < e; k++) {
+                    dst[2 * k] = src[k * stride0];
+                    dst[2 * k + 1] = src[k * stride0 + stride1];
+                }
+            });
         }
-        ST_HIP(hipMemcpyAsync(t->ws_pairs, src, (size_t)m * 16, hipMemcpyHostToDevice, s));
-        int rc = enqueue(t, static_cast<const int64_t *>(t->ws_pairs), m, 2, 1,
-                         out_dist ? static_cast<double *>(t->ws_dist) : nullptr,
-                         out_mrca ? static_cast<int32_t *>(t->ws_mrca) : nullptr, s);
-        if (rc != ST_OK) return rc;
-        if (out_dist) ST_HIP(hipMemcpyAsync(out_dist + off, t->ws_dist, (size_t)m * 8, hipMemcpyDeviceToHost, s));
-        if (out_mrca) ST_HIP(hipMemcpyAsync(out_mrca + off, t->ws_mrca, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-        ST_HIP(hipStreamSynchronize(s));
-    }
-    return read_fault(t, s, bad_id);
+    };
+    auto launch = [&](PipeSlot &s, int64_t, int64_t m) {
+        return enqueue(t, static_cast<const int64_t *>(s.d_in), m, 2, 1,
+                       out_dist ? static_cast<double *>(s.d_d) : nullptr,
+                       out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
+    };
+    const int rc = run_pipe(t, n, true, pack, launch, out_dist, out_mrca);
+    if (rc != ST_OK) return rc;
+    return read_fault(t, t->pipe.slot[0].stream, bad_id);
 }
 
 static int triangle_args(st_tree *t, const int64_t *ids, int64_t m, int64_t k_begin, int64_t k_count,
@@ -824,10 +852,12 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     if (k_count == 0) return ST_OK;
     ST_HIP(hipSetDevice(t->device));
     std::lock_guard<std::mutex> lock(t->ws_mutex);
-    rc = ensure_workspace(t, std::min<int64_t>(k_count, kHostChunk), m);
-    if (rc != ST_OK) return rc;
-    hipStream_t s = t->ws_stream;
-    // the id list goes up once (packed), then results stream back chunk by chunk
+    {
+        hipError_t e = t->pipe.ensure(std::max<int64_t>(std::min<int64_t>(k_count, kHostChunk), 1024));
+        if (e == hipSuccess) e = t->pipe.ensure_ids(m);
+        if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
+    }
+    // the id list goes up once (packed); results stream back through the pipe
     std::vector<int64_t> packed;
     const int64_t *src_ids = ids;
     if (id_stride != 1) {
@@ -835,18 +865,16 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
         for (int64_t i = 0; i < m; i++) packed[(size_t)i] = ids[i * id_stride];
         src_ids = packed.data();
     }
-    ST_HIP(hipMemcpyAsync(t->ws_ids, src_ids, (size_t)m * 8, hipMemcpyHostToDevice, s));
-    for (int64_t off = 0; off < k_count; off += kHostChunk) {
-        const int64_t c = std::min(kHostChunk, k_count - off);
-        const SrcTriangle src{static_cast<const long long *>(t->ws_ids), 1, (long long)(k_begin + off)};
-        rc = enqueue_src(t, src, c, out_dist ? static_cast<double *>(t->ws_dist) : nullptr,
-                         out_mrca ? static_cast<int32_t *>(t->ws_mrca) : nullptr, s);
-        if (rc != ST_OK) return rc;
-        if (out_dist) ST_HIP(hipMemcpyAsync(out_dist + off, t->ws_dist, (size_t)c * 8, hipMemcpyDeviceToHost, s));
-        if (out_mrca) ST_HIP(hipMemcpyAsync(out_mrca + off, t->ws_mrca, (size_t)c * 4, hipMemcpyDeviceToHost, s));
-        ST_HIP(hipStreamSynchronize(s));
-    }
-    return read_fault(t, s, bad_id);
+    ST_HIP(hipMemcpy(t->pipe.d_ids, src_ids, (size_t)m * 8, hipMemcpyHostToDevice));
+    auto pack = [](PipeSlot &, int64_t, int64_t) {};
+    auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
+        const SrcTriangle src{static_cast<const long long *>(t->pipe.d_ids), 1, (long long)(k_begin + off)};
+        return enqueue_src(t, src, c, out_dist ? static_cast<double *>(s.d_d) : nullptr,
+                           out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
+    };
+    rc = run_pipe(t, k_count, false, pack, launch, out_dist, out_mrca);
+    if (rc != ST_OK) return rc;
+    return read_fault(t, t->pipe.slot[0].stream, bad_id);
 }
 
 int st_device_malloc(int device, int64_t bytes, void **out)
