@@ -103,9 +103,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL code path is used even with one rank,
+    # so that it can be exercised on a 1-GPU box
+    distributed = "RANK" in os.environ or world > 1
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from suchtree_amd import _capi, synth
     parent, dist = synth.balanced_tree(args.levels)
@@ -126,7 +130,7 @@ def main():
         tree.distances_device(pairs.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist_.barrier()
 
     for _ in range(args.warmup):
@@ -146,7 +150,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -161,7 +165,7 @@ def main():
     checksum = float(out_d.sum().item())
 
     gather_ms = None
-    if world > 1 and not args.no_gather:
+    if distributed and not args.no_gather:
         # the north star's "final gather" of result shards over xGMI (untimed, reported)
         all_d = torch.empty(world * n, dtype=torch.float64, device=device)
         all_m = torch.empty(world * n, dtype=torch.int32, device=device)
@@ -209,7 +213,7 @@ def main():
             line["cpu_baseline"] = cpu
             line["parity"] = parity
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist_.barrier()
         dist_.destroy_process_group()
     tree.close()

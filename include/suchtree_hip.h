@@ -130,6 +130,16 @@ int st_triangle_host(st_tree *tree, const int64_t *ids, int64_t m, int64_t id_st
                      int64_t k_begin, int64_t k_count,
                      double *out_dist, int32_t *out_mrca, int64_t *bad_id);
 
+/*
+ * Quartet topologies: for each row (a,b,c,d) of the int64 (n,4) view the row re-ordered so
+ * that columns (0,1) and (2,3) are the sister pairs.  Replaces
+ * SuchTree._quartet_topologies (SuchTree/MuchTree.pyx:1331-1376) as called by
+ * quartet_topologies_bulk (:1271-1329).  out_topologies is C-order int64 (n,4).
+ */
+int st_quartets_host(st_tree *tree, const int64_t *quartets, int64_t n,
+                     int64_t stride0, int64_t stride1,
+                     int64_t *out_topologies, int64_t *bad_id);
+
 /* Select the kernel family for subsequent calls (tests / benchmarking).
  * ST_ERR_ARG if the tree was built without that family's tables. */
 int st_tree_set_strategy(st_tree *tree, int strategy);

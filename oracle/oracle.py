@@ -62,6 +62,8 @@ def lib():
         L.oracle_mrca_bulk.restype = None
         L.oracle_linked_pairs.argtypes = [vp, i64, vp, vp]
         L.oracle_linked_pairs.restype = None
+        L.oracle_quartets.argtypes = [vp, i64, vp, vp, vp]
+        L.oracle_quartets.restype = None
         L.oracle_distances_mt.argtypes = [vp, i64, i64, vp, i64, i64, vp, i32]
         L.oracle_distances_mt.restype = i32
         _lib = L
@@ -124,6 +126,14 @@ class OracleTree:
         if ids.shape[0]:
             lib().oracle_mrca_bulk(_p(self.nodes), ids.shape[0], _p(self._visited()),
                                    _p(ids), s0, s1, _p(out))
+        return out
+
+    def quartets(self, quartets):
+        q = np.ascontiguousarray(quartets, dtype=np.int64)
+        assert q.ndim == 2 and q.shape[1] == 4
+        out = np.zeros_like(q)
+        if q.shape[0]:
+            lib().oracle_quartets(_p(self.nodes), q.shape[0], _p(self._visited()), _p(q), _p(out))
         return out
 
     def distances_mt(self, pairs, n_threads):

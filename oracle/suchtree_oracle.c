@@ -20,6 +20,7 @@
  *                            has no bulk MRCA; the oracle for bulk MRCA ids
  *                            is a loop over the scalar call)
  *   linked_distances pairs . SuchTree/MuchTree.pyx:2918-2925
+ *   _quartet_topologies .... SuchTree/MuchTree.pyx:1331-1376
  *
  * Pinning: the reference extension cannot be imported in the build
  * container (hard `import dendropy` at MuchTree.pyx:3; dendropy is not
@@ -196,6 +197,34 @@ void oracle_linked_pairs(const int64_t *linklist, int64_t n_links,
             ids_b[2 * k + 0] = linklist[2 * j + 0];
             k++;
         }
+}
+
+/* MuchTree.pyx:1331-1376 -- quartet topologies with the table I of :1319-1320. */
+void oracle_quartets(const oracle_node *data, int64_t n, int64_t *visited,
+                     const int64_t *quartets, int64_t *topologies)
+{
+    static const int I[6][4] = {{0, 1, 2, 3}, {0, 2, 1, 3}, {0, 3, 1, 2},
+                                {1, 2, 0, 3}, {1, 3, 0, 2}, {2, 3, 0, 1}};
+    int64_t M[6], C[6];
+    for (int64_t i = 0; i < n; i++) {
+        int a = (int)quartets[4 * i], b = (int)quartets[4 * i + 1];
+        int c = (int)quartets[4 * i + 2], d = (int)quartets[4 * i + 3];
+        int j, k;
+        M[0] = oracle_mrca(data, visited, a, b);
+        M[1] = oracle_mrca(data, visited, a, c);
+        M[2] = oracle_mrca(data, visited, a, d);
+        M[3] = oracle_mrca(data, visited, b, c);
+        M[4] = oracle_mrca(data, visited, b, d);
+        M[5] = oracle_mrca(data, visited, c, d);
+        for (j = 0; j < 6; j++) C[j] = 0;
+        for (j = 0; j < 6; j++)
+            for (k = 0; k < 6; k++)
+                if (M[j] == M[k]) C[j] = C[j] + 1;
+        for (j = 0; j < 6; j++)
+            if (C[j] == 1) break;
+        if (j == 6) j = 5;   /* Cython's range loop leaves the last value in j */
+        for (k = 0; k < 4; k++) topologies[4 * i + k] = quartets[4 * i + I[j][k]];
+    }
 }
 
 /* ---- "host cores" baseline ------------------------------------------------

@@ -23,6 +23,7 @@ SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host",
+    "st_quartets_host",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
@@ -84,6 +85,7 @@ def load():
         L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
         L.st_triangle_device.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, vp]
         L.st_triangle_host.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
+        L.st_quartets_host.argtypes = [vp, vp, i64, i64, i64, vp, ctypes.POINTER(i64)]
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
         L.st_device_free.argtypes = [i32, vp]
@@ -228,6 +230,20 @@ class DeviceTree:
                                         _ptr(out_d), _ptr(out_m), ctypes.byref(bad))
         check(rc, tree_size=self.size, bad_id=int(bad.value))
         return out_d, out_m
+
+    def quartets_host(self, quartets):
+        """quartets: int64 (n,4) ndarray (any non-negative strides); returns int64 (n,4)."""
+        n = int(quartets.shape[0])
+        out = np.empty((n, 4), dtype=np.int64)
+        if n == 0:
+            return out
+        if quartets.strides[0] % 8 or quartets.strides[1] % 8 or quartets.strides[0] < 0 or quartets.strides[1] < 0:
+            quartets = np.ascontiguousarray(quartets)
+        bad = ctypes.c_int64(0)
+        rc = self._lib.st_quartets_host(self.handle, _ptr(quartets), n, quartets.strides[0] // 8,
+                                        quartets.strides[1] // 8, _ptr(out), ctypes.byref(bad))
+        check(rc, tree_size=self.size, bad_id=int(bad.value))
+        return out
 
     def triangle_device(self, d_ids, m, k_begin, k_count, d_out_dist=0, d_out_mrca=0, stream=0, id_stride=1):
         rc = self._lib.st_triangle_device(self.handle, ctypes.c_void_p(d_ids), int(m), int(id_stride),

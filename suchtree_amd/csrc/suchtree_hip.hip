@@ -148,6 +148,56 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
     }
 }
 
+// Quartet topologies (MuchTree.pyx:1331-1376): six MRCAs per quartet (ab ac ad bc bd cd),
+// the first MRCA id that occurs exactly once names the sister pair; the row is re-ordered
+// by the matching line of the table I = {0123, 0213, 0312, 1203, 1302, 2301}.  If no id is
+// unique the reference's loop leaves j = 5, reproduced here.  Integer work only.
+__global__ __launch_bounds__(256) void k_quartets(WalkParams P, const long long *__restrict__ q,
+                                                  long long n, long long s0, long long s1,
+                                                  long long *__restrict__ out, Fault *fault)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long id[4];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            id[k] = q[i * s0 + k * s1];
+            ok &= (unsigned long long)id[k] < (unsigned long long)P.n_nodes;
+        }
+        if (!ok) {
+            record_fault(fault, id[0], id[1], P.n_nodes);
+            record_fault(fault, id[2], id[3], P.n_nodes);
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[i * 4 + k] = -1;
+            continue;
+        }
+        const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+        int M[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            M[j] = pair_walk_mrca(P.nodes, P.depth, (int32_t)id[pa[j]], (int32_t)id[pb[j]]);
+        int pick = 5;
+#pragma unroll
+        for (int j = 5; j >= 0; j--) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) c += M[j] == M[k];
+            if (c == 1) pick = j;
+        }
+        // I[pick] = {pa, pb, the other two in increasing order}
+        const int a = pa[pick], b = pb[pick];
+        int rest[2], r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k != a && k != b) { if (r < 2) rest[r] = k; r++; }
+        out[i * 4 + 0] = id[a];
+        out[i * 4 + 1] = id[b];
+        out[i * 4 + 2] = id[rest[0]];
+        out[i * 4 + 3] = id[rest[1]];
+    }
+}
+
 // --------------------------------------------------------------------------
 // canopy kernels
 // --------------------------------------------------------------------------
@@ -875,6 +925,48 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     rc = run_pipe(t, k_count, false, pack, launch, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     return read_fault(t, t->pipe.slot[0].stream, bad_id);
+}
+
+int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t stride0, int64_t stride1,
+                     int64_t *out_topologies, int64_t *bad_id)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n < 0) return fail(ST_ERR_ARG, "n < 0");
+    if (n > 0 && (!quartets || !out_topologies)) return fail(ST_ERR_ARG, "quartets or output is NULL");
+    if (n == 0) return ST_OK;
+    ST_HIP(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> lock(t->ws_mutex);
+    // (n,4) int64 in and out are each the size of two pair rows: reuse the pipe's slots,
+    // input in d_in/h_in of slot 0 and 1 back to back is not possible, so stage by halves:
+    const int64_t chunk = std::min<int64_t>(n, kHostChunk / 2);
+    {
+        const hipError_t e = t->pipe.ensure(std::max<int64_t>(2 * chunk, 1024));
+        if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
+    }
+    PipeSlot &in = t->pipe.slot[0], &out = t->pipe.slot[1];
+    WalkParams P;
+    P.nodes = t->d_nodes;
+    P.depth = t->d_depth;
+    P.n_nodes = t->n_nodes;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        int64_t *h = static_cast<int64_t *>(in.h_in);
+        const int64_t *src = quartets + off * stride0;
+        t->pipe.pool.parallel_for(m, [=](int64_t b, int64_t e) {
+            for (int64_t k = b; k < e; k++)
+                for (int c = 0; c < 4; c++) h[4 * k + c] = src[k * stride0 + c * stride1];
+        });
+        ST_HIP(hipMemcpyAsync(in.d_in, in.h_in, (size_t)m * 32, hipMemcpyHostToDevice, in.stream));
+        int64_t blocks = std::min<int64_t>((m + 255) / 256, (int64_t)t->n_cu * 16);
+        hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, in.stream, P,
+                           static_cast<const long long *>(in.d_in), (long long)m, 4LL, 1LL,
+                           static_cast<long long *>(out.d_in), t->d_fault);
+        ST_HIP(hipGetLastError());
+        ST_HIP(hipMemcpyAsync(out.h_in, out.d_in, (size_t)m * 32, hipMemcpyDeviceToHost, in.stream));
+        ST_HIP(hipStreamSynchronize(in.stream));
+        t->pipe.pool.copy(out_topologies + off * 4, out.h_in, m * 32);
+    }
+    return read_fault(t, in.stream, bad_id);
 }
 
 int st_device_malloc(int device, int64_t bytes, void **out)

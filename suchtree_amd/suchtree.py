@@ -355,6 +355,47 @@ class SuchTree:
         sorted_indices = np.argsort(distances)
         return [(from_nodes_orig[i], distances[i]) for i in sorted_indices[:k]]
 
+    # --------------------------------------------------- quartet topologies (MRCA caller)
+    def quartet_topologies_bulk(self, quartets) -> np.ndarray:
+        """(n, 4) node ids re-ordered so columns (0,1) and (2,3) are sisters (MuchTree.pyx:1271-1376)."""
+        if not isinstance(quartets, np.ndarray):
+            quartets = np.array(quartets, dtype=np.int64)
+        if quartets.ndim != 2 or quartets.shape[1] != 4:
+            raise ValueError(f"Expected (n, 4) array, got shape {quartets.shape}")
+        if quartets.dtype != np.int64:
+            if not np.issubdtype(quartets.dtype, np.integer):
+                raise ValueError("Buffer dtype mismatch, expected 'long' but got '%s'" % quartets.dtype.name)
+            quartets = quartets.astype(np.int64)
+        if quartets.shape[0] == 0:
+            quartets.max()
+        return self._device_tree().quartets_host(quartets)
+
+    def quartet_topology(self, a, b, c, d) -> frozenset:
+        """Topology of one quartet as a frozenset of two sister-pair frozensets (MuchTree.pyx:1202-1248)."""
+        nodes = [a, b, c, d]
+        node_ids = [self._validate_node(node) for node in nodes]
+        has_strings = any(isinstance(node, str) for node in nodes)
+        w, x, y, z = (int(v) for v in self.quartet_topologies_bulk(np.array([node_ids], dtype=np.int64))[0])
+        if has_strings:
+            ln = self.leaf_nodes
+            return frozenset((frozenset((ln[w], ln[x])), frozenset((ln[y], ln[z]))))
+        return frozenset((frozenset((w, x)), frozenset((y, z))))
+
+    def quartet_topologies_by_name(self, quartets) -> list:
+        """MuchTree.pyx:1378-1422."""
+        quartet_ids = []
+        for i, (a, b, c, d) in enumerate(quartets):
+            if not all(isinstance(name, str) for name in (a, b, c, d)):
+                raise TypeError(f"Quartet {i}: all elements must be strings")
+            try:
+                quartet_ids.append([self.leaves[a], self.leaves[b], self.leaves[c], self.leaves[d]])
+            except KeyError as e:
+                raise NodeNotFoundError(str(e).strip("'"))
+        topologies = self.quartet_topologies_bulk(np.array(quartet_ids, dtype=np.int64))
+        ln = self.leaf_nodes
+        return [frozenset((frozenset((ln[a], ln[b])), frozenset((ln[c], ln[d]))))
+                for a, b, c, d in topologies.tolist()]
+
     # deprecated wrappers (MuchTree.pyx:2447-2459)
     def distances(self, pairs):
         _deprecation_warning("distances()", "distances_bulk()")

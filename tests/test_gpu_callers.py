@@ -125,3 +125,29 @@ def test_config5_linked_distances(which):
         assert abs(r - KNOWN["gopher_louse_linked_distances"]["pearson_r"]) < 1e-6
     else:
         assert L == 191 and res["n_pairs"] == 18145
+
+
+def test_quartet_topologies(ml_arrays):
+    parent, dist, leaf_ids = ml_arrays
+    T = SuchTree((parent, dist))
+    O = OracleTree(parent, dist)
+    rng = np.random.default_rng(8)
+    q = rng.choice(leaf_ids, size=(60_000, 4))
+    got = T.quartet_topologies_bulk(q)
+    assert got.dtype == np.int64 and got.shape == q.shape
+    assert np.array_equal(got, O.quartets(q))
+    assert np.array_equal(np.sort(got, axis=1), np.sort(q, axis=1))
+    qi = rng.integers(0, len(parent), (20_000, 4))             # internal nodes, repeated ids
+    assert np.array_equal(T.quartet_topologies_bulk(qi), O.quartets(qi))
+    assert np.array_equal(T.quartet_topologies_bulk(np.asfortranarray(q[:5000])), O.quartets(q[:5000]))
+    with pytest.raises(ValueError, match=r"Expected \(n, 4\) array"):
+        T.quartet_topologies_bulk(np.zeros((3, 3), dtype=np.int64))
+    with pytest.raises(InvalidNodeError):
+        T.quartet_topologies_bulk(np.array([[0, 2, 4, len(parent)]]))
+    G = SuchTree(golden_path("test.tree"))
+    topo = G.quartet_topology("Oche", "Ocav", "Ohet", "Ound")
+    assert topo == frozenset((frozenset(("Oche", "Ohet")), frozenset(("Ocav", "Ound"))))
+    assert G.quartet_topology(0, 4, 2, 6) == frozenset((frozenset((0, 2)), frozenset((4, 6))))
+    by_name = G.quartet_topologies_by_name([("Oche", "Ocav", "Ohet", "Ound"), ("Ttal", "Oche", "Tbot", "Ohet")])
+    assert by_name[0] == topo
+    assert by_name[1] == frozenset((frozenset(("Ttal", "Tbot")), frozenset(("Oche", "Ohet"))))

@@ -140,3 +140,19 @@ def test_linked_pairs_order():
     a, b = linked_pairs(ll)
     assert a.tolist() == [[0, 2], [0, 4], [2, 4], [0, 6], [2, 6], [4, 6]]
     assert b.tolist() == [[10, 11], [10, 12], [11, 12], [10, 13], [11, 13], [12, 13]]
+
+
+def test_quartet_topologies_restatement():
+    """MuchTree.pyx:1331-1376: the sister pair is the one whose MRCA id is unique among the six."""
+    from itertools import permutations
+    t = flat_tree_from_newick("(((A,B),C),(D,E));")
+    O = OracleTree(t.parent, t.distance)
+    L = t.leaves
+    for perm in permutations("ABCD"):
+        row = O.quartets(np.array([[L[x] for x in perm]]))[0].tolist()
+        assert {frozenset(row[:2]), frozenset(row[2:])} == {frozenset((L["A"], L["B"])), frozenset((L["C"], L["D"]))}
+    row = O.quartets(np.array([[L["D"], L["A"], L["E"], L["C"]]]))[0].tolist()
+    assert {frozenset(row[:2]), frozenset(row[2:])} == {frozenset((L["D"], L["E"])), frozenset((L["A"], L["C"]))}
+    # the output row is a permutation of the input row, by the table at :1319-1320
+    q = np.array([[L["B"], L["D"], L["A"], L["E"]]])
+    assert O.quartets(q)[0].tolist() == [L["B"], L["A"], L["D"], L["E"]]
