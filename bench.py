@@ -198,12 +198,24 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None if not traffic else traffic.get("hbm_bytes_per_launch"),
-                         "kernel": "k_canopy" if info["strategy"] == "canopy" else "k_walk",
+                         "kernel": "k_canopy_ilp" if info["strategy"] == "canopy" else "k_walk",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_pair": bytes_per_pair,
-                         "mean_path_edges": h_mean, "pairs_per_launch": n},
+                         "mean_path_edges": h_mean, "pairs_per_launch": n,
+                         "note": "achieved = algorithmic bytes of the reference's walk (28 + 8*h per pair, SURVEY 8d) / "
+                                 "kernel time. The canopy kernel does not move those bytes (climb in LDS, understory "
+                                 "pre-summed): frac > 1 is expected. Its real ceiling is the chip's random 64-B-sector "
+                                 "read rate, see random_sector below and DESIGN.md section 5.2."},
             "kernel_pairs_per_s_per_gpu": n / (kernel_ms * 1e-3),
             "checksum": checksum,
         }
+        if traffic and traffic.get("counters_mean_per_launch", {}).get("TCC_EA0_RDREQ_sum"):
+            # profiled fabric read requests per pair x this run's pair rate, against the measured
+            # ceiling for uniformly random 64-byte-sector reads (profiles/gather_microbench_r01.log)
+            req_per_pair = traffic["counters_mean_per_launch"]["TCC_EA0_RDREQ_sum"] / traffic.get("pairs_per_launch", 1e8)
+            rate = req_per_pair * n / (kernel_ms * 1e-3)
+            line["random_sector"] = {"fabric_reads_per_pair": req_per_pair, "achieved_Greads_per_s": rate / 1e9,
+                                     "ceiling_Greads_per_s": 59.0, "frac": rate / 59.0e9,
+                                     "source": "rocprofv3 TCC_EA0_RDREQ_sum (profiles/) and scripts/micro/gather_bench.hip"}
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:

@@ -55,7 +55,7 @@ def main():
         for r in stats:
             lines.append(",".join(str(r[c]) for c in cols))
     dur = per_kernel_durations(os.path.join(out_dir, "trace"))
-    summary = {"tag": tag, "kernel": kernel, "kernels": {}}
+    summary = {"tag": tag, "kernel": kernel, "kernels": {}, "pairs_per_launch": 1e8}
     for k, v in dur.items():
         v2 = sorted(v)
         summary["kernels"][k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": v2[0], "max_ns": v2[-1]}

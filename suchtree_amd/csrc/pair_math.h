@@ -122,9 +122,9 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
         const CanopyEntry e = can[up_a ? u : v];
         if (up_a) {
             s += e.dist;
-            u = e.parent;
+            u = e.link & kCanopyParentMask;
         } else {
-            v = e.parent;
+            v = e.link & kCanopyParentMask;
         }
     }
     const uint32_t mc = u;
@@ -139,7 +139,7 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
     while (v != mc) {
         const CanopyEntry e = can[v];
         s += e.dist;
-        v = e.parent;
+        v = e.link & kCanopyParentMask;
     }
     PairResult r;
     r.dist = s;

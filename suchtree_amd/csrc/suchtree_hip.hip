@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
 // the same loop iteration as independent ds_read_b64 (low word = dist bits, high word =
 // parent index).  All updates are predicated selects (a finished climb keeps re-reading its
 // meeting node), so the PPL chains never serialise behind a branch.
-template <int CAP, int PPL, typename Src>
+template <int CAP, int PPL, bool LOCKSTEP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              double *__restrict__ out_d,
                                                              int *__restrict__ out_m, Fault *fault)
@@ -372,15 +372,28 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             go = false;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                const bool act = u[j] != v[j];
-                const bool up_a = u[j] > v[j];
-                const unsigned long long e = can[up_a ? u[j] : v[j]];
-                const float e_dist = __uint_as_float((uint32_t)e);
-                const uint32_t e_parent = (uint32_t)(e >> 32);
-                const float s_next = s[j] + e_dist;
-                s[j] = up_a ? s_next : s[j];
-                u[j] = up_a ? e_parent : u[j];
-                v[j] = (act && !up_a) ? e_parent : v[j];
+                if (LOCKSTEP) {
+                    // depth cut inside the canopy: both entries are read every round, the deeper
+                    // side moves (both on a tie), so the climb takes max(ka,kb) rounds, not ka+kb
+                    const unsigned long long eu = can[u[j]], ev = can[v[j]];
+                    const uint32_t lu = (uint32_t)(eu >> 32), lv = (uint32_t)(ev >> 32);
+                    const bool act = u[j] != v[j];
+                    const bool mu = act && (lu >> 16) >= (lv >> 16);
+                    const bool mv = act && (lv >> 16) >= (lu >> 16);
+                    const float s_next = s[j] + __uint_as_float((uint32_t)eu);
+                    s[j] = mu ? s_next : s[j];
+                    u[j] = mu ? (lu & kCanopyParentMask) : u[j];
+                    v[j] = mv ? (lv & kCanopyParentMask) : v[j];
+                } else {
+                    const bool act = u[j] != v[j];
+                    const bool up_a = u[j] > v[j];
+                    const unsigned long long e = can[up_a ? u[j] : v[j]];
+                    const uint32_t e_parent = (uint32_t)(e >> 32) & kCanopyParentMask;
+                    const float s_next = s[j] + __uint_as_float((uint32_t)e);
+                    s[j] = up_a ? s_next : s[j];
+                    u[j] = up_a ? e_parent : u[j];
+                    v[j] = (act && !up_a) ? e_parent : v[j];
+                }
                 go |= u[j] != v[j];
             }
         }
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
                 const unsigned long long e = can[v[j]];
                 const float s_next = s[j] + __uint_as_float((uint32_t)e);
                 s[j] = act ? s_next : s[j];
-                v[j] = act ? (uint32_t)(e >> 32) : v[j];
+                v[j] = act ? ((uint32_t)(e >> 32) & kCanopyParentMask) : v[j];
                 go |= v[j] != u[j];
             }
         }
@@ -457,6 +470,7 @@ struct st_tree {
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 2;   // tuning: 0 = scalar reference kernel, 1/2/4 = ILP kernel
+    int lockstep = 1;         // tuning: canopy climb 1 by depth cut (1) or by "larger index moves" (0)
     // staging of the host entry points (one caller at a time per handle)
     std::mutex ws_mutex;
     HostPipe pipe;
@@ -500,16 +514,20 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, stream);
     } else {
-        switch (t->pairs_per_lane) {
-            case 0: return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, stream);
-            case 1: return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, stream);
-            case 2: return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, stream);
-            default:
-                if constexpr (CAP >= 15)   // 4 x 15 chain registers would spill
-                    return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, stream);
-                else
-                    return launch_canopy_k(k_canopy_ilp<CAP, 4, Src>, 4, t, P, src, n, out_d, out_m, stream);
+        const int ppl = (CAP >= 15 && t->pairs_per_lane > 2) ? 2 : t->pairs_per_lane;   // 4 x 15 chain registers would spill
+        if (ppl == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, stream);
+        if (t->lockstep) {
+            if (ppl == 1) return launch_canopy_k(k_canopy_ilp<CAP, 1, true, Src>, 1, t, P, src, n, out_d, out_m, stream);
+            if (ppl == 2) return launch_canopy_k(k_canopy_ilp<CAP, 2, true, Src>, 2, t, P, src, n, out_d, out_m, stream);
+            if constexpr (CAP < 15)
+                return launch_canopy_k(k_canopy_ilp<CAP, 4, true, Src>, 4, t, P, src, n, out_d, out_m, stream);
+        } else {
+            if (ppl == 1) return launch_canopy_k(k_canopy_ilp<CAP, 1, false, Src>, 1, t, P, src, n, out_d, out_m, stream);
+            if (ppl == 2) return launch_canopy_k(k_canopy_ilp<CAP, 2, false, Src>, 2, t, P, src, n, out_d, out_m, stream);
+            if constexpr (CAP < 15)
+                return launch_canopy_k(k_canopy_ilp<CAP, 4, false, Src>, 4, t, P, src, n, out_d, out_m, stream);
         }
+        return hipErrorInvalidValue;
     }
 }
 
@@ -809,6 +827,11 @@ int st_tree_set_option(st_tree *t, const char *name, int64_t value)
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1, 2 or 4");
         t->pairs_per_lane = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "lockstep") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "lockstep must be 0 or 1");
+        t->lockstep = (int)value;
         return ST_OK;
     }
     return fail(ST_ERR_ARG, std::string("unknown option ") + name);

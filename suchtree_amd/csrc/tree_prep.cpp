@@ -120,7 +120,8 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T)
         int32_t p = parent[x];
         CanopyEntry e;
         e.dist = distance[x];
-        e.parent = p < 0 ? 0u : (uint32_t)cidx[(size_t)p];
+        // a canopy of <= 16384 nodes closed under "parent of" is at most 16383 edges deep
+        e.link = (p < 0 ? 0u : (uint32_t)cidx[(size_t)p]) | ((uint32_t)T.depth[(size_t)x] << 16);
         cidx[(size_t)x] = (int32_t)T.canopy.size();
         T.canopy.push_back(e);
         T.canopy_id.push_back(x);

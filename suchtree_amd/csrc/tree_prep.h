@@ -36,8 +36,9 @@ static_assert(sizeof(Node8) == 8, "Node8 must be 8 bytes");
 
 struct CanopyEntry {
     float dist;        // branch length above this canopy node
-    uint32_t parent;   // canopy index of its parent (root: 0)
+    uint32_t link;     // bits 0..15: canopy index of its parent (root: 0); bits 16..31: depth (edges to the root)
 };
+constexpr uint32_t kCanopyParentMask = 0xFFFFu;
 static_assert(sizeof(CanopyEntry) == 8, "CanopyEntry must be 8 bytes");
 
 // Understory record of R bytes, two halves of R/2:

@@ -282,6 +282,16 @@ class SuchTree:
         if not isinstance(pairs, list):
             raise TypeError("pairs must be a list of tuples")
         leaves = self.leaves
+        try:
+            # fast path: two dict lookups per pair, no per-element checks (keys are str only,
+            # so anything that is not a known leaf name raises here and is diagnosed below)
+            node_pairs = [(leaves[name_a], leaves[name_b]) for name_a, name_b in pairs]
+        except (KeyError, TypeError, ValueError):
+            node_pairs = None
+        if node_pairs is not None:
+            if not node_pairs:
+                node_pairs = np.zeros((0,), dtype=np.int64)   # np.array([]) of the reference: 1-D, fails the shape check
+            return self.distances_bulk(np.array(node_pairs, dtype=np.int64)).tolist()
         node_pairs = []
         for i, (name_a, name_b) in enumerate(pairs):
             if not isinstance(name_a, str) or not isinstance(name_b, str):

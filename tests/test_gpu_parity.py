@@ -29,9 +29,13 @@ def _both(dev, pairs):
         if strategy == "walk":
             out["walk"] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
             continue
-        for ppl in (0, 1, 2, 4):
+        for ppl, lockstep in ((0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (4, 0), (4, 1)):
             dev.set_option("pairs_per_lane", ppl)
-            out["canopy/ppl%d" % ppl] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+            dev.set_option("lockstep", lockstep)
+            out["canopy/ppl%d%s" % (ppl, "" if lockstep else "/index-climb")] = \
+                dev.distances_host(pairs, want_dist=True, want_mrca=True)
+        dev.set_option("pairs_per_lane", 2)
+        dev.set_option("lockstep", 1)
     dev.set_strategy("auto")
     return out
 
