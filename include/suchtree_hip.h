@@ -147,7 +147,10 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
 /* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the
  * canopy kernel keeps in flight: 1, 2 or 4 (default 2); 0 = scalar form.
  * "lockstep": 1 (default) = the climb inside the canopy uses the depth cut (max(ka,kb)
- * rounds), 0 = "larger index moves up" (ka+kb rounds, one LDS read per round). */
+ * rounds), 0 = "larger index moves up" (ka+kb rounds, one LDS read per round).
+ * "flow": 1 = per-lane flow kernel (lanes advance through their own pairs without waiting
+ * for the wave), 0 (default) = wave-synchronous kernels.
+ * "flow_batch": lanes that must be waiting before the flow kernel refills (default 16). */
 int st_tree_set_option(st_tree *tree, const char *name, int64_t value);
 
 /*

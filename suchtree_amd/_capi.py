@@ -62,7 +62,20 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        if not os.path.exists(LIB_PATH) and os.environ.get("SUCHTREE_AMD_AUTOBUILD", "1") != "0":
+            # source checkout without the built library: compile it once (hipcc, gfx950)
+            try:
+                from . import build as _build
+                _build.build()
+            except Exception as e:   # no hipcc / compile error: reported below
+                build_error = e
+            else:
+                build_error = None
+        else:
+            build_error = None
         if not os.path.exists(LIB_PATH):
+            if build_error is not None:
+                raise HipBackendError("libsuchtree_hip.so is not built and building it failed: %s" % build_error)
             raise HipBackendError(
                 "libsuchtree_hip.so is not built (%s). Build it with `python -m suchtree_amd.build` "
                 "(hipcc, gfx950); this package has no CPU fallback." % LIB_PATH)

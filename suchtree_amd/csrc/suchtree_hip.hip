@@ -213,6 +213,7 @@ struct CanopyParams {
 };
 
 constexpr int kCanopyBlock = 1024;
+constexpr int kFlowRounds = 8;   // climb rounds between two control points of the flow kernel
 
 // stage the canopy image into LDS: 16 bytes (two entries) per lane per step, coalesced
 __device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned char *lds_raw)
@@ -446,6 +447,144 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
     }
 }
 
+// "Flow" form for deep canopies (selectable with the "flow" option, off by default).  On
+// trees like data/bigtrees/ml.tree the climb is hundreds of LDS rounds per pair and its
+// length varies 10x between pairs, so in the kernels above a wave idles ~70 % of its lanes
+// waiting for its longest lineage.  Measured on ml.tree (rocprofv3 SQ counters, 5e7 pairs):
+// this form issues 45 % fewer LDS instructions but 22 % more VALU and ends 7 % slower than
+// k_canopy_ilp (5.6e9 vs 6.0e9 pairs/s): both sit at ~45 % VALU issue and ~55 % LDS-pipe
+// occupancy with half of the LDS cycles lost to bank conflicts of the random climbs.  Here
+// every lane runs its own sequence of pairs (pair index = wave tile + 64*t + lane) as a
+// small state machine -- NEED -> CLIMB1 -> CLIMB2 -> DONE -- and moves on without
+// waiting for its neighbours; one unified, branch-free round serves both climbs.  The
+// memory-touching stages (store a finished pair, fetch the next pair and its records) run
+// for a batch of waiting lanes at a time so that their latency is paid once per batch and
+// hidden by the other waves of the SIMD.
+template <int CAP, typename Src>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Src src, long long n,
+                                                              double *__restrict__ out_d,
+                                                              int *__restrict__ out_m, Fault *fault,
+                                                              int batch)
+{
+    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
+    stage_canopy(P, lds_raw);
+
+    constexpr int rec_bytes = 8 * (CAP + 1);
+    const bool parity = P.parity != 0;
+    const int lane = threadIdx.x & 63;
+    const long long waves_per_block = blockDim.x >> 6;
+    const long long n_waves = (long long)gridDim.x * waves_per_block;
+    const long long wave_id = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const long long per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;   // contiguous tile
+    const long long w_begin = wave_id * per_wave;
+    const long long w_end = w_begin + per_wave < n ? w_begin + per_wave : n;
+
+    enum { NEED = 0, CLIMB1 = 1, CLIMB2 = 2, DONE = 3 };
+    long long my_idx = w_begin + lane;   // my next pair, stride 64
+    long long cur_idx = 0;
+    int ph = NEED;
+    uint32_t u = 0, v = 0, pbv = 0, nbv = 0;
+    float s = 0.0f;
+    float Db[CAP];
+#pragma unroll
+    for (int q = 0; q < CAP; q++) Db[q] = 0.0f;
+
+    for (;;) {
+        const unsigned long long act_mask = __ballot(ph == CLIMB1 || ph == CLIMB2);
+        const unsigned long long wait_mask = __ballot(ph == DONE || (ph == NEED && my_idx < w_end));
+        if (act_mask == 0 && wait_mask == 0) break;
+        if (__popcll(wait_mask) >= batch || act_mask == 0) {
+            if (ph == DONE) {
+                store_result(out_d, out_m, cur_idx, s, P.canopy_id[u]);
+                ph = NEED;
+            }
+            if (ph == NEED && my_idx < w_end) {
+                cur_idx = my_idx;
+                my_idx += 64;
+                long long a, b;
+                src.load(cur_idx, a, b);
+                if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
+                    (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+                    record_fault(fault, a, b, P.n_nodes);
+                    store_result(out_d, out_m, cur_idx, __builtin_nanf(""), -1);
+                } else {
+                    const long long sa = record_slot(a, parity, P.n_leaves);
+                    const long long sb = record_slot(b, parity, P.n_leaves);
+                    const uint8_t *ra = P.records + sa * rec_bytes;
+                    const uint8_t *rb = P.records + sb * rec_bytes;
+                    const uint32_t wa = *reinterpret_cast<const uint32_t *>(ra);
+                    s = *reinterpret_cast<const float *>(ra + rec_bytes / 2);
+                    uint32_t wb;
+                    if (CAP == 1) {
+                        const uint2 q = *reinterpret_cast<const uint2 *>(rb);
+                        wb = q.x;
+                        Db[0] = __uint_as_float(q.y);
+                    } else {
+                        uint32_t w[CAP + 1];
+#pragma unroll
+                        for (int q = 0; q < (CAP + 1) / 4; q++) {
+                            const uint4 x = reinterpret_cast<const uint4 *>(rb)[q];
+                            w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+                        }
+                        wb = w[0];
+#pragma unroll
+                        for (int q = 0; q < CAP; q++) Db[q] = __uint_as_float(w[q + 1]);
+                    }
+                    u = wa & 0xFFFFu;
+                    v = wb & 0xFFFFu;
+                    pbv = v;
+                    nbv = wb >> 16;
+                    if (u == v) {   // shared portal: the MRCA is the portal or below it
+                        const RecView A = rec_view(P.records, sa, rec_bytes);
+                        const RecView B = rec_view(P.records, sb, rec_bytes);
+                        const PairResult r = pair_canopy_same_portal(P.canopy_id, A, B);
+                        store_result(out_d, out_m, cur_idx, r.dist, r.mrca);
+                    } else {
+                        ph = CLIMB1;
+                    }
+                }
+            }
+        }
+        // kFlowRounds rounds of whichever climb the lane is in (both entries are always read;
+        // in CLIMB2 u is the meeting node and stays put).  The phase only changes at the
+        // control points around this block, so a lane that meets early idles < kFlowRounds.
+        {
+            const bool c1 = ph == CLIMB1;
+            const bool climbing = c1 || ph == CLIMB2;
+#pragma unroll
+            for (int r = 0; r < kFlowRounds; r++) {
+                const unsigned long long eu = can[u], ev = can[v];
+                const uint32_t lu = (uint32_t)(eu >> 32), lv = (uint32_t)(ev >> 32);
+                const bool act = climbing && u != v;
+                const bool mu = act && c1 && (lu >> 16) >= (lv >> 16);
+                const bool mv = act && (!c1 || (lv >> 16) >= (lu >> 16));
+                const float addend = __uint_as_float(c1 ? (uint32_t)eu : (uint32_t)ev);
+                const float s_next = s + addend;
+                s = (c1 ? mu : act) ? s_next : s;
+                u = mu ? (lu & kCanopyParentMask) : u;
+                v = mv ? (lv & kCanopyParentMask) : v;
+            }
+        }
+        // CLIMB1 met: add b's understory, restart v at b's portal for CLIMB2
+        const bool met1 = ph == CLIMB1 && u == v;
+        if (__ballot(met1)) {
+            if (met1) {
+#pragma unroll
+                for (int q = 0; q < CAP; q++) {
+                    const float s_next = s + Db[q];
+                    s = (uint32_t)q < nbv ? s_next : s;
+                }
+                v = pbv;
+                ph = v == u ? DONE : CLIMB2;
+            }
+        } else if (ph == CLIMB2 && v == u) {
+            ph = DONE;
+        }
+    }
+}
+
 }  // namespace st
 
 // --------------------------------------------------------------------------
@@ -471,6 +610,9 @@ struct st_tree {
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 2;   // tuning: 0 = scalar reference kernel, 1/2/4 = ILP kernel
     int lockstep = 1;         // tuning: canopy climb 1 by depth cut (1) or by "larger index moves" (0)
+    int flow = 0;             // tuning: per-lane flow kernel 1 / 0 (measured: no faster than the ILP form, kept selectable)
+    int flow_batch = 16;      // lanes that must be waiting before the flow kernel refills
+    int canopy_depth = 0;     // deepest canopy node (edges)
     // staging of the host entry points (one caller at a time per handle)
     std::mutex ws_mutex;
     HostPipe pipe;
@@ -508,9 +650,33 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
 }
 
 template <int CAP, typename Src>
+static hipError_t launch_canopy_flow(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
+                                     double *out_d, int32_t *out_m, hipStream_t stream)
+{
+    const size_t lds = canopy_lds_bytes(t);
+    auto kern = k_canopy_flow<CAP, Src>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+    // every wave should own at least a few pairs per lane
+    int64_t blocks = (n + (int64_t)kCanopyBlock * 8 - 1) / ((int64_t)kCanopyBlock * 8);
+    blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
+    blocks = std::max<int64_t>(blocks, 1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
+                       (long long)n, out_d, out_m, t->d_fault, t->flow_batch);
+    return hipGetLastError();
+}
+
+template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                   double *out_d, int32_t *out_m, hipStream_t stream)
 {
+    if constexpr (CAP != 0) {
+        if (t->flow == 1) return launch_canopy_flow<CAP>(t, P, src, n, out_d, out_m, stream);
+    }
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, stream);
     } else {
@@ -569,6 +735,8 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, doubl
     return hipGetLastError();
 }
 
+// Canopies deeper than this use the flow kernel unless told otherwise (climb length varies
+// enough between pairs that wave-synchronous climbs waste most lanes).
 // Small batches are not worth staging 128 KiB of canopy per workgroup.
 constexpr int64_t kCanopyMinPairs = 4096;
 
@@ -756,6 +924,7 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
         t->rec_bytes = T.record_bytes;
         t->rec_cap = T.record_cap;
         t->parity = T.parity_layout ? 1 : 0;
+        for (const CanopyEntry &e : T.canopy) t->canopy_depth = std::max<int>(t->canopy_depth, (int)(e.link >> 16));
         if (T.canopy.size() & 1) T.canopy.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
         rc = upload(&t->d_canopy, T.canopy, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
@@ -827,6 +996,16 @@ int st_tree_set_option(st_tree *t, const char *name, int64_t value)
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1, 2 or 4");
         t->pairs_per_lane = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "flow") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "flow must be 0 or 1");
+        t->flow = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "flow_batch") == 0) {
+        if (value < 1 || value > 64) return fail(ST_ERR_ARG, "flow_batch must be in [1, 64]");
+        t->flow_batch = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "lockstep") == 0) {

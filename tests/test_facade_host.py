@@ -115,6 +115,7 @@ def test_no_gpu_means_loud_failure_not_a_cpu_answer(T):
 
 def test_missing_library_is_reported(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setenv("SUCHTREE_AMD_AUTOBUILD", "0")
     monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "libsuchtree_hip.so"))
     with pytest.raises(HipBackendError, match="not built"):
         _capi.load()

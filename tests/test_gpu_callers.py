@@ -31,11 +31,14 @@ def test_triangle_generator_equals_explicit_pairs(strategy, ml_arrays):
     ids = np.random.default_rng(4).choice(leaf_ids, size=700, replace=False)
     pairs = _tri_pairs(ids)
     want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
-    for ppl in (0, 1, 2, 4):
+    for flow, ppl in ((1, 2), (0, 0), (0, 1), (0, 2), (0, 4)):
+        dev.set_option("flow", flow)
         dev.set_option("pairs_per_lane", ppl)
         d, m = dev.triangle_host(ids, want_dist=True, want_mrca=True)
-        assert_bits_equal(d, want_d, "ppl%d" % ppl)
+        assert_bits_equal(d, want_d, "flow%d ppl%d" % (flow, ppl))
         assert np.array_equal(m, want_m)
+    dev.set_option("flow", 0)
+    dev.set_option("pairs_per_lane", 2)
     # any k-range gives the matching slice (what multi-GPU sharding and tiling rely on)
     total = len(pairs)
     for g in range(3):

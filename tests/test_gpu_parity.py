@@ -29,6 +29,12 @@ def _both(dev, pairs):
         if strategy == "walk":
             out["walk"] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
             continue
+        dev.set_option("flow", 1)
+        for batch in (1, 16, 64):
+            dev.set_option("flow_batch", batch)
+            out["canopy/flow%d" % batch] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+        dev.set_option("flow_batch", 16)
+        dev.set_option("flow", 0)
         for ppl, lockstep in ((0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (4, 0), (4, 1)):
             dev.set_option("pairs_per_lane", ppl)
             dev.set_option("lockstep", lockstep)
@@ -36,6 +42,7 @@ def _both(dev, pairs):
                 dev.distances_host(pairs, want_dist=True, want_mrca=True)
         dev.set_option("pairs_per_lane", 2)
         dev.set_option("lockstep", 1)
+        dev.set_option("flow", 0)
     dev.set_strategy("auto")
     return out
 
@@ -119,7 +126,7 @@ def test_config3_balanced_2_20_sample_and_full_size_properties():
     # full batch size of the bench step: size-independent properties
     big = synth.random_leaf_pairs(n_leaves, 20_000_000, seed=11)
     res = _both(dev, big)
-    (dw, mw), (dc, mc) = res["walk"], res["canopy/ppl4"]
+    (dw, mw), (dc, mc) = res["walk"], res["canopy/ppl2"]
     for name, (d, m) in res.items():
         assert_bits_equal(d, dw, name + " vs walk at 2e7 pairs")
         assert np.array_equal(m, mw), name
