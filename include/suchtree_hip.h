@@ -160,6 +160,23 @@ int st_tree_set_option(st_tree *tree, const char *name, int64_t value);
 int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths,
                    int32_t *out_tree_depth);
 
+/*
+ * Native Newick ingest (host only).  Replaces the dendropy calls of SuchTree.__init__
+ * (SuchTree/MuchTree.pyx:138-157, 171-216): first tree of the text, polytomies resolved,
+ * nodes numbered in order.  st_newick_open parses and reports sizes; st_newick_fill copies
+ * the flat arrays (any pointer may be NULL) -- leaf names come back concatenated, in
+ * increasing leaf-id order, with n_leaves+1 byte offsets; st_newick_close frees.
+ * ST_ERR_TREE means "not handled here" (syntax error or a token whose Python meaning is
+ * not reproduced): callers fall back to suchtree_amd/newick.py, which owns the errors.
+ */
+typedef struct st_newick st_newick;
+int st_newick_open(const char *text, int64_t len, st_newick **out, int64_t *n_nodes,
+                   int64_t *n_leaves, int64_t *names_bytes, int32_t *root, int32_t *depth);
+int st_newick_fill(const st_newick *h, int32_t *parent, int32_t *left, int32_t *right,
+                   float *support, float *distance, int32_t *leaf_ids, char *names,
+                   int64_t *name_offsets);
+void st_newick_close(st_newick *h);
+
 /* Thin device-memory helpers so callers without torch can stage buffers. */
 int st_device_malloc(int device, int64_t bytes, void **out);
 int st_device_free(int device, void *ptr);

@@ -23,7 +23,7 @@ SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host",
-    "st_quartets_host",
+    "st_quartets_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
@@ -99,6 +99,12 @@ def load():
         L.st_triangle_device.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, vp]
         L.st_triangle_host.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_quartets_host.argtypes = [vp, vp, i64, i64, i64, vp, ctypes.POINTER(i64)]
+        L.st_newick_open.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
+                                     ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                     ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+        L.st_newick_fill.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.st_newick_close.argtypes = [vp]
+        L.st_newick_close.restype = None
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
         L.st_device_free.argtypes = [i32, vp]
@@ -106,7 +112,7 @@ def load():
         L.st_memcpy_d2h.argtypes = [i32, vp, vp, i64]
         L.st_device_synchronize.argtypes = [i32]
         for name in SYMBOLS:
-            if name not in ("st_last_error", "st_tree_destroy"):
+            if name not in ("st_last_error", "st_tree_destroy", "st_newick_close"):
                 getattr(L, name).restype = i32
         _lib = L
     return _lib
@@ -130,6 +136,44 @@ def check(rc, tree_size=None, bad_id=None):
     if rc == ST_ERR_NOMEM:
         raise MemoryError(msg)
     raise HipBackendError(msg)
+
+
+def newick_native(text):
+    """Parse with the native ingest; returns a dict of arrays or None when the native
+    parser declines (the pure-Python parser then handles -- and diagnoses -- the input)."""
+    try:
+        L = load()
+    except HipBackendError:
+        return None
+    try:
+        raw = text.encode("ascii")
+    except UnicodeEncodeError:
+        return None
+    h = ctypes.c_void_p()
+    n, nl, nb = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    root, depth = ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = L.st_newick_open(raw, len(raw), ctypes.byref(h), ctypes.byref(n), ctypes.byref(nl), ctypes.byref(nb),
+                          ctypes.byref(root), ctypes.byref(depth))
+    if rc != ST_OK:
+        return None
+    try:
+        n, nl, nb = n.value, nl.value, nb.value
+        out = {k: np.empty(n, dtype=np.int32) for k in ("parent", "left", "right")}
+        out["support"] = np.empty(n, dtype=np.float32)
+        out["distance"] = np.empty(n, dtype=np.float32)
+        out["leaf_ids"] = np.empty(nl, dtype=np.int32)
+        names = ctypes.create_string_buffer(max(nb, 1))
+        offs = np.empty(nl + 1, dtype=np.int64)
+        check(L.st_newick_fill(h, _ptr(out["parent"]), _ptr(out["left"]), _ptr(out["right"]),
+                               _ptr(out["support"]), _ptr(out["distance"]), _ptr(out["leaf_ids"]),
+                               ctypes.cast(names, ctypes.c_void_p), _ptr(offs)))
+        blob = names.raw[:nb].decode("ascii")
+        o = offs.tolist()
+        out["names"] = [blob[o[i]:o[i + 1]] for i in range(nl)]
+        out["root"], out["depth"] = int(root.value), int(depth.value)
+        return out
+    finally:
+        L.st_newick_close(h)
 
 
 def device_count():

@@ -13,7 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsuchtree_hip.so")
-SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep.cpp")]
+SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep.cpp"),
+           os.path.join(CSRC, "newick_parse.cpp")]
 HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
            os.path.join(CSRC, "host_pipe.h"),
            os.path.join(HERE, "..", "include", "suchtree_hip.h")]

@@ -745,7 +745,9 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, double *d_out, int
                        hipStream_t stream)
 {
     if (n == 0) return ST_OK;
-    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && d_out != nullptr && n >= kCanopyMinPairs;
+    // MRCA-only requests (d_out == NULL) also go through the canopy kernels: the id comes out
+    // of the same climb, and that is ~7x faster than walking the global table
+    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && n >= kCanopyMinPairs;
     const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, stream)
                                 : launch_walk(t, src, n, d_out, d_mrca, stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

@@ -205,8 +205,33 @@ def node_depths(parent: np.ndarray) -> np.ndarray:
     return d
 
 
-def flat_tree_from_newick(text: str) -> FlatTree:
-    """MuchTree.pyx:157-228 on top of :func:`parse_newick`."""
+def flat_tree_from_newick(text: str, native: bool = True) -> FlatTree:
+    """Newick text -> :class:`FlatTree` (MuchTree.pyx:138-228).
+
+    Uses the native ingest of libsuchtree_hip.so (csrc/newick_parse.cpp, host code, no GPU
+    needed) when it is available and accepts the input; anything it declines -- every
+    syntax error included -- goes through the pure-Python path below, which is the
+    reference statement of the behaviour and the owner of the error messages.
+    """
+    if native:
+        try:
+            from . import _capi
+            got = _capi.newick_native(text)
+        except Exception:
+            got = None
+        if got is not None:
+            leaf_list = got["leaf_ids"].tolist()
+            names = got["names"]
+            return FlatTree(parent=got["parent"], left=got["left"], right=got["right"],
+                            support=got["support"], distance=got["distance"], root=got["root"],
+                            depth=got["depth"], leaves=dict(zip(names, leaf_list)),
+                            leaf_nodes=dict(zip(leaf_list, names)),
+                            internal_nodes=np.flatnonzero(got["left"] >= 0))
+    return _flat_tree_from_newick_py(text)
+
+
+def _flat_tree_from_newick_py(text: str) -> FlatTree:
+    """MuchTree.pyx:157-228 on top of :func:`parse_newick` (pure Python)."""
     children, label, length, root0 = parse_newick(text)
     _resolve_polytomies(children, label, length)
     order = _inorder(children, root0)

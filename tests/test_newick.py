@@ -123,3 +123,98 @@ def test_flat_arrays_validation():
         flat_tree_from_arrays(np.array([1, 2, 1]), np.zeros(3))       # cycle, no root
     with pytest.raises(TreeStructureError):
         flat_tree_from_arrays(np.array([1, -1, 1, 1, 1]), np.zeros(5))  # not binary
+
+
+# ---- native ingest (csrc/newick_parse.cpp) against the pure-Python statement ----------------
+
+def _same_tree(a, b):
+    for k in ("parent", "left", "right", "support", "distance"):
+        x, y = getattr(a, k), getattr(b, k)
+        assert x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True), k
+    assert (a.root, a.depth, a.size) == (b.root, b.depth, b.size)
+    assert list(a.leaves.items()) == list(b.leaves.items()) and a.leaf_nodes == b.leaf_nodes
+    assert np.array_equal(a.internal_nodes, b.internal_nodes)
+
+
+def _native_available():
+    from suchtree_amd import _capi
+    return _capi.newick_native("(A,B);") is not None
+
+
+@pytest.mark.skipif(not _native_available(), reason="libsuchtree_hip.so not built")
+class TestNativeNewick:
+    def test_fixture_trees(self):
+        from suchtree_amd.newick import _flat_tree_from_newick_py
+        import glob
+        files = [golden_path("test.tree"), golden_path("host.tree")] + \
+            sorted(glob.glob(golden_path("gopher_louse") + "/*.tree")) + \
+            sorted(glob.glob(golden_path("fish_worm") + "/*.tree"))
+        for f in files:
+            text = open(f).read()
+            _same_tree(flat_tree_from_newick(text), _flat_tree_from_newick_py(text))
+
+    def test_syntax_corners(self):
+        from suchtree_amd import _capi
+        from suchtree_amd.newick import _flat_tree_from_newick_py
+        handled = ["(A,B,(C,D));", "(A:1,B:2,C:0,D:4)R:9;", "A;", "((A:-0.5,B:1):1,C:2);", "(A:1e-3,B:.5)\n",
+                   "[&R] ((a_b:1,'c d''e':2)0.95:3,(x:1,y:1)boot:2)[note];\n", "(A:1,B:2);(C,D);",
+                   "( A : 1 ,\n B : 2 ) ;", "((A,B)1e2,(C,D)-3.5)root;", "(A[x]:1[y],B:2);", "('':1,B:2);",
+                   "(A:0.0,B:-0.0,(C:5E-1,D:+2)n9);", "(((((A,B),C),D),E),F,G,H,I);"]
+        for text in handled:
+            assert _capi.newick_native(text) is not None, text
+            _same_tree(flat_tree_from_newick(text), _flat_tree_from_newick_py(text))
+        # tokens whose Python meaning the native parser does not claim: it declines, Python decides
+        declined = ["((A,B)n1,(C,D)'1.5 ')1_0;", "((A,B)inf,(C,D)NaN);", "(A:1_0,B:2);", "(é:1,B:2);"]
+        for text in declined:
+            assert _capi.newick_native(text) is None, text
+            _same_tree(flat_tree_from_newick(text), _flat_tree_from_newick_py(text))
+
+    def test_errors_come_from_the_python_path(self):
+        from suchtree_amd import _capi
+        for text, exc in (("((A,B);", TreeStructureError), ("(A:x,B);", TreeStructureError), ("", TreeStructureError),
+                          ("((A:1,B:1):1);", TypeError), ("(A,B));", TreeStructureError), ("(A,(B,));", TreeStructureError),
+                          ("(A:1,B:2]", TreeStructureError), ("(A,'B);", TreeStructureError)):
+            assert _capi.newick_native(text) is None, text
+            with pytest.raises(exc):
+                flat_tree_from_newick(text)
+
+    def test_random_trees_with_random_syntax(self):
+        from suchtree_amd.newick import _flat_tree_from_newick_py
+        rng = np.random.default_rng(12)
+
+        def gen(depth):
+            if depth == 0 or rng.random() < 0.3:
+                name = "t%d" % rng.integers(0, 10**6)
+                if rng.random() < 0.2:
+                    name = "'%s x''y'" % name
+                core = name
+            else:
+                k = int(rng.choice([2, 2, 2, 3, 4, 5]))
+                core = "(" + ",".join(gen(depth - 1) for _ in range(k)) + ")"
+                r = rng.random()
+                if r < 0.3:
+                    core += "%.3f" % rng.random()
+                elif r < 0.4:
+                    core += "lab%d" % rng.integers(0, 99)
+            r = rng.random()
+            if r < 0.7:
+                core += ":%r" % float(np.round(rng.random() * 3, int(rng.integers(1, 9))))
+            elif r < 0.8:
+                core += ":0"
+            elif r < 0.85:
+                core += ":%.2e" % (rng.random() * 1e-3)
+            if rng.random() < 0.1:
+                core += "[c%d]" % rng.integers(0, 9)
+            if rng.random() < 0.1:
+                core = " " + core + "\n"
+            return core
+
+        for _ in range(60):
+            text = "(" + gen(6) + "," + gen(6) + ");"
+            _same_tree(flat_tree_from_newick(text), _flat_tree_from_newick_py(text))
+
+    def test_big_tree_round_trip(self):
+        parent, dist = synth.random_binary_tree(30_000, seed=2, zero_fraction=0.05)
+        t = flat_tree_from_newick(synth.to_newick(parent, dist))
+        # epsilon edges print as 2.22e-16 and come back as the same float32
+        assert np.array_equal(t.parent, parent) and np.array_equal(t.distance, dist)
