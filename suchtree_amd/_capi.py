@@ -54,6 +54,30 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_hip_runtime():
+    """Make this library and PyTorch agree on ONE HIP runtime, whichever is imported first.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so with the same SONAME as the system
+    one.  If this library pulled in /opt/rocm's copy first, a later ``import torch`` would
+    mix two ROCm stacks in one process and see no device.  So when torch is installed but
+    not yet imported, its bundled runtime is loaded first (RTLD_GLOBAL); libsuchtree_hip.so's
+    NEEDED libamdhip64.so.7 then resolves to it, exactly as when torch was imported first.
+    """
+    import sys
+    if "torch" in sys.modules or os.environ.get("SUCHTREE_AMD_SYSTEM_HIP", "0") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass   # fall back to the system runtime through the library's RPATH
+
+
 def load():
     """Load the HIP library once; raise HipBackendError if it is absent."""
     global _lib
@@ -79,6 +103,7 @@ def load():
             raise HipBackendError(
                 "libsuchtree_hip.so is not built (%s). Build it with `python -m suchtree_amd.build` "
                 "(hipcc, gfx950); this package has no CPU fallback." % LIB_PATH)
+        _preload_hip_runtime()
         try:
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:

@@ -154,3 +154,57 @@ def test_quartet_topologies(ml_arrays):
     by_name = G.quartet_topologies_by_name([("Oche", "Ocav", "Ohet", "Ound"), ("Ttal", "Oche", "Tbot", "Ohet")])
     assert by_name[0] == topo
     assert by_name[1] == frozenset((frozenset(("Ttal", "Tbot")), frozenset(("Oche", "Ohet"))))
+
+
+def test_config4_full_size_index_arithmetic():
+    """The full 100k-leaf triangle has 4,999,950,000 pairs: pair indices beyond 2^32 must map to
+    the right (row, column).  Slices at the far end and across the 2^31 / 2^32 boundaries."""
+    m = 100_000
+    parent, dist = synth.random_binary_tree(m, seed=44)
+    dev = _capi.DeviceTree(parent, dist)
+    O = OracleTree(parent, dist)
+    ids = np.arange(0, 2 * m, 2, dtype=np.int64)
+    total = m * (m - 1) // 2
+    assert total == 4_999_950_000
+    for k0 in (total - 150_000, 2**31 - 70_000, 2**32 - 70_000, 0):
+        c = 150_000 if k0 + 150_000 <= total else total - k0
+        d, mm = dev.triangle_host(ids, k_begin=k0, k_count=c, want_dist=True, want_mrca=True)
+        kk = np.arange(k0, k0 + c)
+        rows = sharding.triangle_row_of(kk)
+        cols = kk - rows * (rows - 1) // 2
+        assert rows.max() <= m - 1 and cols.min() >= 0 and np.all(cols < rows)
+        pp = np.stack([ids[cols], ids[rows]], 1)
+        assert_bits_equal(d, O.distances(pp), "k0=%d" % k0)
+        assert np.array_equal(mm, O.mrca_bulk(pp))
+    with pytest.raises(ValueError):
+        dev.triangle_host(ids, k_begin=total - 10, k_count=11)
+    dev.close()
+
+
+def test_more_than_2_31_pairs_in_one_launch():
+    """Pair indices are 64-bit end to end: one device-resident launch over 2^31 + 2^20 pairs."""
+    import torch
+    parent, dist = synth.balanced_tree(16)
+    dev = _capi.DeviceTree(parent, dist)
+    O = OracleTree(parent, dist)
+    n = 2**31 + 2**20
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    base = torch.randint(0, 1 << 16, (1 << 22, 2), generator=g, device="cuda", dtype=torch.int64) * 2
+    pairs = base.repeat(n // (1 << 22) + 1, 1)[:n].contiguous()        # 34 GB of ids in HBM
+    out_d = torch.empty(n, dtype=torch.float64, device="cuda")
+    out_m = torch.empty(n, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    dev.distances_device(pairs.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream)
+    dev.fault_check(stream)
+    host_base = base.cpu().numpy()
+    want_d, want_m = O.distances(host_base), O.mrca_bulk(host_base)
+    for start in (0, 2**31 - (1 << 21), n - (1 << 22)):
+        start -= start % (1 << 22)
+        sl = slice(start, start + (1 << 22))
+        assert_bits_equal(out_d[sl].cpu().numpy(), want_d, "slice at %d" % start)
+        assert np.array_equal(out_m[sl].cpu().numpy(), want_m)
+    tail = out_d[n - (n % (1 << 22)):].cpu().numpy()
+    assert_bits_equal(tail, want_d[: len(tail)])
+    assert float(out_d.sum().item()) > 0
+    dev.close()
