@@ -174,7 +174,7 @@ def main():
         t_new = timed(lambda: tree.distances_host(pairs, True, True), reps=2)
         emit(fh, config="3-host", workload="balanced 2^20-leaf tree, 1e8 pairs, host numpy in/out (PCIe inclusive)",
              pairs_per_s_reused_outputs=n / t, pairs_per_s_dist_only=n / t_d, pairs_per_s_fresh_outputs=n / t_new,
-             GBps_over_pcie=n * 28 / t / 1e9)
+             GBps_over_pcie=n * 16 / t / 1e9, pcie_bytes_per_pair="8 in (int32 ids) + 4 (float32) + 4 (int32) out")
         tree.close()
 
     if "5" in todo:

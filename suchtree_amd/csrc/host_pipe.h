@@ -5,8 +5,9 @@
 // device buffers on two streams and a small pool of copy threads:
 //
 //   pack(c)   : caller's pairs  -> pinned (parallel memcpy / strided gather)
-//   gpu(c)    : H2D, kernel, D2H into pinned, on stream c&1   (async)
-//   unpack(c) : pinned -> caller's result arrays (parallel memcpy)
+//   gpu(c)    : H2D, kernel, D2H into pinned, on stream c&1   (async); distances travel
+//               as float32 (they are float32 sums), MRCA ids as int32
+//   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / memcpy)
 //
 // unpack(c-1) and pack(c+1) run on the CPU while gpu(c) is in flight, and the two
 // streams let the H2D of one chunk overlap the D2H of the other (PCIe is full duplex).
@@ -56,7 +57,7 @@ public:
     void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)> &fn)
     {
         if (n <= 0) return;
-        if (workers_.empty() || n < (int64_t)1 << 16) { fn(0, n); return; }
+        if (workers_.empty() || n < (int64_t)1 << 14) { fn(0, n); return; }
         {
             std::lock_guard<std::mutex> g(m_);
             fn_ = &fn;
@@ -137,10 +138,10 @@ struct HostPipe {
         for (auto &s : slot) {
             hipError_t e;
             if ((e = hipHostMalloc(&s.h_in, (size_t)pairs * 16, hipHostMallocDefault)) != hipSuccess) return e;
-            if ((e = hipHostMalloc(&s.h_d, (size_t)pairs * 8, hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipHostMalloc(&s.h_d, (size_t)pairs * 4, hipHostMallocDefault)) != hipSuccess) return e;   // float32 transport
             if ((e = hipHostMalloc(&s.h_m, (size_t)pairs * 4, hipHostMallocDefault)) != hipSuccess) return e;
             if ((e = hipMalloc(&s.d_in, (size_t)pairs * 16)) != hipSuccess) return e;
-            if ((e = hipMalloc(&s.d_d, (size_t)pairs * 8)) != hipSuccess) return e;
+            if ((e = hipMalloc(&s.d_d, (size_t)pairs * 4)) != hipSuccess) return e;
             if ((e = hipMalloc(&s.d_m, (size_t)pairs * 4)) != hipSuccess) return e;
             if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
             if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;

@@ -50,6 +50,33 @@ static int fail(int code, const std::string &msg)
             return fail(ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Selects a device for the scope of one C-ABI call and puts the caller's current device
+// back afterwards (callers such as PyTorch keep their own notion of "current device").
+class DeviceScope {
+public:
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+        err_ = (prev_ == device) ? hipSuccess : hipSetDevice(device);
+        changed_ = err_ == hipSuccess && prev_ != device;
+    }
+    ~DeviceScope()
+    {
+        if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_);
+    }
+    hipError_t error() const { return err_; }
+
+private:
+    int prev_ = -1;
+    hipError_t err_ = hipSuccess;
+    bool changed_ = false;
+};
+
+#define ST_DEVICE(dev)                                                                     \
+    DeviceScope device_scope_(dev);                                                        \
+    if (device_scope_.error() != hipSuccess)                                               \
+        return fail(ST_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.error()))
+
 // --------------------------------------------------------------------------
 // device-side helpers
 // --------------------------------------------------------------------------
@@ -71,6 +98,18 @@ struct SrcContig {
     __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
     {
         const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];
+        a = v.x;
+        b = v.y;
+    }
+};
+
+// C-order int32 (n,2): what the host path ships over PCIe (node ids always fit in 31 bits;
+// the packing step clamps anything wider so that it still fails the range check).
+struct SrcContig32 {
+    const int *pairs;
+    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
+    {
+        const int2 v = reinterpret_cast<const int2 *>(pairs)[i];
         a = v.x;
         b = v.y;
     }
@@ -108,10 +147,20 @@ struct SrcTriangle {
     }
 };
 
-__device__ __forceinline__ void store_result(double *__restrict__ out_d, int *__restrict__ out_m,
+// Where distances go.  The C ABI's contract is float64 (what the reference returns); the
+// values are float32 sums, so the host path ships them over PCIe as float32 and widens them
+// on the host (half the D2H bytes, bit-identical result).
+struct DistSink {
+    double *d64;
+    float *f32;
+    __host__ __device__ bool any() const { return d64 != nullptr || f32 != nullptr; }
+};
+
+__device__ __forceinline__ void store_result(const DistSink &out_d, int *__restrict__ out_m,
                                              long long i, float d, int m)
 {
-    if (out_d) out_d[i] = (double)d;
+    if (out_d.d64) out_d.d64[i] = (double)d;
+    else if (out_d.f32) out_d.f32[i] = d;
     if (out_m) out_m[i] = m;
 }
 
@@ -126,7 +175,7 @@ struct WalkParams {
 
 template <typename Src>
 __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n,
-                                              double *__restrict__ out_d, int *__restrict__ out_m,
+                                              DistSink out_d, int *__restrict__ out_m,
                                               Fault *fault)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -139,7 +188,7 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
             store_result(out_d, out_m, i, __builtin_nanf(""), -1);
             continue;
         }
-        if (out_d) {
+        if (out_d.any()) {
             const PairResult r = pair_walk(P.nodes, P.depth, (int32_t)a, (int32_t)b);
             store_result(out_d, out_m, i, r.dist, r.mrca);
         } else {
@@ -230,7 +279,7 @@ __device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned cha
 // through a pointer.
 template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src, long long n,
-                                                         double *__restrict__ out_d,
+                                                         DistSink out_d,
                                                          int *__restrict__ out_m, Fault *fault)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -297,7 +346,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
 // meeting node), so the PPL chains never serialise behind a branch.
 template <int CAP, int PPL, bool LOCKSTEP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
-                                                             double *__restrict__ out_d,
+                                                             DistSink out_d,
                                                              int *__restrict__ out_m, Fault *fault)
 {
     static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
@@ -462,7 +511,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 // hidden by the other waves of the SIMD.
 template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Src src, long long n,
-                                                              double *__restrict__ out_d,
+                                                              DistSink out_d,
                                                               int *__restrict__ out_m, Fault *fault,
                                                               int batch)
 {
@@ -628,7 +677,7 @@ static size_t canopy_lds_bytes(const st_tree *t)
 
 template <typename Kern, typename Src>
 static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
-                                  const Src &src, int64_t n, double *out_d, int32_t *out_m,
+                                  const Src &src, int64_t n, DistSink out_d, int32_t *out_m,
                                   hipStream_t stream)
 {
     const size_t lds = canopy_lds_bytes(t);
@@ -651,7 +700,7 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
 
 template <int CAP, typename Src>
 static hipError_t launch_canopy_flow(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                     double *out_d, int32_t *out_m, hipStream_t stream)
+                                     DistSink out_d, int32_t *out_m, hipStream_t stream)
 {
     const size_t lds = canopy_lds_bytes(t);
     auto kern = k_canopy_flow<CAP, Src>;
@@ -672,7 +721,7 @@ static hipError_t launch_canopy_flow(const st_tree *t, const CanopyParams &P, co
 
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                  double *out_d, int32_t *out_m, hipStream_t stream)
+                                  DistSink out_d, int32_t *out_m, hipStream_t stream)
 {
     if constexpr (CAP != 0) {
         if (t->flow == 1) return launch_canopy_flow<CAP>(t, P, src, n, out_d, out_m, stream);
@@ -698,7 +747,7 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
 }
 
 template <typename Src>
-static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, double *out_d,
+static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
                                 int32_t *out_m, hipStream_t stream)
 {
     CanopyParams P;
@@ -720,7 +769,7 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, dou
 }
 
 template <typename Src>
-static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, double *out_d,
+static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
                               int32_t *out_m, hipStream_t stream)
 {
     WalkParams P;
@@ -735,13 +784,11 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, doubl
     return hipGetLastError();
 }
 
-// Canopies deeper than this use the flow kernel unless told otherwise (climb length varies
-// enough between pairs that wave-synchronous climbs waste most lanes).
 // Small batches are not worth staging 128 KiB of canopy per workgroup.
 constexpr int64_t kCanopyMinPairs = 4096;
 
 template <typename Src>
-static int enqueue_src(st_tree *t, const Src &src, int64_t n, double *d_out, int32_t *d_mrca,
+static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, int32_t *d_mrca,
                        hipStream_t stream)
 {
     if (n == 0) return ST_OK;
@@ -755,7 +802,7 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, double *d_out, int
 }
 
 static int enqueue(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s0, int64_t s1,
-                   double *d_out, int32_t *d_mrca, hipStream_t stream)
+                   DistSink d_out, int32_t *d_mrca, hipStream_t stream)
 {
     const long long *p = reinterpret_cast<const long long *>(d_pairs);
     if (s0 == 2 && s1 == 1 && (reinterpret_cast<uintptr_t>(d_pairs) & 15) == 0)
@@ -763,12 +810,17 @@ static int enqueue(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s0, in
     return enqueue_src(t, SrcStrided{p, (long long)s0, (long long)s1}, n, d_out, d_mrca, stream);
 }
 
-static int read_fault(st_tree *t, hipStream_t stream, int64_t *bad_id)
+// host_max / host_min: exact extremes of ids the host path had to clamp to 32 bits.
+static int read_fault(st_tree *t, hipStream_t stream, int64_t *bad_id,
+                      long long host_max = std::numeric_limits<long long>::min(),
+                      long long host_min = std::numeric_limits<long long>::max())
 {
     Fault f;
     ST_HIP(hipMemcpyAsync(&f, t->d_fault, sizeof(Fault), hipMemcpyDeviceToHost, stream));
     ST_HIP(hipStreamSynchronize(stream));
     if (f.max_bad == kFaultInit.max_bad && f.min_bad == kFaultInit.min_bad) return ST_OK;
+    f.max_bad = std::max(f.max_bad, host_max);
+    f.min_bad = std::min(f.min_bad, host_min);
     ST_HIP(hipMemcpyAsync(t->d_fault, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream));
     ST_HIP(hipStreamSynchronize(stream));
     // the reference reports max_id when it is too large, else min_id (MuchTree.pyx:897-903)
@@ -791,11 +843,11 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
 constexpr int64_t kHostChunk = (int64_t)1 << 22;   // pairs per pipeline chunk
 
 // Push n pairs through the two-slot pipe (host_pipe.h).  pack(slot, off, m) fills
-// slot.h_in for chunk [off, off+m) (skipped when has_input is false: generated pairs);
+// slot.h_in for chunk [off, off+m) with in_bytes_per_pair bytes per pair (0: generated pairs, no input);
 // launch(slot, off, m) enqueues the kernel on slot.stream reading slot.d_in and writing
 // slot.d_d / slot.d_m.  Caller holds ws_mutex.
 template <typename Pack, typename Launch>
-static int run_pipe(st_tree *t, int64_t n, bool has_input, Pack pack, Launch launch,
+static int run_pipe(st_tree *t, int64_t n, int in_bytes_per_pair, Pack pack, Launch launch,
                     double *out_dist, int32_t *out_mrca)
 {
     HostPipe &P = t->pipe;
@@ -812,7 +864,14 @@ static int run_pipe(st_tree *t, int64_t n, bool has_input, Pack pack, Launch lau
         s.busy = false;
         const hipError_t e = hipEventSynchronize(s.done);
         if (e != hipSuccess) return e;
-        if (out_dist) P.pool.copy(out_dist + s.off, s.h_d, s.m * 8);
+        if (out_dist) {
+            // distances crossed PCIe as float32; widen into the caller's float64 array
+            const float *src = static_cast<const float *>(s.h_d);
+            double *dst = out_dist + s.off;
+            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) {
+                for (int64_t k = b; k < e; k++) dst[k] = (double)src[k];
+            });
+        }
         if (out_mrca) P.pool.copy(out_mrca + s.off, s.h_m, s.m * 4);
         return hipSuccess;
     };
@@ -829,15 +888,15 @@ static int run_pipe(st_tree *t, int64_t n, bool has_input, Pack pack, Launch lau
         PipeSlot &s = P.slot[c & 1];
         hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
-        if (has_input) {
+        if (in_bytes_per_pair > 0) {
             pack(s, off, m);
-            e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * 16, hipMemcpyHostToDevice, s.stream);
+            e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * (size_t)in_bytes_per_pair, hipMemcpyHostToDevice, s.stream);
             if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e));
         }
         const int rc = launch(s, off, m);
         if (rc != ST_OK) return bail(rc, g_last_error);
         if (out_dist && e == hipSuccess)
-            e = hipMemcpyAsync(s.h_d, s.d_d, (size_t)m * 8, hipMemcpyDeviceToHost, s.stream);
+            e = hipMemcpyAsync(s.h_d, s.d_d, (size_t)m * 4, hipMemcpyDeviceToHost, s.stream);
         if (out_mrca && e == hipSuccess)
             e = hipMemcpyAsync(s.h_m, s.d_m, (size_t)m * 4, hipMemcpyDeviceToHost, s.stream);
         if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
@@ -907,7 +966,7 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
     if (device < 0 || device >= n_dev)
         return fail(ST_ERR_HIP, "device " + std::to_string(device) + " not available (" +
                                     std::to_string(n_dev) + " visible)");
-    ST_HIP(hipSetDevice(device));
+    ST_DEVICE(device);
     hipDeviceProp_t prop;
     ST_HIP(hipGetDeviceProperties(&prop, device));
 
@@ -960,7 +1019,7 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
 void st_tree_destroy(st_tree *t)
 {
     if (!t) return;
-    (void)hipSetDevice(t->device);
+    DeviceScope scope(t->device);
     (void)hipFree(t->d_nodes);
     (void)hipFree(t->d_depth);
     (void)hipFree(t->d_canopy);
@@ -1025,15 +1084,15 @@ int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s
     if (n < 0) return fail(ST_ERR_ARG, "n < 0");
     if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
     if (!d_out_dist && !d_out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
-    ST_HIP(hipSetDevice(t->device));
-    return enqueue(t, d_pairs, n, stride0, stride1, d_out_dist, d_out_mrca,
+    ST_DEVICE(t->device);
+    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{d_out_dist, nullptr}, d_out_mrca,
                    reinterpret_cast<hipStream_t>(stream));
 }
 
 int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)
 {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
-    ST_HIP(hipSetDevice(t->device));
+    ST_DEVICE(t->device);
     return read_fault(t, reinterpret_cast<hipStream_t>(stream), bad_id);
 }
 
@@ -1045,33 +1104,45 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
     if (n > 0 && !pairs) return fail(ST_ERR_ARG, "pairs is NULL");
     if (!out_dist && !out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
     if (n == 0) return ST_OK;
-    ST_HIP(hipSetDevice(t->device));
+    ST_DEVICE(t->device);
     std::lock_guard<std::mutex> lock(t->ws_mutex);
 
-    const bool c_order = (stride0 == 2 && stride1 == 1);
+    // Ids cross PCIe as int32 (half the H2D bytes).  Values that do not fit are clamped to
+    // INT32_MAX / INT32_MIN -- still out of range for the kernel -- and their exact extremes
+    // are kept here so that the reported id is the one the reference would report.
     CopyPool &pool = t->pipe.pool;
+    std::mutex wide_mutex;
+    long long wide_max = std::numeric_limits<long long>::min();
+    long long wide_min = std::numeric_limits<long long>::max();
     auto pack = [&](PipeSlot &s, int64_t off, int64_t m) {
         const int64_t *src = pairs + off * stride0;
-        int64_t *dst = static_cast<int64_t *>(s.h_in);
-        if (c_order) {
-            pool.copy(dst, src, m * 16);
-        } else {
-            pool.parallel_for(m, [=](int64_t b, int64_t e) {
-                for (int64_t k = b; k < e; k++) {
-                    dst[2 * k] = src[k * stride0];
-                    dst[2 * k + 1] = src[k * stride0 + stride1];
+        int32_t *dst = static_cast<int32_t *>(s.h_in);
+        pool.parallel_for(m, [&, src, dst](int64_t b, int64_t e) {
+            long long hi = std::numeric_limits<long long>::min(), lo = std::numeric_limits<long long>::max();
+            for (int64_t k = b; k < e; k++) {
+                for (int c = 0; c < 2; c++) {
+                    const long long v = src[k * stride0 + c * stride1];
+                    int32_t w = (int32_t)v;
+                    if (v > INT32_MAX) { w = INT32_MAX; hi = std::max(hi, v); }
+                    else if (v < INT32_MIN) { w = INT32_MIN; lo = std::min(lo, v); }
+                    dst[2 * k + c] = w;
                 }
-            });
-        }
+            }
+            if (hi != std::numeric_limits<long long>::min() || lo != std::numeric_limits<long long>::max()) {
+                std::lock_guard<std::mutex> g(wide_mutex);
+                wide_max = std::max(wide_max, hi);
+                wide_min = std::min(wide_min, lo);
+            }
+        });
     };
     auto launch = [&](PipeSlot &s, int64_t, int64_t m) {
-        return enqueue(t, static_cast<const int64_t *>(s.d_in), m, 2, 1,
-                       out_dist ? static_cast<double *>(s.d_d) : nullptr,
-                       out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
+        return enqueue_src(t, SrcContig32{static_cast<const int *>(s.d_in)}, m,
+                           DistSink{nullptr, out_dist ? static_cast<float *>(s.d_d) : nullptr},
+                           out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
     };
-    const int rc = run_pipe(t, n, true, pack, launch, out_dist, out_mrca);
+    const int rc = run_pipe(t, n, 8, pack, launch, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
-    return read_fault(t, t->pipe.slot[0].stream, bad_id);
+    return read_fault(t, t->pipe.slot[0].stream, bad_id, wide_max, wide_min);
 }
 
 static int triangle_args(st_tree *t, const int64_t *ids, int64_t m, int64_t k_begin, int64_t k_count,
@@ -1093,9 +1164,10 @@ int st_triangle_device(st_tree *t, const int64_t *d_ids, int64_t m, int64_t id_s
 {
     int rc = triangle_args(t, d_ids, m, k_begin, k_count, d_out_dist, d_out_mrca);
     if (rc != ST_OK) return rc;
-    ST_HIP(hipSetDevice(t->device));
+    ST_DEVICE(t->device);
     const SrcTriangle src{reinterpret_cast<const long long *>(d_ids), (long long)id_stride, (long long)k_begin};
-    return enqueue_src(t, src, k_count, d_out_dist, d_out_mrca, reinterpret_cast<hipStream_t>(stream));
+    return enqueue_src(t, src, k_count, DistSink{d_out_dist, nullptr}, d_out_mrca,
+                       reinterpret_cast<hipStream_t>(stream));
 }
 
 int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_stride, int64_t k_begin,
@@ -1104,7 +1176,7 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
-    ST_HIP(hipSetDevice(t->device));
+    ST_DEVICE(t->device);
     std::lock_guard<std::mutex> lock(t->ws_mutex);
     {
         hipError_t e = t->pipe.ensure(std::max<int64_t>(std::min<int64_t>(k_count, kHostChunk), 1024));
@@ -1123,10 +1195,10 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     auto pack = [](PipeSlot &, int64_t, int64_t) {};
     auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
         const SrcTriangle src{static_cast<const long long *>(t->pipe.d_ids), 1, (long long)(k_begin + off)};
-        return enqueue_src(t, src, c, out_dist ? static_cast<double *>(s.d_d) : nullptr,
+        return enqueue_src(t, src, c, DistSink{nullptr, out_dist ? static_cast<float *>(s.d_d) : nullptr},
                            out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
     };
-    rc = run_pipe(t, k_count, false, pack, launch, out_dist, out_mrca);
+    rc = run_pipe(t, k_count, 0, pack, launch, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     return read_fault(t, t->pipe.slot[0].stream, bad_id);
 }
@@ -1138,7 +1210,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     if (n < 0) return fail(ST_ERR_ARG, "n < 0");
     if (n > 0 && (!quartets || !out_topologies)) return fail(ST_ERR_ARG, "quartets or output is NULL");
     if (n == 0) return ST_OK;
-    ST_HIP(hipSetDevice(t->device));
+    ST_DEVICE(t->device);
     std::lock_guard<std::mutex> lock(t->ws_mutex);
     // (n,4) int64 in and out are each the size of two pair rows: reuse the pipe's slots,
     // input in d_in/h_in of slot 0 and 1 back to back is not possible, so stage by halves:
@@ -1176,35 +1248,35 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
 int st_device_malloc(int device, int64_t bytes, void **out)
 {
     if (!out || bytes < 0) return fail(ST_ERR_ARG, "bad arguments");
-    ST_HIP(hipSetDevice(device));
+    ST_DEVICE(device);
     ST_HIP(hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16)));
     return ST_OK;
 }
 
 int st_device_free(int device, void *ptr)
 {
-    ST_HIP(hipSetDevice(device));
+    ST_DEVICE(device);
     ST_HIP(hipFree(ptr));
     return ST_OK;
 }
 
 int st_memcpy_h2d(int device, void *dst, const void *src, int64_t bytes)
 {
-    ST_HIP(hipSetDevice(device));
+    ST_DEVICE(device);
     ST_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
     return ST_OK;
 }
 
 int st_memcpy_d2h(int device, void *dst, const void *src, int64_t bytes)
 {
-    ST_HIP(hipSetDevice(device));
+    ST_DEVICE(device);
     ST_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return ST_OK;
 }
 
 int st_device_synchronize(int device)
 {
-    ST_HIP(hipSetDevice(device));
+    ST_DEVICE(device);
     ST_HIP(hipDeviceSynchronize());
     return ST_OK;
 }

@@ -212,7 +212,12 @@ def test_out_of_range_ids_raise_like_the_reference(gopher_flat):
         (np.array([[0, 2], [n, 4]]), n),                 # max too large -> max reported
         (np.array([[0, 2], [-3, 4]]), -3),               # only negative -> min reported
         (np.array([[-7, n + 5], [1, 2]]), n + 5),        # both -> max reported (MuchTree.pyx:897-903)
-        (np.array([[0, 2**40]]), 2**40),
+        (np.array([[0, 2**40]]), 2**40),                 # wider than the int32 transport of the host path
+        (np.array([[0, 2**40], [2**41 + 5, 1]]), 2**41 + 5),
+        (np.array([[-2**40, 2], [-5, 1]]), -2**40),
+        (np.array([[-2**40, n]]), n),
+        (np.array([[2**31 - 1, 0]]), 2**31 - 1),
+        (np.array([[-2**31, 0]]), -2**31),
     ]
     for pairs, bad in cases:
         with pytest.raises(InvalidNodeError) as e:
