@@ -22,6 +22,11 @@
  *   linked_distances pairs . SuchTree/MuchTree.pyx:2918-2925
  *   _quartet_topologies .... SuchTree/MuchTree.pyx:1331-1376
  *
+ * The C that Cython generated from those lines ships in the snapshot and settles the
+ * arithmetic: `float __pyx_v_d;` (SuchTree/MuchTree.c:32341), two plain
+ * `__pyx_v_d = (__pyx_v_d + data[n].distance)` statements in path order (:32435 a-side,
+ * :32475 b-side) and a widening store into the double result (:32496).
+ *
  * Pinning: the reference extension cannot be imported in the build
  * container (hard `import dendropy` at MuchTree.pyx:3; dendropy is not
  * installed and no stand-in is written for it).  The oracle is therefore
