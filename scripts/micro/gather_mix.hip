@@ -1,0 +1,75 @@
+// gather_mix.hip -- would splitting the understory records pay?  Emulates the memory side of
+// one pair: (A) two random 64-B-sector reads from one 64 MiB table [today], (B) one random
+// 8-byte read from an 8 MiB table + one random 32-byte read from a 32 MiB table [split],
+// each with the 16-byte pair stream in and 12 bytes out.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/gather_mix scripts/micro/gather_mix.hip && /tmp/gather_mix
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__device__ __forceinline__ uint32_t hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(1024) void k_mix(const uint8_t *__restrict__ ta, uint32_t mask_a, int stride_a,
+                                              const uint8_t *__restrict__ tb, uint32_t mask_b, int stride_b,
+                                              const longlong2 *__restrict__ pairs, long long n,
+                                              double *__restrict__ out_d, int *__restrict__ out_m)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        longlong2 p;
+        if (NT) { const ll2 v = __builtin_nontemporal_load(reinterpret_cast<const ll2 *>(&pairs[i])); p.x = v.x; p.y = v.y; }
+        else p = pairs[i];
+        const uint32_t ia = hash((uint32_t)p.x) & mask_a, ib = hash((uint32_t)p.y) & mask_b;
+        const uint8_t *pa = ta + (size_t)ia * stride_a, *pb = tb + (size_t)ib * stride_b;
+        uint32_t acc;
+        if (MODE == 0) {   // today: word0 + pbot of a (two dwords of one 64-B record), 32 B of b's record
+            acc = *reinterpret_cast<const uint32_t *>(pa) + *reinterpret_cast<const uint32_t *>(pa + 32);
+        } else {           // split: 8-byte a entry
+            const uint2 v = *reinterpret_cast<const uint2 *>(pa);
+            acc = v.x + v.y;
+        }
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(pb), b1 = *reinterpret_cast<const uint4 *>(pb + 16);
+        acc += b0.x + b1.w;
+        if (NT) { __builtin_nontemporal_store((double)acc, &out_d[i]); __builtin_nontemporal_store((int)acc, &out_m[i]); }
+        else { out_d[i] = (double)acc; out_m[i] = (int)acc; }
+    }
+}
+
+int main()
+{
+    const long long n = 100000000;
+    uint8_t *ta, *tb; longlong2 *pairs; double *od; int *om;
+    CK(hipMalloc(&ta, 128u << 20)); CK(hipMalloc(&tb, 128u << 20));
+    CK(hipMalloc(&pairs, n * 16)); CK(hipMalloc(&od, n * 8)); CK(hipMalloc(&om, n * 4));
+    CK(hipMemset(ta, 1, 128u << 20)); CK(hipMemset(tb, 1, 128u << 20));
+    {   // pseudo-random pair contents
+        uint64_t *h = (uint64_t *)malloc(n * 16);
+        uint64_t s = 88172645463325252ull;
+        for (long long i = 0; i < 2 * n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = s & 0xFFFFF; }
+        CK(hipMemcpy(pairs, h, n * 16, hipMemcpyHostToDevice)); free(h);
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char *name, auto kern, uint32_t ma, int sa, const uint8_t *tbp, uint32_t mb, int sb) -> int {
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3(512), dim3(1024), 0, 0, ta, ma, sa, tbp, mb, sb, pairs, n, od, om);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        printf("%-64s %7.3f ms  %6.2f G pairs/s\n", name, best, n / best / 1e6);
+        return 0;
+    };
+    const uint32_t M1 = (1u << 20) - 1;   // 1M leaves
+    if (run("today : a,b both from one 64 MiB table of 64-B records", k_mix<0, false>, M1, 64, ta, M1, 64)) return 1;
+    if (run("today + non-temporal stream loads/stores", k_mix<0, true>, M1, 64, ta, M1, 64)) return 1;
+    if (run("split : a from 8 MiB (8 B), b from 32 MiB (32 B)", k_mix<1, false>, M1, 8, tb, M1, 32)) return 1;
+    if (run("split + non-temporal stream loads/stores", k_mix<1, true>, M1, 8, tb, M1, 32)) return 1;
+    if (run("split : a from 8 MiB (8 B), b from 64 MiB (64-B records)", k_mix<1, false>, M1, 8, tb, M1, 64)) return 1;
+    if (run("floor : a and b from 2 MiB tables (L2 resident)", k_mix<1, false>, (1u << 15) - 1, 8, tb, (1u << 15) - 1, 32)) return 1;
+    return 0;
+}
