@@ -145,7 +145,7 @@ int st_quartets_host(st_tree *tree, const int64_t *quartets, int64_t n,
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
 /* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the
- * canopy kernel keeps in flight: 1, 2 or 4 (default 2); 0 = scalar form.
+ * canopy kernel keeps in flight: 1 or 2 (default 2); 0 = scalar form.
  * "lockstep": 1 (default) = the climb inside the canopy uses the depth cut (max(ka,kb)
  * rounds), 0 = "larger index moves up" (ka+kb rounds, one LDS read per round).
  * "flow": 1 = per-lane flow kernel (lanes advance through their own pairs without waiting

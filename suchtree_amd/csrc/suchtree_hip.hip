@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -729,18 +730,14 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, stream);
     } else {
-        const int ppl = (CAP >= 15 && t->pairs_per_lane > 2) ? 2 : t->pairs_per_lane;   // 4 x 15 chain registers would spill
+        const int ppl = std::min(t->pairs_per_lane, 2);
         if (ppl == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, stream);
         if (t->lockstep) {
             if (ppl == 1) return launch_canopy_k(k_canopy_ilp<CAP, 1, true, Src>, 1, t, P, src, n, out_d, out_m, stream);
-            if (ppl == 2) return launch_canopy_k(k_canopy_ilp<CAP, 2, true, Src>, 2, t, P, src, n, out_d, out_m, stream);
-            if constexpr (CAP < 15)
-                return launch_canopy_k(k_canopy_ilp<CAP, 4, true, Src>, 4, t, P, src, n, out_d, out_m, stream);
+            return launch_canopy_k(k_canopy_ilp<CAP, 2, true, Src>, 2, t, P, src, n, out_d, out_m, stream);
         } else {
             if (ppl == 1) return launch_canopy_k(k_canopy_ilp<CAP, 1, false, Src>, 1, t, P, src, n, out_d, out_m, stream);
-            if (ppl == 2) return launch_canopy_k(k_canopy_ilp<CAP, 2, false, Src>, 2, t, P, src, n, out_d, out_m, stream);
-            if constexpr (CAP < 15)
-                return launch_canopy_k(k_canopy_ilp<CAP, 4, false, Src>, 4, t, P, src, n, out_d, out_m, stream);
+            return launch_canopy_k(k_canopy_ilp<CAP, 2, false, Src>, 2, t, P, src, n, out_d, out_m, stream);
         }
         return hipErrorInvalidValue;
     }
@@ -841,6 +838,8 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
 }
 
 constexpr int64_t kHostChunk = (int64_t)1 << 22;   // pairs per pipeline chunk
+constexpr int kDeepCanopyDepth = 100;     // canopies deeper than this (edges) are "deep"
+constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
 
 // Push n pairs through the two-slot pipe (host_pipe.h).  pack(slot, off, m) fills
 // slot.h_in for chunk [off, off+m) with in_bytes_per_pair bytes per pair (0: generated pairs, no input);
@@ -957,7 +956,27 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
     std::string err;
     if (!prepare_basic(parent, distance, n_nodes, T, err)) return fail(ST_ERR_TREE, err);
     bool canopy_ok = false;
-    if (strategy != ST_STRATEGY_WALK) canopy_ok = prepare_canopy(parent, distance, T);
+    int max_canopy = 0;
+    bool deep = false;
+    if (const char *env = std::getenv("SUCHTREE_AMD_CANOPY_NODES")) max_canopy = std::atoi(env);   // tuning experiments
+    if (strategy != ST_STRATEGY_WALK) {
+        canopy_ok = prepare_canopy(parent, distance, T, max_canopy);
+        // Deep canopies (real, unbalanced phylogenies: hundreds of levels) spend their time in
+        // the LDS climb, not in memory.  There a canopy image small enough for two workgroups
+        // per CU, a longer understory (more of each lineage pre-summed in its record) and the
+        // branchy scalar kernel (finished lanes stop issuing LDS reads) measured 13-30 % faster.
+        if (canopy_ok && max_canopy == 0) {
+            int cdepth = 0;
+            for (const CanopyEntry &e : T.canopy) cdepth = std::max<int>(cdepth, (int)(e.link >> 16));
+            if (cdepth > kDeepCanopyDepth) {
+                deep = true;
+                if (T.canopy_nodes > kDeepCanopyNodes) {
+                    TreeTables T2 = T;
+                    if (prepare_canopy(parent, distance, T2, kDeepCanopyNodes)) T = std::move(T2);
+                }
+            }
+        }
+    }
     if (strategy == ST_STRATEGY_CANOPY && !canopy_ok)
         return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
 
@@ -976,6 +995,7 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
     t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     t->n_nodes = T.n;
     t->n_leaves = T.n_leaves;
+    if (deep) t->pairs_per_lane = 0;
     int64_t bytes = 0;
     int rc = upload(&t->d_nodes, T.nodes, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
@@ -1054,8 +1074,8 @@ int st_tree_set_option(st_tree *t, const char *name, int64_t value)
 {
     if (!t || !name) return fail(ST_ERR_ARG, "tree or name is NULL");
     if (std::strcmp(name, "pairs_per_lane") == 0) {
-        if (value != 0 && value != 1 && value != 2 && value != 4)
-            return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1, 2 or 4");
+        if (value != 0 && value != 1 && value != 2)
+            return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1 or 2");
         t->pairs_per_lane = (int)value;
         return ST_OK;
     }

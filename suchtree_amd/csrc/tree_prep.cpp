@@ -84,10 +84,11 @@ static int32_t pow2_ceil(int32_t v) {
     return p;
 }
 
-bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T)
+bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T, int max_canopy_nodes)
 {
     const int64_t n = T.n;
     T.has_canopy = false;
+    if (max_canopy_nodes <= 0 || max_canopy_nodes > kMaxCanopyNodes) max_canopy_nodes = kMaxCanopyNodes;
 
     // canopy(H) = { x : height(x) > H } is closed under "parent of", and the
     // longest lineage left below it has exactly H nodes.  Smallest H whose
@@ -99,8 +100,8 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T)
     for (int32_t h = hmax - 1; h >= 0; h--) count_ge[(size_t)h] += count_ge[(size_t)h + 1];
     // count(height > H) = count_ge[H+1]
     int32_t h_min = 0;
-    while (h_min < hmax && count_ge[(size_t)h_min + 1] > kMaxCanopyNodes) h_min++;
-    if (count_ge[(size_t)h_min + 1] > kMaxCanopyNodes) return false;   // cannot happen (count_ge[hmax+1] = 0)
+    while (h_min < hmax && count_ge[(size_t)h_min + 1] > max_canopy_nodes) h_min++;
+    if (count_ge[(size_t)h_min + 1] > max_canopy_nodes) return false;   // cannot happen (count_ge[hmax+1] = 0)
     int32_t rec_bytes = std::max(kMinRecordBytes, pow2_ceil(8 + 8 * h_min));
     if (rec_bytes > kMaxRecordBytes) return false;
     // use the whole record: a longer understory means a smaller canopy

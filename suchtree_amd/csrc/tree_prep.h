@@ -88,6 +88,8 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
 // Chooses the canopy and builds canopy + records.  Returns false (without
 // error) when the tree does not admit the canopy family (lineages below any
 // 16k-node canopy longer than a record can hold).
-bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T);
+// max_canopy_nodes <= 0: the LDS limit (kMaxCanopyNodes); smaller values trade a longer
+// understory (bigger records) for a smaller LDS image, i.e. more workgroups per CU.
+bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T, int max_canopy_nodes = 0);
 
 }  // namespace st

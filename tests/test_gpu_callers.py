@@ -31,7 +31,7 @@ def test_triangle_generator_equals_explicit_pairs(strategy, ml_arrays):
     ids = np.random.default_rng(4).choice(leaf_ids, size=700, replace=False)
     pairs = _tri_pairs(ids)
     want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
-    for flow, ppl in ((1, 2), (0, 0), (0, 1), (0, 2), (0, 4)):
+    for flow, ppl in ((1, 2), (0, 0), (0, 1), (0, 2)):
         dev.set_option("flow", flow)
         dev.set_option("pairs_per_lane", ppl)
         d, m = dev.triangle_host(ids, want_dist=True, want_mrca=True)

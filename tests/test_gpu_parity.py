@@ -35,7 +35,7 @@ def _both(dev, pairs):
             out["canopy/flow%d" % batch] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
         dev.set_option("flow_batch", 16)
         dev.set_option("flow", 0)
-        for ppl, lockstep in ((0, 1), (1, 0), (1, 1), (2, 0), (2, 1), (4, 0), (4, 1)):
+        for ppl, lockstep in ((0, 1), (1, 0), (1, 1), (2, 0), (2, 1)):
             dev.set_option("pairs_per_lane", ppl)
             dev.set_option("lockstep", lockstep)
             out["canopy/ppl%d%s" % (ppl, "" if lockstep else "/index-climb")] = \
@@ -93,7 +93,9 @@ def test_config2_bigtrees(which, ml_arrays, nj_arrays):
     parent, dist, leaf_ids = ml_arrays if which == "ml" else nj_arrays
     rng = np.random.default_rng(2)
     info = _check(parent, dist, rng.choice(leaf_ids, size=(300_000, 2)))
-    assert info["strategy"] == "canopy" and info["record_bytes"] == (64 if which == "ml" else 128)
+    # deep canopies (hundreds of levels) get the smaller LDS image and longer understory chains
+    assert info["strategy"] == "canopy" and info["canopy_nodes"] <= 10240
+    assert info["record_bytes"] == (128 if which == "ml" else 256)
     _check(parent, dist, rng.integers(0, len(parent), (100_000, 2)))      # internal nodes too
     a = np.arange(0, 60_000)
     _check(parent, dist, np.stack([a, a + rng.integers(0, 7, a.size)], 1))   # shared portals / understory MRCAs
