@@ -150,7 +150,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * rounds), 0 = "larger index moves up" (ka+kb rounds, one LDS read per round).
  * "flow": 1 = per-lane flow kernel (lanes advance through their own pairs without waiting
  * for the wave), 0 (default) = wave-synchronous kernels.
- * "flow_batch": lanes that must be waiting before the flow kernel refills (default 16). */
+ * "flow_batch": lanes that must be waiting before the flow kernel refills (default 16).
+ * "small_batch_path": 1 (default) = host batches of <= 2048 pairs go through a pinned,
+ * device-mapped mailbox (one launch + one synchronisation), 0 = through the staged pipe. */
 int st_tree_set_option(st_tree *tree, const char *name, int64_t value);
 
 /*

@@ -663,9 +663,15 @@ struct st_tree {
     int flow = 0;             // tuning: per-lane flow kernel 1 / 0 (measured: no faster than the ILP form, kept selectable)
     int flow_batch = 16;      // lanes that must be waiting before the flow kernel refills
     int canopy_depth = 0;     // deepest canopy node (edges)
+    int small_batch_path = 1; // tuning: batches <= kMailboxPairs go through the pinned mailbox
     // staging of the host entry points (one caller at a time per handle)
     std::mutex ws_mutex;
     HostPipe pipe;
+    // mailbox of the small-batch path: pinned host memory the kernel reads and writes directly
+    void *mb_host = nullptr;      // [pairs int64 x2 | dist double | mrca int32] x kMailboxPairs
+    void *mb_dev = nullptr;       // device alias of mb_host
+    Fault *d_fault_mb = nullptr;  // scratch fault word of that path (ids are checked on the host there)
+    hipStream_t mb_stream = nullptr;
 };
 
 static const Fault kFaultInit = {std::numeric_limits<long long>::min(),
@@ -840,6 +846,57 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
 constexpr int64_t kHostChunk = (int64_t)1 << 22;   // pairs per pipeline chunk
 constexpr int kDeepCanopyDepth = 100;     // canopies deeper than this (edges) are "deep"
 constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
+constexpr int64_t kMailboxPairs = 2048;   // largest batch served through the mailbox
+
+// Small batches (a scalar distance(a,b) call is a batch of one) are all latency: instead of
+// H2D copy + kernel + D2H copy + fault read-back, the walk kernel reads the pairs from and
+// writes the results to pinned host memory mapped into the device, so a call is one launch
+// and one stream synchronisation.  Ids are range-checked here on the host (the batch is
+// tiny), with the reference's choice of the id to report (MuchTree.pyx:897-903).
+static int small_batch(st_tree *t, const int64_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
+                       double *out_dist, int32_t *out_mrca, int64_t *bad_id)
+{
+    if (!t->mb_host) {
+        const size_t bytes = (size_t)kMailboxPairs * (16 + 8 + 4);
+        ST_HIP(hipHostMalloc(&t->mb_host, bytes, hipHostMallocMapped));
+        ST_HIP(hipHostGetDevicePointer(&t->mb_dev, t->mb_host, 0));
+        ST_HIP(hipMalloc(reinterpret_cast<void **>(&t->d_fault_mb), sizeof(Fault)));
+        ST_HIP(hipStreamCreateWithFlags(&t->mb_stream, hipStreamNonBlocking));
+    }
+    int64_t *h_pairs = static_cast<int64_t *>(t->mb_host);
+    double *h_dist = reinterpret_cast<double *>(h_pairs + 2 * kMailboxPairs);
+    int32_t *h_mrca = reinterpret_cast<int32_t *>(h_dist + kMailboxPairs);
+    long long max_id = std::numeric_limits<long long>::min(), min_id = std::numeric_limits<long long>::max();
+    for (int64_t k = 0; k < n; k++) {
+        const long long a = pairs[k * stride0], b = pairs[k * stride0 + stride1];
+        h_pairs[2 * k] = a;
+        h_pairs[2 * k + 1] = b;
+        max_id = std::max(max_id, std::max(a, b));
+        min_id = std::min(min_id, std::min(a, b));
+    }
+    if (min_id < 0 || max_id >= t->n_nodes) {
+        const long long bad = max_id >= t->n_nodes ? max_id : min_id;
+        if (bad_id) *bad_id = bad;
+        return fail(ST_ERR_BOUNDS, "Node ID " + std::to_string(bad) + " out of bounds (tree size: " +
+                                       std::to_string(t->n_nodes) + ")");
+    }
+    char *d_base = static_cast<char *>(t->mb_dev);
+    WalkParams P;
+    P.nodes = t->d_nodes;
+    P.depth = t->d_depth;
+    P.n_nodes = t->n_nodes;
+    const SrcContig src{reinterpret_cast<const long long *>(d_base)};
+    double *d_dist = reinterpret_cast<double *>(d_base + (size_t)kMailboxPairs * 16);
+    int32_t *d_mrca = reinterpret_cast<int32_t *>(d_base + (size_t)kMailboxPairs * 24);
+    hipLaunchKernelGGL(k_walk<SrcContig>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, t->mb_stream, P, src,
+                       (long long)n, DistSink{out_dist ? d_dist : nullptr, nullptr},
+                       out_mrca ? d_mrca : nullptr, t->d_fault_mb);
+    ST_HIP(hipGetLastError());
+    ST_HIP(hipStreamSynchronize(t->mb_stream));
+    if (out_dist) std::memcpy(out_dist, h_dist, (size_t)n * 8);
+    if (out_mrca) std::memcpy(out_mrca, h_mrca, (size_t)n * 4);
+    return ST_OK;
+}
 
 // Push n pairs through the two-slot pipe (host_pipe.h).  pack(slot, off, m) fills
 // slot.h_in for chunk [off, off+m) with in_bytes_per_pair bytes per pair (0: generated pairs, no input);
@@ -1047,6 +1104,9 @@ void st_tree_destroy(st_tree *t)
     (void)hipFree(t->d_records);
     (void)hipFree(t->d_fault);
     t->pipe.destroy();
+    if (t->mb_host) (void)hipHostFree(t->mb_host);
+    (void)hipFree(t->d_fault_mb);
+    if (t->mb_stream) (void)hipStreamDestroy(t->mb_stream);
     delete t;
 }
 
@@ -1077,6 +1137,10 @@ int st_tree_set_option(st_tree *t, const char *name, int64_t value)
         if (value != 0 && value != 1 && value != 2)
             return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1 or 2");
         t->pairs_per_lane = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "small_batch_path") == 0) {
+        t->small_batch_path = value != 0;
         return ST_OK;
     }
     if (std::strcmp(name, "flow") == 0) {
@@ -1126,6 +1190,8 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
     if (n == 0) return ST_OK;
     ST_DEVICE(t->device);
     std::lock_guard<std::mutex> lock(t->ws_mutex);
+    if (n <= kMailboxPairs && t->small_batch_path)
+        return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
 
     // Ids cross PCIe as int32 (half the H2D bytes).  Values that do not fit are clamped to
     // INT32_MAX / INT32_MIN -- still out of range for the kernel -- and their exact extremes

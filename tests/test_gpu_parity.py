@@ -86,6 +86,23 @@ def test_config1_gopher_1000_random_leaf_pairs(gopher_flat):
     leaf_ids = np.array(list(gopher_flat.leaves.values()))
     pairs = np.random.default_rng(1).choice(leaf_ids, size=(1000, 2)).astype(np.int64)
     _check(gopher_flat.parent, gopher_flat.distance, pairs)
+    # small batches: the pinned-mailbox path and the staged pipe must agree, for every batch
+    # size around the mailbox limit and for strided views
+    O = OracleTree(gopher_flat.parent, gopher_flat.distance)
+    dev = _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance)
+    big = np.random.default_rng(2).choice(leaf_ids, size=(5000, 2)).astype(np.int64)
+    for n in (1, 2, 63, 64, 65, 1000, 2047, 2048, 2049, 5000):
+        for mailbox in (1, 0):
+            dev.set_option("small_batch_path", mailbox)
+            for view in (big[:n], np.asfortranarray(big[:n]), big[:n][:, ::-1]):
+                d, m = dev.distances_host(view, True, True)
+                assert_bits_equal(d, O.distances(view), "n=%d mailbox=%d" % (n, mailbox))
+                assert np.array_equal(m, O.mrca_bulk(view))
+            d, _ = dev.distances_host(big[:n], True, False)
+            assert_bits_equal(d, O.distances(big[:n]))
+            _, m = dev.distances_host(big[:n], False, True)
+            assert np.array_equal(m, O.mrca_bulk(big[:n]))
+    dev.close()
 
 
 @pytest.mark.parametrize("which", ["ml", "nj"])
