@@ -315,3 +315,53 @@ def test_concurrent_callers_share_one_handle(ml_arrays):
     [t.join() for t in threads]
     for g, w in zip(got, want):
         assert_bits_equal(g, w)
+
+
+def _random_shape_tree(rng, n_leaves, skew):
+    """Random strictly binary tree whose split sizes are skewed towards caterpillars
+    (skew -> 1) or towards balance (skew -> 0); in-order ids."""
+    n = 2 * n_leaves - 1
+    parent = np.full(n, -1, dtype=np.int64)
+    stack = [(0, n - 1, -1)]
+    while stack:
+        lo, hi, par = stack.pop()
+        if lo == hi:
+            parent[lo] = par
+            continue
+        leaves = (hi - lo) // 2 + 1
+        if rng.random() < skew:
+            left = 1 if rng.random() < 0.5 else leaves - 1
+        else:
+            left = int(rng.integers(max(1, leaves // 2 - leaves // 8), min(leaves - 1, leaves // 2 + leaves // 8) + 1))
+        left = min(max(left, 1), leaves - 1)
+        node = lo + 2 * left - 1
+        parent[node] = par
+        stack.append((lo, node - 1, node))
+        stack.append((node + 1, hi, node))
+    dist = rng.uniform(1e-4, 3.0, size=n)
+    dist[rng.random(n) < 0.1] = np.finfo(np.float64).eps
+    dist[parent < 0] = -1.0
+    return parent.astype(np.int32), dist.astype(np.float32)
+
+
+def test_record_sizes_and_shapes_sweep():
+    """Every record stride the library can choose (16 ... 512 bytes) and both climb regimes,
+    on trees from perfectly balanced to nearly caterpillar."""
+    rng = np.random.default_rng(77)
+    seen = set()
+    cases = [(lv, None) for lv in range(11, 19)]                       # balanced: R = 16, 32, 64
+    cases += [(int(rng.integers(2000, 60000)), float(s)) for s in (0.0, 0.1, 0.3, 0.5, 0.7, 0.85, 0.95, 0.99)]
+    for size, skew in cases:
+        if skew is None:
+            parent, dist = synth.balanced_tree(size)
+        else:
+            parent, dist = _random_shape_tree(rng, size, skew)
+        n = len(parent)
+        pairs = rng.integers(0, n, (60_000, 2))
+        a = rng.integers(0, n - 40, 30_000)
+        near = np.stack([a, a + rng.integers(0, 40, a.size)], 1)
+        info = _check(parent, dist, np.concatenate([pairs, near]))
+        seen.add((info["strategy"], info["record_bytes"]))
+    strides = {r for s, r in seen if s == "canopy"}
+    # (128-byte records: ml.tree in test_config2_bigtrees)
+    assert {16, 32, 64, 256, 512}.issubset(strides), seen
