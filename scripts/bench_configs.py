@@ -177,6 +177,22 @@ def main():
              GBps_over_pcie=n * 16 / t / 1e9, pcie_bytes_per_pair="8 in (int32 ids) + 4 (float32) + 4 (int32) out")
         tree.close()
 
+    if "quartets" in todo:
+        # row f4: quartet topologies (6 MRCAs per quartet), host numpy in/out
+        for name in ("ml",):
+            z = np.load(os.path.join(G, "%s_tree.npz" % name))
+            parent, dist, leaf_ids = z["parent"], z["distance"], z["leaf_ids"].astype(np.int64)
+            T = SuchTree((parent, dist)).to_device()
+            O = OracleTree(parent, dist)
+            q = np.random.default_rng(8).choice(leaf_ids, size=(4_000_000, 4))
+            got = T.quartet_topologies_bulk(q)
+            ok = np.array_equal(got[:200_000], O.quartets(q[:200_000]))
+            t = timed(lambda: T.quartet_topologies_bulk(q), reps=3)
+            t_cpu = timed(lambda: O.quartets(q[:100_000]), reps=1)
+            emit(fh, config="f4-quartets", tree=name + ".tree", quartets=len(q), quartets_per_s=len(q) / t,
+                 cpu_oracle_quartets_per_s_single_thread=100_000 / t_cpu,
+                 parity="bit-exact on 200000" if ok else "MISMATCH")
+
     if "5" in todo:
         import pandas as pd
         d = os.path.join(G, "fish_worm")
