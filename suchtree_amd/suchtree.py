@@ -94,6 +94,22 @@ class SuchTree:
             self._dev_tree.close()
             self._dev_tree = None
 
+    # trees travel between processes as their flat arrays; every process uploads its own copy
+    # (the reference's users parallelise with fork pools, docs/examples/SuchTree_examples.md:462-497)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_dev_tree"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._dev_tree = None
+
+    def __repr__(self) -> str:
+        return "<SuchTree %d nodes, %d leaves, depth %d, device %d%s>" % (
+            self.size, self.num_leaves, self.depth, self._device,
+            "" if self._dev_tree is None else ", resident")
+
     # -------------------------------------------------------------- properties
     @property
     def size(self) -> int:

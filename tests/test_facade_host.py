@@ -119,3 +119,11 @@ def test_missing_library_is_reported(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "libsuchtree_hip.so"))
     with pytest.raises(HipBackendError, match="not built"):
         _capi.load()
+
+
+def test_pickle_round_trip_drops_the_device_handle(T):
+    import pickle
+    T2 = pickle.loads(pickle.dumps(T))
+    assert T2.leaves == T.leaves and T2.size == T.size and T2._dev_tree is None
+    assert np.array_equal(T2._flat.parent, T._flat.parent)
+    assert "29 nodes" in repr(T2)
