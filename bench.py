@@ -197,7 +197,10 @@ def main():
                        "sharding": "pairs sharded across ranks, tree replicated, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None if not traffic else traffic.get("hbm_bytes_per_launch"),
+                         # PMC-derived HBM bytes per launch (profiled at pairs_per_launch pairs; scaled
+                         # linearly if this run uses another batch size)
+                         "traffic": None if not traffic or not traffic.get("hbm_bytes_per_launch") else
+                         traffic["hbm_bytes_per_launch"] * n / traffic.get("pairs_per_launch", n),
                          "kernel": "k_canopy_ilp" if info["strategy"] == "canopy" else "k_walk",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_pair": bytes_per_pair,
                          "mean_path_edges": h_mean, "pairs_per_launch": n,
