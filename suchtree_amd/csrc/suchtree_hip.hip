@@ -157,6 +157,22 @@ struct DistSink {
     __host__ __device__ bool any() const { return d64 != nullptr || f32 != nullptr; }
 };
 
+// The six pairs of a quartet (a,b,c,d), in the reference's order ab ac ad bc bd cd
+// (MuchTree.pyx:1353-1358): pair i is combination i % 6 of quartet i / 6.  Lets the canopy
+// kernels produce the six MRCA ids of every quartet without a pair array.
+struct SrcQuartet {
+    const long long *q;   // C-order int64 (n,4)
+    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
+    {
+        const long long quartet = i / 6;
+        const int combo = (int)(i - quartet * 6);
+        const int ia = (0x940 >> (2 * combo)) & 3;    // 0 0 0 1 1 2
+        const int ib = (0xFB9 >> (2 * combo)) & 3;    // 1 2 3 2 3 3
+        a = q[quartet * 4 + ia];
+        b = q[quartet * 4 + ib];
+    }
+};
+
 __device__ __forceinline__ void store_result(const DistSink &out_d, int *__restrict__ out_m,
                                              long long i, float d, int m)
 {
@@ -237,6 +253,45 @@ __global__ __launch_bounds__(256) void k_quartets(WalkParams P, const long long 
         }
         // I[pick] = {pa, pb, the other two in increasing order}
         const int a = pa[pick], b = pb[pick];
+        int rest[2], r = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k != a && k != b) { if (r < 2) rest[r] = k; r++; }
+        out[i * 4 + 0] = id[a];
+        out[i * 4 + 1] = id[b];
+        out[i * 4 + 2] = id[rest[0]];
+        out[i * 4 + 3] = id[rest[1]];
+    }
+}
+
+// Second half of the quartet path when the MRCA ids came from a canopy launch over
+// SrcQuartet: M[6*i .. 6*i+5] are the ids of quartet i (-1 where an id was out of range).
+__global__ __launch_bounds__(256) void k_quartet_pick(const long long *__restrict__ q, const int *__restrict__ M,
+                                                      long long n, long long *__restrict__ out)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int m[6];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { m[j] = M[i * 6 + j]; bad |= m[j] < 0; }
+        long long id[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) id[k] = q[i * 4 + k];
+        if (bad) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[i * 4 + k] = -1;
+            continue;
+        }
+        int pick = 5;
+#pragma unroll
+        for (int j = 5; j >= 0; j--) {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) c += m[j] == m[k];
+            if (c == 1) pick = j;
+        }
+        const int a = (0x940 >> (2 * pick)) & 3, b = (0xFB9 >> (2 * pick)) & 3;
         int rest[2], r = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -667,6 +722,8 @@ struct st_tree {
     // staging of the host entry points (one caller at a time per handle)
     std::mutex ws_mutex;
     HostPipe pipe;
+    void *q_tmp = nullptr;        // MRCA ids of the quartet path (6 int32 per quartet)
+    int64_t q_tmp_cap = 0;
     // mailbox of the small-batch path: pinned host memory the kernel reads and writes directly
     void *mb_host = nullptr;      // [pairs int64 x2 | dist double | mrca int32] x kMailboxPairs
     void *mb_dev = nullptr;       // device alias of mb_host
@@ -1104,6 +1161,7 @@ void st_tree_destroy(st_tree *t)
     (void)hipFree(t->d_records);
     (void)hipFree(t->d_fault);
     t->pipe.destroy();
+    (void)hipFree(t->q_tmp);
     if (t->mb_host) (void)hipHostFree(t->mb_host);
     (void)hipFree(t->d_fault_mb);
     if (t->mb_stream) (void)hipStreamDestroy(t->mb_stream);
@@ -1320,9 +1378,26 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         });
         ST_HIP(hipMemcpyAsync(in.d_in, in.h_in, (size_t)m * 32, hipMemcpyHostToDevice, in.stream));
         int64_t blocks = std::min<int64_t>((m + 255) / 256, (int64_t)t->n_cu * 16);
-        hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, in.stream, P,
-                           static_cast<const long long *>(in.d_in), (long long)m, 4LL, 1LL,
-                           static_cast<long long *>(out.d_in), t->d_fault);
+        if (t->strategy == ST_STRATEGY_CANOPY && 6 * m >= kCanopyMinPairs) {
+            // six MRCA ids per quartet out of the canopy kernels, then the pick
+            if (t->q_tmp_cap < m) {
+                (void)hipFree(t->q_tmp);
+                t->q_tmp = nullptr;
+                t->q_tmp_cap = 0;
+                ST_HIP(hipMalloc(&t->q_tmp, (size_t)chunk * 24));
+                t->q_tmp_cap = chunk;
+            }
+            const int rc = enqueue_src(t, SrcQuartet{static_cast<const long long *>(in.d_in)}, 6 * m,
+                                       DistSink{nullptr, nullptr}, static_cast<int32_t *>(t->q_tmp), in.stream);
+            if (rc != ST_OK) return rc;
+            hipLaunchKernelGGL(k_quartet_pick, dim3((unsigned)blocks), dim3(256), 0, in.stream,
+                               static_cast<const long long *>(in.d_in), static_cast<const int *>(t->q_tmp),
+                               (long long)m, static_cast<long long *>(out.d_in));
+        } else {
+            hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, in.stream, P,
+                               static_cast<const long long *>(in.d_in), (long long)m, 4LL, 1LL,
+                               static_cast<long long *>(out.d_in), t->d_fault);
+        }
         ST_HIP(hipGetLastError());
         ST_HIP(hipMemcpyAsync(out.h_in, out.d_in, (size_t)m * 32, hipMemcpyDeviceToHost, in.stream));
         ST_HIP(hipStreamSynchronize(in.stream));

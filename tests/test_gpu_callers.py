@@ -139,6 +139,10 @@ def test_quartet_topologies(ml_arrays):
     got = T.quartet_topologies_bulk(q)
     assert got.dtype == np.int64 and got.shape == q.shape
     assert np.array_equal(got, O.quartets(q))
+    for strategy in ("walk", "canopy"):            # MRCA ids from either kernel family
+        T._device_tree().set_strategy(strategy)
+        assert np.array_equal(T.quartet_topologies_bulk(q), got), strategy
+        assert np.array_equal(T.quartet_topologies_bulk(q[:100]), got[:100]), strategy
     assert np.array_equal(np.sort(got, axis=1), np.sort(q, axis=1))
     qi = rng.integers(0, len(parent), (20_000, 4))             # internal nodes, repeated ids
     assert np.array_equal(T.quartet_topologies_bulk(qi), O.quartets(qi))
