@@ -212,3 +212,34 @@ def test_more_than_2_31_pairs_in_one_launch():
     assert_bits_equal(tail, want_d[: len(tail)])
     assert float(out_d.sum().item()) > 0
     dev.close()
+
+
+def test_torch_interop_device_resident(ml_arrays):
+    import torch
+    from suchtree_amd import torch_interop
+    parent, dist, leaf_ids = ml_arrays
+    T = SuchTree((parent, dist))
+    O = OracleTree(parent, dist)
+    host = np.random.default_rng(21).choice(leaf_ids, size=(300_000, 2))
+    pairs = torch.from_numpy(host).cuda()
+    d, m = torch_interop.distances_device(T, pairs)
+    assert d.dtype == torch.float64 and m.dtype == torch.int32 and d.is_cuda
+    assert_bits_equal(d.cpu().numpy(), O.distances(host))
+    assert np.array_equal(m.cpu().numpy(), O.mrca_bulk(host))
+    # strided views: swapped columns, every other row
+    d2, _ = torch_interop.distances_device(T, pairs[::2], want_mrca=False)
+    assert_bits_equal(d2.cpu().numpy(), O.distances(host[::2]))
+    cols = torch.from_numpy(np.ascontiguousarray(host.T)).cuda().t()      # column-major storage
+    d3, m3 = torch_interop.distances_device(T, cols)
+    assert_bits_equal(d3.cpu().numpy(), O.distances(host))
+    bad = pairs.clone()
+    bad[17, 1] = len(parent)
+    with pytest.raises(InvalidNodeError):
+        torch_interop.distances_device(T, bad)
+    with pytest.raises(ValueError):
+        torch_interop.distances_device(T, pairs.to(torch.int32))
+    ids = torch.from_numpy(np.ascontiguousarray(leaf_ids[:500])).cuda()
+    tri, _ = torch_interop.triangle_device(T, ids)
+    rows, cols_ = np.tril_indices(500, -1)
+    want = O.distances(np.stack([leaf_ids[:500][cols_], leaf_ids[:500][rows]], 1))
+    assert_bits_equal(tri.cpu().numpy(), want)
