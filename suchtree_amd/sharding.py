@@ -90,3 +90,44 @@ def distances_sharded(tree, pairs, group=None, gather: bool = True,
         out_d[glo:ghi] = all_d[g, : ghi - glo]
         out_m[glo:ghi] = all_m[g, : ghi - glo]
     return out_d, out_m
+
+
+def distances_sharded_device(tree, pairs, group=None, gather: bool = True):
+    """Device-resident form: ``pairs`` is an int64 (n,2) CUDA/HIP tensor present on every
+    rank's GPU; each rank computes its contiguous slice with the HIP kernels and the result
+    slices are all-gathered GPU-to-GPU (RCCL over xGMI) -- nothing touches the host.
+    Returns ``(dist float64[n], mrca int32[n])`` tensors on this rank's GPU (or this rank's
+    slice and its bounds with ``gather=False``)."""
+    import torch
+    import torch.distributed as dist
+    from . import torch_interop
+
+    n = int(pairs.shape[0])
+    if group is None and not dist.is_initialized():
+        world, rank = 1, 0
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(n, world, rank)
+    d, m = torch_interop.distances_device(tree, pairs[lo:hi])
+    if not gather:
+        return d, m, (lo, hi)
+    if world == 1:
+        return d, m
+    width = (n + world - 1) // world
+    buf_d = torch.zeros(width, dtype=torch.float64, device=pairs.device)
+    buf_m = torch.zeros(width, dtype=torch.int32, device=pairs.device)
+    buf_d[: hi - lo] = d
+    buf_m[: hi - lo] = m
+    all_d = torch.empty(world * width, dtype=torch.float64, device=pairs.device)
+    all_m = torch.empty(world * width, dtype=torch.int32, device=pairs.device)
+    dist.all_gather_into_tensor(all_d, buf_d, group=group)
+    dist.all_gather_into_tensor(all_m, buf_m, group=group)
+    if n == world * width:
+        return all_d, all_m
+    out_d = torch.empty(n, dtype=torch.float64, device=pairs.device)
+    out_m = torch.empty(n, dtype=torch.int32, device=pairs.device)
+    for g in range(world):
+        glo, ghi = shard_bounds(n, world, g)
+        out_d[glo:ghi] = all_d[g * width: g * width + (ghi - glo)]
+        out_m[glo:ghi] = all_m[g * width: g * width + (ghi - glo)]
+    return out_d, out_m

@@ -243,3 +243,30 @@ def test_torch_interop_device_resident(ml_arrays):
     rows, cols_ = np.tril_indices(500, -1)
     want = O.distances(np.stack([leaf_ids[:500][cols_], leaf_ids[:500][rows]], 1))
     assert_bits_equal(tri.cpu().numpy(), want)
+
+
+def test_sharded_device_path_with_rccl_single_rank(ml_arrays):
+    """The device-resident sharded call through a real RCCL process group (one rank here;
+    the slicing / gather arithmetic for more ranks is covered by the gloo tests)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    parent, dist_arr, leaf_ids = ml_arrays
+    T = SuchTree((parent, dist_arr))
+    O = OracleTree(parent, dist_arr)
+    host = np.random.default_rng(31).choice(leaf_ids, size=(100_001, 2))
+    pairs = torch.from_numpy(host).cuda()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        d, m = sharding.distances_sharded_device(T, pairs)
+        ds, ms, (lo, hi) = sharding.distances_sharded_device(T, pairs, gather=False)
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t)
+    finally:
+        dist.destroy_process_group()
+    assert (lo, hi) == (0, 100_001) and torch.equal(ds, d) and torch.equal(ms, m)
+    assert_bits_equal(d.cpu().numpy(), O.distances(host))
+    assert np.array_equal(m.cpu().numpy(), O.mrca_bulk(host))
