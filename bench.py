@@ -90,6 +90,11 @@ def latest_traffic():
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when a
+    # communicator is created, so everything else is sent to stderr until the line is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist_
 
@@ -227,7 +232,10 @@ def main():
                                        out_m[:k].cpu().numpy(), args.cpu_seconds)
             line["cpu_baseline"] = cpu
             line["parity"] = parity
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist_.barrier()
         dist_.destroy_process_group()
