@@ -1,0 +1,122 @@
+// sanitize_main.cpp -- TEST INFRASTRUCTURE ONLY.
+// Address/UB-sanitizer run of the product's host-side C++ (table construction, per-pair
+// functions compiled for the host, native Newick ingest) on generated trees.  Built and run
+// by tests/test_sanitizers.py with g++ -fsanitize=address,undefined; exits non-zero on any
+// finding or on a mismatch between the walk and canopy families.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/suchtree_hip.h"
+#include "../../suchtree_amd/csrc/pair_math.h"
+#include "../../suchtree_amd/csrc/tree_prep.h"
+
+using namespace st;
+
+static void random_tree(std::mt19937_64 &rng, int n_leaves, double skew, std::vector<int32_t> &parent,
+                        std::vector<float> &dist)
+{
+    const int n = 2 * n_leaves - 1;
+    parent.assign(n, -1);
+    dist.assign(n, -1.0f);
+    struct Item { int lo, hi, par; };
+    std::vector<Item> stack{{0, n - 1, -1}};
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.lo == it.hi) { parent[it.lo] = it.par; continue; }
+        const int leaves = (it.hi - it.lo) / 2 + 1;
+        int left = U(rng) < skew ? (U(rng) < 0.5 ? 1 : leaves - 1) : 1 + (int)(U(rng) * (leaves - 1));
+        if (left < 1) left = 1;
+        if (left > leaves - 1) left = leaves - 1;
+        const int node = it.lo + 2 * left - 1;
+        parent[node] = it.par;
+        stack.push_back({it.lo, node - 1, node});
+        stack.push_back({node + 1, it.hi, node});
+    }
+    for (int i = 0; i < n; i++)
+        if (parent[i] >= 0) dist[i] = U(rng) < 0.1 ? 2.220446e-16f : (float)(U(rng) * 2.0);
+}
+
+static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_canopy)
+{
+    std::vector<int32_t> parent;
+    std::vector<float> dist;
+    random_tree(rng, n_leaves, skew, parent, dist);
+    TreeTables T;
+    std::string err;
+    if (!prepare_basic(parent.data(), dist.data(), (int64_t)parent.size(), T, err)) {
+        std::printf("prepare_basic failed: %s\n", err.c_str());
+        return 1;
+    }
+    const bool canopy = prepare_canopy(parent.data(), dist.data(), T, max_canopy);
+    const int64_t n = T.n;
+    std::uniform_int_distribution<int64_t> pick(0, n - 1);
+    for (int k = 0; k < 20000; k++) {
+        const int64_t a = pick(rng), b = k % 3 == 0 ? std::min<int64_t>(n - 1, a + k % 17) : pick(rng);
+        const PairResult w = pair_walk(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
+        if (pair_walk_mrca(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b) != w.mrca) return 2;
+        if (!canopy) continue;
+        const RecView A = rec_view(T.records.data(), record_slot(a, T.parity_layout, T.n_leaves), T.record_bytes);
+        const RecView B = rec_view(T.records.data(), record_slot(b, T.parity_layout, T.n_leaves), T.record_bytes);
+        const PairResult c = A.portal != B.portal
+            ? pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), A.portal, A.pbot, B.portal, B.D, B.nb)
+            : pair_canopy_same_portal(T.canopy_id.data(), A, B);
+        if (c.mrca != w.mrca || std::memcmp(&c.dist, &w.dist, 4) != 0) {
+            std::printf("mismatch leaves=%d skew=%g pair (%lld,%lld)\n", n_leaves, skew, (long long)a, (long long)b);
+            return 3;
+        }
+    }
+    return 0;
+}
+
+static int check_newick(std::mt19937_64 &rng)
+{
+    const char *texts[] = {"(A,B,(C,D));", "((a:1,b:2)0.9:3,(c:1,(d:1,e:2,f:3,g:4):0)x:2);", "A;", "((A,B);",
+                           "(A:1,B:2", "[c](A[x]:1,'q''r':2)[y];", "(,);", "(A:1e400,B:-0.0);", "", ")("};
+    for (const char *t : texts) {
+        st_newick *h = nullptr;
+        int64_t n = 0, nl = 0, nb = 0;
+        int32_t root = 0, depth = 0;
+        if (st_newick_open(t, (int64_t)std::strlen(t), &h, &n, &nl, &nb, &root, &depth) == ST_OK) {
+            std::vector<int32_t> p(n), l(n), r(n), ids(nl);
+            std::vector<float> s(n), d(n);
+            std::vector<char> names((size_t)nb + 1);
+            std::vector<int64_t> off(nl + 1);
+            st_newick_fill(h, p.data(), l.data(), r.data(), s.data(), d.data(), ids.data(), names.data(), off.data());
+            st_newick_close(h);
+        }
+    }
+    // random bytes must never crash the parser
+    std::uniform_int_distribution<int> ch(0, 11);
+    const char alphabet[] = "(),:;'[]A1. ";
+    for (int k = 0; k < 3000; k++) {
+        std::string t;
+        const int len = 1 + (int)(rng() % 60);
+        for (int i = 0; i < len; i++) t.push_back(alphabet[ch(rng)]);
+        st_newick *h = nullptr;
+        if (st_newick_open(t.data(), (int64_t)t.size(), &h, nullptr, nullptr, nullptr, nullptr, nullptr) == ST_OK)
+            st_newick_close(h);
+    }
+    return 0;
+}
+
+int main()
+{
+    std::mt19937_64 rng(12345);
+    const int sizes[] = {1, 2, 3, 7, 64, 1000, 20000};
+    const double skews[] = {0.0, 0.5, 0.9, 0.999};
+    for (int n : sizes)
+        for (double s : skews)
+            for (int cap : {0, 64, 1}) {
+                const int rc = check_tree(rng, n, s, cap);
+                if (rc) { std::printf("FAILED rc=%d\n", rc); return rc; }
+            }
+    if (check_newick(rng)) return 9;
+    std::printf("sanitize ok\n");
+    return 0;
+}

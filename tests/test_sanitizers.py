@@ -1,0 +1,23 @@
+"""AddressSanitizer + UBSan over the product's host-side C++ (CPU only; GPU sanitizers are
+not available on the pool).  Builds tests/emu/sanitize_main.cpp with the product sources."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_code_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "sanitize_main")
+    csrc = os.path.join(ROOT, "suchtree_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "emu", "sanitize_main.cpp"),
+           os.path.join(csrc, "tree_prep.cpp"), os.path.join(csrc, "newick_parse.cpp")]
+    subprocess.check_call(cmd)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "sanitize ok" in out.stdout
