@@ -365,3 +365,21 @@ def test_record_sizes_and_shapes_sweep():
     strides = {r for s, r in seen if s == "canopy"}
     # (128-byte records: ml.tree in test_config2_bigtrees)
     assert {16, 32, 64, 256, 512}.issubset(strides), seen
+
+
+def test_general_trees_through_the_c_abi():
+    """Arbitrary arity and arbitrary node numbering (not what the facade produces, but what the
+    C ABI accepts): records in identity order, checked against the plain-Python restatement."""
+    from oracle.oracle import py_distances, py_mrca
+    from test_tables_emulated import _general_tree
+    for n, max_children in ((400, 2), (3000, 3), (20000, 8)):
+        rng = np.random.default_rng(n)
+        parent, dist = _general_tree(rng, n, max_children)
+        pairs = rng.integers(0, n, (6000, 2))
+        want_d = py_distances(parent, dist, pairs)
+        want_m = np.array([py_mrca(parent, int(a), int(b)) for a, b in pairs])
+        dev = _capi.DeviceTree(parent, dist)
+        for name, (d, m) in _both(dev, pairs).items():
+            assert_bits_equal(d, want_d, name)
+            assert np.array_equal(m, want_m), name
+        dev.close()

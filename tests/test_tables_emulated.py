@@ -109,3 +109,39 @@ def test_bad_trees_are_rejected(emulator):
         emulator.run(np.array([1, 2, 0]), np.zeros(3), np.array([[0, 1]]), "walk")   # cycle
     with pytest.raises(RuntimeError):
         emulator.run(np.array([-1, -1]), np.zeros(2), np.array([[0, 1]]), "walk")    # two roots
+
+
+def _general_tree(rng, n, max_children):
+    """Random rooted tree with arbitrary arity and arbitrary node numbering (what a C-ABI caller
+    other than the facade may hand over): parent[] only, no in-order structure."""
+    order = rng.permutation(n)
+    parent = np.full(n, -1, dtype=np.int32)
+    n_child = np.zeros(n, dtype=np.int64)
+    for k in range(1, n):
+        while True:
+            p = order[rng.integers(max(0, k - 50), k)]
+            if n_child[p] < max_children:
+                break
+        parent[order[k]] = p
+        n_child[p] += 1
+    dist = rng.uniform(0.01, 2.0, n).astype(np.float32)
+    dist[order[0]] = -1.0
+    return parent, dist
+
+
+@pytest.mark.parametrize("n,max_children", [(50, 1), (400, 2), (3000, 3), (20000, 8)])
+def test_general_trees_through_the_c_tables(emulator, n, max_children):
+    """The table builder does not rely on the tree being binary or numbered in order: unary
+    chains, wide polytomies and shuffled ids go through both families (records in identity
+    order, `parity` off) and agree with the plain-Python restatement of the reference."""
+    from oracle.oracle import py_distances, py_mrca
+    rng = np.random.default_rng(n)
+    parent, dist = _general_tree(rng, n, max_children)
+    pairs = rng.integers(0, n, (3000, 2))
+    want_d = py_distances(parent, dist, pairs)
+    want_m = np.array([py_mrca(parent, int(a), int(b)) for a, b in pairs])
+    for strategy in ("walk", "canopy"):
+        d, m, info = emulator.run(parent, dist, pairs, strategy)
+        assert_bits_equal(d, want_d, strategy)
+        assert np.array_equal(m, want_m), strategy
+    assert info.parity == 0
