@@ -10,6 +10,16 @@
 //           everything below it is folded into one fixed-stride understory
 //           record per node, so a pair costs two record reads from HBM plus an
 //           LDS climb instead of ~h dependent global gathers.
+//           k_canopy      scalar, branchy (default for deep canopies)
+//           k_canopy_ilp  1-2 pairs per lane, predicated (default otherwise)
+//           k_canopy_flow per-lane state machine (selectable)
+//
+// Every kernel is templated on a pair source (SrcContig / SrcContig32 / SrcStrided /
+// SrcTriangle / SrcQuartet): an explicit (n,2) array in HBM, or pairs derived from their
+// index (all-pairs triangle, the six pairs of a quartet).
+//
+// Host side of the C ABI: tree upload (tree_prep.cpp builds the tables), the staged
+// host path (host_pipe.h), the small-batch mailbox, fault read-back.
 //
 // Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <hip/hip_runtime.h>
