@@ -232,6 +232,13 @@ def test_torch_interop_device_resident(ml_arrays):
     cols = torch.from_numpy(np.ascontiguousarray(host.T)).cuda().t()      # column-major storage
     d3, m3 = torch_interop.distances_device(T, cols)
     assert_bits_equal(d3.cpu().numpy(), O.distances(host))
+    # a C-order view whose base is only 8-byte aligned (no 16-byte vector loads possible)
+    flat = torch.empty(2 * len(host) + 1, dtype=torch.int64, device="cuda")
+    flat[1:] = pairs.reshape(-1)
+    odd = flat[1:].view(-1, 2)
+    assert odd.data_ptr() % 16 == 8
+    d4, m4 = torch_interop.distances_device(T, odd)
+    assert torch.equal(d4, d) and torch.equal(m4, m)
     bad = pairs.clone()
     bad[17, 1] = len(parent)
     with pytest.raises(InvalidNodeError):

@@ -218,6 +218,12 @@ def test_strides_and_dtypes_through_the_facade(ml_arrays):
     assert_bits_equal(T.distances_bulk(pairs[::-1])[::-1], want)
     assert_bits_equal(T.distances_bulk(pairs.astype(np.int32)), want)
     assert_bits_equal(T.distances_bulk(pairs[:100].tolist()), want[:100])
+    # more than one pipeline chunk (2^22 pairs) of a strided view
+    big = np.asfortranarray(np.random.default_rng(8).choice(leaf_ids, size=(6_000_000, 2)))
+    got = T.distances_bulk(big)
+    pick = np.random.default_rng(9).integers(0, len(big), 200_000)
+    assert_bits_equal(got[pick], O.distances(np.ascontiguousarray(big[pick])))
+    assert_bits_equal(got[-1000:], O.distances(np.ascontiguousarray(big[-1000:])))
     d, m = T.distances_and_ancestors_bulk(pairs)
     assert_bits_equal(d, want)
     assert np.array_equal(m, O.mrca_bulk(pairs))
