@@ -1,0 +1,85 @@
+"""Soak test on the GPU box: random batch sizes / layouts / output selections / kernel options,
+several host threads sharing handles, results checked against the oracle.  Not part of the
+pytest suite (minutes long); run manually:  python scripts/soak_gpu.py --seconds 180"""
+import argparse
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--threads", type=int, default=4)
+    args = ap.parse_args()
+    from oracle.oracle import OracleTree
+    from suchtree_amd import _capi, synth
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ml_tree.npz"))
+    trees = [(z["parent"], z["distance"]), synth.balanced_tree(16), synth.random_binary_tree(30000, seed=3),
+             synth.caterpillar_tree(2500)]
+    devs = [_capi.DeviceTree(p, d) for p, d in trees]
+    oracles = [OracleTree(p, d) for p, d in trees]
+    stop = time.time() + args.seconds
+    errors, counts = [], [0] * args.threads
+
+    def worker(tid):
+        rng = np.random.default_rng(1000 + tid)
+        while time.time() < stop and not errors:
+            k = int(rng.integers(0, len(devs)))
+            dev, O, n_nodes = devs[k], oracles[k], len(trees[k][0])
+            n = int(10 ** rng.uniform(0, 6.3))
+            pairs = rng.integers(0, n_nodes, (n, 2))
+            layout = rng.integers(0, 4)
+            if layout == 1:
+                view = np.asfortranarray(pairs)
+            elif layout == 2:
+                wide = np.zeros((n, 5), dtype=np.int64)
+                wide[:, 1::3] = pairs
+                view = wide[:, 1::3]
+            elif layout == 3:
+                view = pairs.astype(np.int64)[::-1][::-1]
+            else:
+                view = pairs
+            want_d, want_m = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            if not (want_d or want_m):
+                want_d = True
+            try:
+                if rng.random() < 0.3:
+                    dev.set_option("pairs_per_lane", int(rng.choice([0, 1, 2])))
+                    dev.set_option("small_batch_path", int(rng.integers(0, 2)))
+                d, m = dev.distances_host(view, want_d, want_m)
+                s = min(n, 20000)
+                if want_d and not np.array_equal(d[:s].view(np.int64), O.distances(pairs[:s]).view(np.int64)):
+                    errors.append("dist mismatch tree %d n %d layout %d" % (k, n, layout))
+                if want_m and not np.array_equal(m[:s], O.mrca_bulk(pairs[:s])):
+                    errors.append("mrca mismatch tree %d n %d layout %d" % (k, n, layout))
+                if n > 10 and rng.random() < 0.1:
+                    bad = pairs.copy()
+                    bad[int(rng.integers(0, n)), int(rng.integers(0, 2))] = n_nodes + 3
+                    try:
+                        dev.distances_host(bad, True, False)
+                        errors.append("missing bounds error")
+                    except _capi.InvalidNodeError as e:
+                        if e.node_id != n_nodes + 3:
+                            errors.append("wrong bad id %r" % e.node_id)
+                counts[tid] += 1
+            except Exception as e:   # noqa: BLE001
+                errors.append("exception %r" % (e,))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(args.threads)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    print("calls per thread:", counts, "errors:", errors[:5])
+    for d in devs:
+        d.close()
+    sys.exit(1 if errors else 0)
+
+
+if __name__ == "__main__":
+    main()
