@@ -263,8 +263,13 @@ def test_sharded_device_path_with_rccl_single_rank(ml_arrays):
     O = OracleTree(parent, dist_arr)
     host = np.random.default_rng(31).choice(leaf_ids, size=(100_001, 2))
     pairs = torch.from_numpy(host).cuda()
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29544")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
