@@ -140,6 +140,18 @@ int st_quartets_host(st_tree *tree, const int64_t *quartets, int64_t n,
                      int64_t stride0, int64_t stride1,
                      int64_t *out_topologies, int64_t *bad_id);
 
+/*
+ * Dense graph matrices of SuchLinkedTrees: adjacency A (A[u][v] = A[v][u] = w per edge) and
+ * Laplacian L = diag(column sums of A) - A, both n x n float64, C order; either output may
+ * be NULL.  Replaces the numpy assembly at the end of SuchLinkedTrees.adjacency / .laplacian
+ * (SuchTree/MuchTree.pyx:3110-3145); the edge list (tree edges normalised by the largest
+ * edge, link edges at the mean weight, :3113-3129) is prepared by the caller.  No tree
+ * handle involved.
+ */
+int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t *u,
+                           const int32_t *v, const double *w,
+                           double *out_adjacency, double *out_laplacian);
+
 /* Select the kernel family for subsequent calls (tests / benchmarking).
  * ST_ERR_ARG if the tree was built without that family's tables. */
 int st_tree_set_strategy(st_tree *tree, int strategy);

@@ -201,8 +201,10 @@ def main():
         SLT.linked_distances()
         t = timed(lambda: SLT.linked_distances(), reps=10)
         t_lap = timed(lambda: SLT.laplacian(), reps=3)
+        t_lap_np = timed(lambda: SLT.laplacian(on_gpu=False), reps=3)
         emit(fh, config=5, workload="fish-worm: 191 links -> 18145 link pairs on both trees", seconds_linked_distances=t,
-             pairs_per_s=2 * 18145 / t, seconds_laplacian_422x422_host=t_lap)
+             pairs_per_s=2 * 18145 / t, seconds_laplacian_422x422_gpu_assembly=t_lap,
+             seconds_laplacian_422x422_numpy_assembly=t_lap_np)
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host",
-    "st_quartets_host", "st_newick_open", "st_newick_fill", "st_newick_close",
+    "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
@@ -124,6 +124,7 @@ def load():
         L.st_triangle_device.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, vp]
         L.st_triangle_host.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_quartets_host.argtypes = [vp, vp, i64, i64, i64, vp, ctypes.POINTER(i64)]
+        L.st_graph_matrices_host.argtypes = [i32, i64, i64, vp, vp, vp, vp, vp]
         L.st_newick_open.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
                                      ctypes.POINTER(i64), ctypes.POINTER(i64),
                                      ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
@@ -161,6 +162,18 @@ def check(rc, tree_size=None, bad_id=None):
     if rc == ST_ERR_NOMEM:
         raise MemoryError(msg)
     raise HipBackendError(msg)
+
+
+def graph_matrices(n, u, v, w, device=0, want_adjacency=True, want_laplacian=True):
+    """Dense adjacency / Laplacian (n x n float64) of an undirected weighted edge list, on the GPU."""
+    L = load()
+    u = np.ascontiguousarray(u, dtype=np.int32)
+    v = np.ascontiguousarray(v, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    adj = np.empty((n, n), dtype=np.float64) if want_adjacency else None
+    lap = np.empty((n, n), dtype=np.float64) if want_laplacian else None
+    check(L.st_graph_matrices_host(int(device), int(n), int(len(u)), _ptr(u), _ptr(v), _ptr(w), _ptr(adj), _ptr(lap)))
+    return adj, lap
 
 
 def newick_native(text):

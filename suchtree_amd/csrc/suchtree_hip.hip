@@ -700,6 +700,42 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Sr
     }
 }
 
+// ---- dense graph matrices of SuchLinkedTrees (adjacency / Laplacian, MuchTree.pyx:3081-3145)
+// A[u][v] = A[v][u] = w for every edge; L = diag(column sums of A) - A.  The column sums run
+// over the rows in increasing order, like numpy's sum(axis=0), so L is bit-identical to the
+// host formula.
+__global__ void k_graph_scatter(double *__restrict__ A, long long n, long long n_edges,
+                                const int *__restrict__ u, const int *__restrict__ v,
+                                const double *__restrict__ w)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
+         e += (long long)gridDim.x * blockDim.x) {
+        A[(long long)u[e] * n + v[e]] = w[e];
+        A[(long long)v[e] * n + u[e]] = w[e];
+    }
+}
+
+__global__ void k_graph_degree(const double *__restrict__ A, long long n, double *__restrict__ deg)
+{
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += (long long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (long long i = 0; i < n; i++) s += A[i * n + j];   // lanes read consecutive columns: coalesced
+        deg[j] = s;
+    }
+}
+
+__global__ void k_graph_laplacian(const double *__restrict__ A, const double *__restrict__ deg, long long n,
+                                  double *__restrict__ L)
+{
+    const long long total = n * n;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total;
+         k += (long long)gridDim.x * blockDim.x) {
+        const long long i = k / n, j = k - i * n;
+        L[k] = (i == j ? deg[j] : 0.0) - A[k];
+    }
+}
+
 }  // namespace st
 
 // --------------------------------------------------------------------------
@@ -1414,6 +1450,47 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         t->pipe.pool.copy(out_topologies + off * 4, out.h_in, m * 32);
     }
     return read_fault(t, in.stream, bad_id);
+}
+
+int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t *u, const int32_t *v,
+                           const double *w, double *out_adjacency, double *out_laplacian)
+{
+    if (n <= 0 || n_edges < 0) return fail(ST_ERR_ARG, "bad sizes");
+    if (n_edges > 0 && (!u || !v || !w)) return fail(ST_ERR_ARG, "edge arrays are NULL");
+    if (!out_adjacency && !out_laplacian) return fail(ST_ERR_ARG, "both outputs are NULL");
+    if (n > 100000) return fail(ST_ERR_ARG, "dense n x n matrix too large");
+    for (int64_t e = 0; e < n_edges; e++)
+        if (u[e] < 0 || u[e] >= n || v[e] < 0 || v[e] >= n) return fail(ST_ERR_ARG, "edge endpoint out of range");
+    ST_DEVICE(device);
+    const size_t mat = (size_t)n * (size_t)n * 8;
+    double *d_A = nullptr, *d_L = nullptr, *d_deg = nullptr, *d_w = nullptr;
+    int *d_u = nullptr, *d_v = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_A), mat);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_L), mat);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_deg), (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_u), (size_t)std::max<int64_t>(n_edges, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_v), (size_t)std::max<int64_t>(n_edges, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_w), (size_t)std::max<int64_t>(n_edges, 1) * 8);
+    if (e == hipSuccess) e = hipMemset(d_A, 0, mat);
+    if (e == hipSuccess && n_edges) e = hipMemcpy(d_u, u, (size_t)n_edges * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_edges) e = hipMemcpy(d_v, v, (size_t)n_edges * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_edges) e = hipMemcpy(d_w, w, (size_t)n_edges * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (n_edges)
+            hipLaunchKernelGGL(k_graph_scatter, dim3((unsigned)std::min<int64_t>((n_edges + 255) / 256, 4096)),
+                               dim3(256), 0, nullptr, d_A, (long long)n, (long long)n_edges, d_u, d_v, d_w);
+        hipLaunchKernelGGL(k_graph_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0,
+                           nullptr, d_A, (long long)n, d_deg);
+        hipLaunchKernelGGL(k_graph_laplacian, dim3((unsigned)std::min<int64_t>((n * n + 255) / 256, 65536)),
+                           dim3(256), 0, nullptr, d_A, d_deg, (long long)n, d_L);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && out_adjacency) e = hipMemcpy(out_adjacency, d_A, mat, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_laplacian) e = hipMemcpy(out_laplacian, d_L, mat, hipMemcpyDeviceToHost);
+    (void)hipFree(d_A); (void)hipFree(d_L); (void)hipFree(d_deg);
+    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_w);
+    if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("graph matrices: ") + hipGetErrorString(e));
+    return ST_OK;
 }
 
 int st_device_malloc(int device, int64_t bytes, void **out)

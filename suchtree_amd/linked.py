@@ -221,8 +221,10 @@ class SuchLinkedTrees:
             adj[index[p], i] = d
         return adj, node_ids
 
-    def adjacency(self, deletions=0, additions=0, swaps=0) -> np.ndarray:
-        """Graph adjacency matrix of both (subsetted) trees plus the link edges (pyx:3081-3131)."""
+    def _graph_edges(self, deletions=0, additions=0, swaps=0):
+        """Edge list (u, v, weight) and size of the two-tree graph of pyx:3081-3131: tree edges
+        normalised by each tree's longest edge, link edges at the mean of the two trees' mean
+        (non-epsilon) normalised edge lengths; optional random link perturbations as the reference."""
         ta_aj, ta_ids = self._tree_adjacency(self._tree_a, self._subset_a_root)
         tb_aj, tb_ids = self._tree_adjacency(self._tree_b, self._subset_b_root)
         ta_node_ids, tb_node_ids = ta_ids.tolist(), tb_ids.tolist()
@@ -236,26 +238,50 @@ class SuchLinkedTrees:
             a = np.random.choice(list(self._tree_a.leaves.values()))
             b = np.random.choice(list(self._tree_b.leaves.values()))
             ll = np.concatenate((ll, np.array([[b, a]])), axis=0)
-        ta_links = [ta_node_ids.index(x) for x in ll[:, 1]]
-        tb_links = [tb_node_ids.index(x) + ta_aj.shape[0] for x in ll[:, 0]]
-        aj = np.zeros((ta_aj.shape[0] + tb_aj.shape[0], ta_aj.shape[1] + tb_aj.shape[1]))
-        aj[0:ta_aj.shape[0], 0:ta_aj.shape[1]] = ta_aj / ta_aj.max()
-        aj[ta_aj.shape[0]:, ta_aj.shape[1]:] = tb_aj / tb_aj.max()
+        na, nb = ta_aj.shape[0], tb_aj.shape[0]
+        a_index = {x: i for i, x in enumerate(ta_node_ids)}
+        b_index = {x: i for i, x in enumerate(tb_node_ids)}
+        ta_links = [a_index[int(x)] for x in ll[:, 1]]
+        tb_links = [b_index[int(x)] + na for x in ll[:, 0]]
         ta_mean = np.mean(ta_aj.flatten()[ta_aj.flatten() > self._tree_a.polytomy_epsilon])
         tb_mean = np.mean(tb_aj.flatten()[tb_aj.flatten() > self._tree_b.polytomy_epsilon])
         link_mean = (ta_mean / ta_aj.max() + tb_mean / tb_aj.max()) / 2.0
-        for i, j in zip(tb_links, ta_links):
-            aj[i, j] = link_mean
-            aj[j, i] = link_mean
-        return aj
+        ua, va = np.nonzero(np.triu(ta_aj))
+        ub, vb = np.nonzero(np.triu(tb_aj))
+        u = np.concatenate([ua, ub + na, np.array(tb_links, dtype=np.int64)])
+        v = np.concatenate([va, vb + na, np.array(ta_links, dtype=np.int64)])
+        w = np.concatenate([ta_aj[ua, va] / ta_aj.max(), tb_aj[ub, vb] / tb_aj.max(),
+                            np.full(len(ta_links), link_mean)])
+        return na + nb, u, v, w
 
-    def laplacian(self, deletions=0, additions=0, swaps=0) -> np.ndarray:
+    def _matrices(self, deletions, additions, swaps, on_gpu, want_adjacency, want_laplacian):
+        n, u, v, w = self._graph_edges(deletions, additions, swaps)
+        if on_gpu:
+            from . import _capi
+            return _capi.graph_matrices(n, u, v, w, device=self._tree_a._device,
+                                        want_adjacency=want_adjacency, want_laplacian=want_laplacian)
+        aj = np.zeros((n, n))
+        aj[u, v] = w
+        aj[v, u] = w
+        lp = None
+        if want_laplacian:
+            lp = np.zeros(aj.shape)
+            np.fill_diagonal(lp, aj.sum(axis=0))
+            lp = lp - aj
+        return (aj if want_adjacency else None), lp
+
+    def adjacency(self, deletions=0, additions=0, swaps=0, on_gpu=True) -> np.ndarray:
+        """Graph adjacency matrix of both (subsetted) trees plus the link edges (pyx:3081-3131).
+        The dense matrix is assembled on the GPU (``st_graph_matrices_host``); ``on_gpu=False``
+        assembles it with numpy exactly as the reference does."""
+        return self._matrices(deletions, additions, swaps, on_gpu, True, False)[0]
+
+    def laplacian(self, deletions=0, additions=0, swaps=0, on_gpu=True) -> np.ndarray:
         """Graph Laplacian L = D - A of the current subset (pyx:3133-3145)."""
-        aj = self.adjacency(deletions=deletions, additions=additions, swaps=swaps)
-        lp = np.zeros(aj.shape)
-        np.fill_diagonal(lp, aj.sum(axis=0))
-        return lp - aj
+        return self._matrices(deletions, additions, swaps, on_gpu, False, True)[1]
 
-    def spectrum(self, deletions=0, additions=0, swaps=0) -> np.ndarray:
-        """Eigenvalues of the Laplacian (the reference calls LAPACK dsyev, pyx:3147-3173)."""
-        return np.linalg.eigvalsh(self.laplacian(deletions=deletions, additions=additions, swaps=swaps))
+    def spectrum(self, deletions=0, additions=0, swaps=0, on_gpu=True) -> np.ndarray:
+        """Eigenvalues of the Laplacian (the reference calls LAPACK dsyev, pyx:3147-3173; the
+        eigen-solve stays on the host)."""
+        return np.linalg.eigvalsh(self.laplacian(deletions=deletions, additions=additions, swaps=swaps,
+                                                 on_gpu=on_gpu))

@@ -123,6 +123,13 @@ def test_config5_linked_distances(which):
     OB = OracleTree(SLT.TreeB._flat.parent, SLT.TreeB._flat.distance)
     assert_bits_equal(res["TreeA"], OA.distances(ids_a))
     assert_bits_equal(res["TreeB"], OB.distances(ids_b))
+    # adjacency / Laplacian: dense assembly on the GPU equals the numpy assembly bit for bit
+    aj_gpu, aj_np = SLT.adjacency(), SLT.adjacency(on_gpu=False)
+    lp_gpu, lp_np = SLT.laplacian(), SLT.laplacian(on_gpu=False)
+    n_graph = SLT.TreeA.size + SLT.TreeB.size
+    assert aj_gpu.shape == lp_gpu.shape == (n_graph, n_graph)
+    assert np.array_equal(aj_gpu, aj_np) and np.array_equal(lp_gpu.view(np.int64), lp_np.view(np.int64))
+    assert np.allclose(lp_gpu.sum(axis=0), 0)
     if which == "gopher_louse":
         r = pearsonr(res["TreeA"], res["TreeB"])[0]
         assert abs(r - KNOWN["gopher_louse_linked_distances"]["pearson_r"]) < 1e-6

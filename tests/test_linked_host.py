@@ -58,15 +58,15 @@ def test_fish_worm_sizes_and_laplacian_shape():
     SLT, _ = _fish_worm()
     k = KNOWN["fish_worm_sizes"]
     assert (SLT.n_links, SLT.TreeA.num_leaves, SLT.TreeB.num_leaves) == (k["links"], k["hosts"], k["guests"])
-    aj = SLT.adjacency()
+    aj = SLT.adjacency(on_gpu=False)
     assert aj.shape == (41 + 381, 41 + 381)
     assert np.allclose(aj, aj.T) and aj.max() == pytest.approx(1.0)
-    lp = SLT.laplacian()
+    lp = SLT.laplacian(on_gpu=False)
     assert np.allclose(lp.sum(axis=0), 0) and np.allclose(np.diag(lp), aj.sum(axis=0))
     # tree blocks carry 40 + 380 edges, the off-diagonal block the 191 links
     assert (aj[:41, :41] > 0).sum() == 2 * 40 and (aj[41:, 41:] > 0).sum() == 2 * 380
     assert (aj[41:, :41] > 0).sum() == 191
-    ev = SLT.spectrum()
+    ev = SLT.spectrum(on_gpu=False)
     assert ev.shape == (422,) and abs(ev[0]) < 1e-9
 
 
