@@ -226,6 +226,23 @@ def main():
                                      "source": "rocprofv3 TCC_EA0_RDREQ_sum (profiles/) and scripts/micro/gather_bench.hip"}
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
+        if world == 1:
+            # end-to-end leg (SURVEY 8d asks for it next to the kernel-only figure; it is never
+            # `value`): the same batch prefix from pageable host numpy arrays, through the
+            # library's staged host path, into reused host result arrays
+            k2 = min(n, 50_000_000)
+            host_pairs = pairs[:k2].cpu().numpy()
+            h_d, h_m = np.empty(k2), np.empty(k2, dtype=np.int32)
+            tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+            t_h = time.perf_counter()
+            tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+            t_h = time.perf_counter() - t_h
+            line["end_to_end_host_path"] = {
+                "pairs_per_s": k2 / t_h, "pairs": k2,
+                "what": "pageable numpy int64 pairs in -> float64 distances + int32 MRCA ids out, PCIe inclusive "
+                        "(ids cross as int32, distances as float32, widened on the host)",
+                "matches_device_results": bool(np.array_equal(h_d.view(np.int64), out_d[:k2].cpu().numpy().view(np.int64))
+                                               and np.array_equal(h_m, out_m[:k2].cpu().numpy()))}
         if world == 1 and not args.no_cpu_baseline:
             k = min(n, 50_000_000)
             cpu, parity = cpu_baseline(parent, dist, pairs[:k].cpu().numpy(), out_d[:k].cpu().numpy(),
