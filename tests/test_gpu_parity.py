@@ -389,3 +389,27 @@ def test_general_trees_through_the_c_abi():
             assert_bits_equal(d, want_d, name)
             assert np.array_equal(m, want_m), name
         dev.close()
+
+
+def test_argument_errors_on_a_live_handle(gopher_flat):
+    dev = _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance)
+    for name, value in (("pairs_per_lane", 3), ("lockstep", 2), ("flow", 5), ("flow_batch", 0), ("nope", 1)):
+        with pytest.raises(ValueError):
+            dev.set_option(name, value)
+    with pytest.raises(ValueError):
+        dev.triangle_host(np.arange(0, 10, 2), k_begin=0, k_count=11)        # 5 ids -> 10 pairs
+    with pytest.raises(ValueError):
+        dev.triangle_host(np.zeros((2, 2), dtype=np.int64))
+    with pytest.raises(ValueError):
+        dev.distances_host(np.array([[0, 2]]), True, False, out_dist=np.empty(3))
+    with pytest.raises(ValueError):
+        dev.distances_device(0, 5, 0, 0)                                      # NULL pairs, both outputs NULL
+    info = dev.info()
+    assert info["n_nodes"] == 29 and info["device_bytes"] > 0
+    dev.close()
+    with pytest.raises(_capi.HipBackendError):
+        dev.info()                                                            # closed handle
+    with pytest.raises(ValueError):
+        _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance[:-1])
+    with pytest.raises(_capi.HipBackendError):
+        _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance, device=99)
