@@ -106,6 +106,12 @@ int st_distances_device(st_tree *tree, const int64_t *d_pairs, int64_t n,
                         int64_t stride0, int64_t stride1,
                         double *d_out_dist, int32_t *d_out_mrca, void *stream);
 
+/* Same, writing the distances as the float32 values they are (half the output bytes; the
+ * float64 form above holds exactly these values widened). */
+int st_distances_device_f32(st_tree *tree, const int64_t *d_pairs, int64_t n,
+                            int64_t stride0, int64_t stride1,
+                            float *d_out_dist, int32_t *d_out_mrca, void *stream);
+
 /*
  * Synchronise `stream`, then report and clear the fault word written by
  * earlier st_distances_device calls: ST_OK, or ST_ERR_BOUNDS with *bad_id set

@@ -21,7 +21,7 @@ STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
-    "st_distances_host", "st_distances_device", "st_fault_check", "st_tree_set_strategy",
+    "st_distances_host", "st_distances_device", "st_distances_device_f32", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
@@ -118,6 +118,7 @@ def load():
         L.st_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
         L.st_distances_host.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_distances_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+        L.st_distances_device_f32.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
         L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.st_tree_set_strategy.argtypes = [vp, i32]
         L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
@@ -346,9 +347,12 @@ class DeviceTree:
                                           ctypes.c_void_p(d_out_mrca or None), ctypes.c_void_p(stream or None))
         check(rc)
 
-    def distances_device(self, d_pairs, n, d_out_dist=0, d_out_mrca=0, stream=0, stride0=2, stride1=1):
-        """Raw device pointers (ints); enqueues on ``stream`` without synchronising."""
-        rc = self._lib.st_distances_device(self.handle, ctypes.c_void_p(d_pairs), int(n), int(stride0),
+    def distances_device(self, d_pairs, n, d_out_dist=0, d_out_mrca=0, stream=0, stride0=2, stride1=1,
+                         f32=False):
+        """Raw device pointers (ints); enqueues on ``stream`` without synchronising.
+        ``f32``: d_out_dist is a float32 buffer (the values are float32 sums)."""
+        fn = self._lib.st_distances_device_f32 if f32 else self._lib.st_distances_device
+        rc = fn(self.handle, ctypes.c_void_p(d_pairs), int(n), int(stride0),
                                            int(stride1), ctypes.c_void_p(d_out_dist or None),
                                            ctypes.c_void_p(d_out_mrca or None),
                                            ctypes.c_void_p(stream or None))

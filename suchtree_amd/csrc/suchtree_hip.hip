@@ -1277,6 +1277,18 @@ int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s
                    reinterpret_cast<hipStream_t>(stream));
 }
 
+int st_distances_device_f32(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0,
+                            int64_t stride1, float *d_out_dist, int32_t *d_out_mrca, void *stream)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n < 0) return fail(ST_ERR_ARG, "n < 0");
+    if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
+    if (!d_out_dist && !d_out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
+    ST_DEVICE(t->device);
+    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{nullptr, d_out_dist}, d_out_mrca,
+                   reinterpret_cast<hipStream_t>(stream));
+}
+
 int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)
 {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");

@@ -23,26 +23,33 @@ def _check_pairs(pairs):
 
 
 def distances_device(tree: SuchTree, pairs, want_dist: bool = True, want_mrca: bool = True,
-                     out_dist=None, out_mrca=None, check: bool = True) -> Tuple[Optional[object], Optional[object]]:
+                     out_dist=None, out_mrca=None, check: bool = True,
+                     dist_dtype=None) -> Tuple[Optional[object], Optional[object]]:
     """(dist float64[n], mrca int32[n]) torch tensors on the tree's GPU for an int64 (n,2)
     tensor of node-id pairs (any strides).  Asynchronous on torch's current stream unless
     ``check`` (default) asks for the bounds report, which synchronises that stream and raises
-    ``InvalidNodeError`` exactly like ``distances_bulk``."""
+    ``InvalidNodeError`` exactly like ``distances_bulk``.  ``dist_dtype=torch.float32`` returns the
+    distances as the float32 values they are (the float64 form holds the same values widened)."""
     import torch
     _check_pairs(pairs)
+    if dist_dtype is None:
+        dist_dtype = out_dist.dtype if out_dist is not None else torch.float64
+    if dist_dtype not in (torch.float64, torch.float32):
+        raise ValueError("dist_dtype must be torch.float64 or torch.float32")
     dev = tree._device_tree()
     if pairs.device.index != dev.device:
         raise ValueError("pairs live on cuda:%d but the tree is on device %d" % (pairs.device.index, dev.device))
     n = int(pairs.shape[0])
     if want_dist and out_dist is None:
-        out_dist = torch.empty(n, dtype=torch.float64, device=pairs.device)
+        out_dist = torch.empty(n, dtype=dist_dtype, device=pairs.device)
     if want_mrca and out_mrca is None:
         out_mrca = torch.empty(n, dtype=torch.int32, device=pairs.device)
     stream = torch.cuda.current_stream(pairs.device).cuda_stream
     if n:
         dev.distances_device(pairs.data_ptr(), n, out_dist.data_ptr() if want_dist else 0,
                              out_mrca.data_ptr() if want_mrca else 0, stream=stream,
-                             stride0=pairs.stride(0), stride1=pairs.stride(1))
+                             stride0=pairs.stride(0), stride1=pairs.stride(1),
+                             f32=want_dist and out_dist.dtype == torch.float32)
         if check:
             dev.fault_check(stream)
     return (out_dist if want_dist else None), (out_mrca if want_mrca else None)

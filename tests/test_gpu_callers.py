@@ -239,6 +239,8 @@ def test_torch_interop_device_resident(ml_arrays):
     cols = torch.from_numpy(np.ascontiguousarray(host.T)).cuda().t()      # column-major storage
     d3, m3 = torch_interop.distances_device(T, cols)
     assert_bits_equal(d3.cpu().numpy(), O.distances(host))
+    d32, _ = torch_interop.distances_device(T, pairs, want_mrca=False, dist_dtype=torch.float32)
+    assert d32.dtype == torch.float32 and torch.equal(d32.double(), d)
     # a C-order view whose base is only 8-byte aligned (no 16-byte vector loads possible)
     flat = torch.empty(2 * len(host) + 1, dtype=torch.int64, device="cuda")
     flat[1:] = pairs.reshape(-1)
