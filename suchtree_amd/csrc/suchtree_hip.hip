@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Sr
         const unsigned long long act_mask = __ballot(ph == CLIMB1 || ph == CLIMB2);
         const unsigned long long wait_mask = __ballot(ph == DONE || (ph == NEED && my_idx < w_end));
         if (act_mask == 0 && wait_mask == 0) break;
-        if (__popcll(wait_mask) >= batch || act_mask == 0) {
+        if ((int)__popcll(wait_mask) >= batch || act_mask == 0) {
             if (ph == DONE) {
                 store_result(out_d, out_m, cur_idx, s, P.canopy_id[u]);
                 ph = NEED;
