@@ -8,6 +8,7 @@ arithmetic happens in libsuchtree_hip.so on the GPU; nothing here computes a
 distance or an MRCA on the CPU, and a missing library or GPU raises
 ``HipBackendError``.
 """
+from itertools import chain
 from numbers import Integral
 from typing import Dict, List, Tuple, Union
 from urllib.parse import urlparse
@@ -299,15 +300,18 @@ class SuchTree:
             raise TypeError("pairs must be a list of tuples")
         leaves = self.leaves
         try:
-            # fast path: two dict lookups per pair, no per-element checks (keys are str only,
-            # so anything that is not a known leaf name raises here and is diagnosed below)
-            node_pairs = [(leaves[name_a], leaves[name_b]) for name_a, name_b in pairs]
+            # fast path: the dict lookups run at C speed over the flattened names, no per-element
+            # checks (keys are str only, so anything that is not a known leaf name raises here
+            # and is diagnosed by the loop below, which owns the error messages)
+            if set(map(len, pairs)) - {2}:
+                raise ValueError("a pair does not have two elements")
+            ids = np.fromiter(map(leaves.__getitem__, chain.from_iterable(pairs)),
+                              dtype=np.int64, count=2 * len(pairs))
         except (KeyError, TypeError, ValueError):
-            node_pairs = None
-        if node_pairs is not None:
-            if not node_pairs:
-                node_pairs = np.zeros((0,), dtype=np.int64)   # np.array([]) of the reference: 1-D, fails the shape check
-            return self.distances_bulk(np.array(node_pairs, dtype=np.int64)).tolist()
+            ids = None
+        if ids is not None:
+            # (an empty list becomes the 1-D empty array of the reference and fails the shape check)
+            return self.distances_bulk(ids.reshape(-1, 2) if len(pairs) else ids).tolist()
         node_pairs = []
         for i, (name_a, name_b) in enumerate(pairs):
             if not isinstance(name_a, str) or not isinstance(name_b, str):
