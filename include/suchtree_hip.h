@@ -96,6 +96,12 @@ int st_distances_host(st_tree *tree, const int64_t *pairs, int64_t n,
                       int64_t stride0, int64_t stride1,
                       double *out_dist, int32_t *out_mrca, int64_t *bad_id);
 
+/* Same for int32 ids (element strides of the int32 view): half the host-side read traffic,
+ * and a C-order array is already what is sent over PCIe. */
+int st_distances_host_i32(st_tree *tree, const int32_t *pairs, int64_t n,
+                          int64_t stride0, int64_t stride1,
+                          double *out_dist, int32_t *out_mrca, int64_t *bad_id);
+
 /*
  * Same computation on device-resident buffers, enqueued on `stream`
  * (a hipStream_t; NULL = default stream).  Does not synchronise.  Out-of-range

@@ -21,7 +21,7 @@ STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
-    "st_distances_host", "st_distances_device", "st_distances_device_f32", "st_fault_check", "st_tree_set_strategy",
+    "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
@@ -117,6 +117,7 @@ def load():
         L.st_tree_destroy.restype = None
         L.st_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
         L.st_distances_host.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
+        L.st_distances_host_i32.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_distances_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
         L.st_distances_device_f32.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
         L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
@@ -293,14 +294,18 @@ class DeviceTree:
         out_m = self._out(out_mrca, n, np.int32, want_mrca)
         if n == 0:
             return out_d, out_m
-        if pairs.strides[0] % 8 or pairs.strides[1] % 8:
+        item = pairs.dtype.itemsize
+        if pairs.dtype not in (np.int64, np.int32):
+            raise ValueError("pairs must be int64 or int32")
+        if pairs.strides[0] % item or pairs.strides[1] % item:
             pairs = np.ascontiguousarray(pairs)
-        s0, s1 = pairs.strides[0] // 8, pairs.strides[1] // 8
+        s0, s1 = pairs.strides[0] // item, pairs.strides[1] // item
         if s0 < 0 or s1 < 0:   # negative strides: the base pointer is not the lowest address
             pairs = np.ascontiguousarray(pairs)
             s0, s1 = 2, 1
         bad = ctypes.c_int64(0)
-        rc = self._lib.st_distances_host(self.handle, _ptr(pairs), n, s0, s1, _ptr(out_d), _ptr(out_m),
+        fn = self._lib.st_distances_host if item == 8 else self._lib.st_distances_host_i32
+        rc = fn(self.handle, _ptr(pairs), n, s0, s1, _ptr(out_d), _ptr(out_m),
                                          ctypes.byref(bad))
         check(rc, tree_size=self.size, bad_id=int(bad.value))
         return out_d, out_m

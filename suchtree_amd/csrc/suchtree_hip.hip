@@ -956,7 +956,8 @@ constexpr int64_t kMailboxPairs = 2048;   // largest batch served through the ma
 // writes the results to pinned host memory mapped into the device, so a call is one launch
 // and one stream synchronisation.  Ids are range-checked here on the host (the batch is
 // tiny), with the reference's choice of the id to report (MuchTree.pyx:897-903).
-static int small_batch(st_tree *t, const int64_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
+template <typename Id>
+static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, int64_t stride1,
                        double *out_dist, int32_t *out_mrca, int64_t *bad_id)
 {
     if (!t->mb_host) {
@@ -1296,8 +1297,12 @@ int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)
     return read_fault(t, reinterpret_cast<hipStream_t>(stream), bad_id);
 }
 
-int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
-                      double *out_dist, int32_t *out_mrca, int64_t *bad_id)
+}  // extern "C"
+
+// Host-buffer entry point for int64 ids (the reference's dtype) and int32 ids.
+template <typename Id>
+static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, int64_t stride1,
+                               double *out_dist, int32_t *out_mrca, int64_t *bad_id)
 {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     if (n < 0) return fail(ST_ERR_ARG, "n < 0");
@@ -1317,8 +1322,12 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
     long long wide_max = std::numeric_limits<long long>::min();
     long long wide_min = std::numeric_limits<long long>::max();
     auto pack = [&](PipeSlot &s, int64_t off, int64_t m) {
-        const int64_t *src = pairs + off * stride0;
+        const Id *src = pairs + off * stride0;
         int32_t *dst = static_cast<int32_t *>(s.h_in);
+        if (sizeof(Id) == 4 && stride0 == 2 && stride1 == 1) {   // int32 C-order: already the wire format
+            pool.copy(dst, src, m * 8);
+            return;
+        }
         pool.parallel_for(m, [&, src, dst](int64_t b, int64_t e) {
             long long hi = std::numeric_limits<long long>::min(), lo = std::numeric_limits<long long>::max();
             for (int64_t k = b; k < e; k++) {
@@ -1345,6 +1354,20 @@ int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t strid
     const int rc = run_pipe(t, n, 8, pack, launch, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     return read_fault(t, t->pipe.slot[0].stream, bad_id, wide_max, wide_min);
+}
+
+extern "C" {
+
+int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
+                      double *out_dist, int32_t *out_mrca, int64_t *bad_id)
+{
+    return distances_host_impl(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
+}
+
+int st_distances_host_i32(st_tree *t, const int32_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
+                          double *out_dist, int32_t *out_mrca, int64_t *bad_id)
+{
+    return distances_host_impl(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
 }
 
 static int triangle_args(st_tree *t, const int64_t *ids, int64_t m, int64_t k_begin, int64_t k_count,

@@ -255,7 +255,10 @@ class SuchTree:
         if pairs.dtype != np.int64:
             if not np.issubdtype(pairs.dtype, np.integer):
                 raise ValueError("Buffer dtype mismatch, expected 'long' but got '%s'" % pairs.dtype.name)
-            pairs = pairs.astype(np.int64)   # more permissive than the reference: other int widths are widened
+            # more permissive than the reference (which only takes int64): int32 goes to the
+            # library as it is, other integer widths are widened
+            if pairs.dtype != np.int32:
+                pairs = pairs.astype(np.int64)
         if pairs.shape[0] == 0:
             pairs.max()   # the reference fails here: ValueError (zero-size array to reduction ...)
         return pairs

@@ -83,7 +83,8 @@ def test_pair_array_conventions(T):
         T.distances_bulk(np.zeros((3, 2), dtype=np.float64))
     c = T._coerce_pairs([(0, 2), (4, 6)])
     assert c.dtype == np.int64 and c.shape == (2, 2)
-    assert T._coerce_pairs(np.array([[0, 2]], dtype=np.int32)).dtype == np.int64
+    assert T._coerce_pairs(np.array([[0, 2]], dtype=np.int32)).dtype == np.int32    # taken as it is
+    assert T._coerce_pairs(np.array([[0, 2]], dtype=np.int16)).dtype == np.int64    # widened
 
 
 def test_by_name_errors_come_before_any_device_work(T):

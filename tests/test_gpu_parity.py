@@ -216,7 +216,19 @@ def test_strides_and_dtypes_through_the_facade(ml_arrays):
     wide[:, 1::3] = pairs
     assert_bits_equal(T.distances_bulk(wide[:, 1::3]), want)
     assert_bits_equal(T.distances_bulk(pairs[::-1])[::-1], want)
-    assert_bits_equal(T.distances_bulk(pairs.astype(np.int32)), want)
+    p32 = pairs.astype(np.int32)
+    assert_bits_equal(T.distances_bulk(p32), want)                                   # int32 entry point
+    assert_bits_equal(T.distances_bulk(np.asfortranarray(p32)), want)
+    assert_bits_equal(T.distances_bulk(p32[:1500]), want[:1500])                     # mailbox path, int32
+    assert_bits_equal(T.distances_bulk(pairs.astype(np.uint16 if len(parent) < 65536 else np.uint32)), want)
+    big32 = np.random.default_rng(8).choice(leaf_ids, size=(5_000_000, 2)).astype(np.int32)
+    pick32 = np.random.default_rng(9).integers(0, len(big32), 100_000)
+    assert_bits_equal(T.distances_bulk(big32)[pick32], O.distances(big32[pick32].astype(np.int64)))
+    bad32 = p32.copy()
+    bad32[5, 0] = -4
+    with pytest.raises(InvalidNodeError) as e32:
+        T.distances_bulk(bad32)
+    assert e32.value.node_id == -4
     assert_bits_equal(T.distances_bulk(pairs[:100].tolist()), want[:100])
     # more than one pipeline chunk (2^22 pairs) of a strided view
     big = np.asfortranarray(np.random.default_rng(8).choice(leaf_ids, size=(6_000_000, 2)))
