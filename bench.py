@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive end-to-end leg")
     return ap.parse_args()
 
 
@@ -226,7 +227,7 @@ def main():
                                      "source": "rocprofv3 TCC_EA0_RDREQ_sum (profiles/) and scripts/micro/gather_bench.hip"}
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
-        if world == 1:
+        if world == 1 and not args.no_host_path:
             # end-to-end leg (SURVEY 8d asks for it next to the kernel-only figure; it is never
             # `value`): the same batch prefix from pageable host numpy arrays, through the
             # library's staged host path, into reused host result arrays

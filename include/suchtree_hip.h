@@ -169,7 +169,7 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
 /* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the
- * canopy kernel keeps in flight: 1 or 2 (default 2); 0 = scalar form.
+ * canopy kernel keeps in flight: 1 (default) or 2; 0 = scalar, branchy form (default for deep canopies).
  * "lockstep": 1 (default) = the climb inside the canopy uses the depth cut (max(ka,kb)
  * rounds), 0 = "larger index moves up" (ka+kb rounds, one LDS read per round).
  * "flow": 1 = per-lane flow kernel (lanes advance through their own pairs without waiting

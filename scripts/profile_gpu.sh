@@ -5,7 +5,7 @@
 # usage: scripts/profile_gpu.sh <round-tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline"}
+ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

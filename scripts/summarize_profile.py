@@ -27,6 +27,15 @@ def per_kernel_durations(trace_dir):
     return dur
 
 
+def dominant_kernel(dur, substr):
+    """full name of the kernel containing substr with the largest total duration"""
+    best, best_t = None, -1
+    for k, v in dur.items():
+        if substr in k and sum(v) > best_t:
+            best, best_t = k, sum(v)
+    return best
+
+
 def counter_means(pmc_dir, kernel_substr):
     """mean counter value per dispatch of kernels whose name contains kernel_substr"""
     acc = defaultdict(list)
@@ -59,10 +68,13 @@ def main():
     for k, v in dur.items():
         v2 = sorted(v)
         summary["kernels"][k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": v2[0], "max_ns": v2[-1]}
+    full = dominant_kernel(dur, kernel)
+    if full:
+        summary["kernel_full_name"] = full
     counters = {}
     for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
         if os.path.isdir(d):
-            means, counts = counter_means(d, kernel)
+            means, counts = counter_means(d, full or kernel)
             counters.update(means)
     summary["counters_mean_per_launch"] = counters
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:

@@ -759,7 +759,7 @@ struct st_tree {
     // canopy geometry
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
-    int pairs_per_lane = 2;   // tuning: 0 = scalar reference kernel, 1/2/4 = ILP kernel
+    int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int lockstep = 1;         // tuning: canopy climb 1 by depth cut (1) or by "larger index moves" (0)
     int flow = 0;             // tuning: per-lane flow kernel 1 / 0 (measured: no faster than the ILP form, kept selectable)
     int flow_batch = 16;      // lanes that must be waiting before the flow kernel refills

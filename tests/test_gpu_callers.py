@@ -38,7 +38,7 @@ def test_triangle_generator_equals_explicit_pairs(strategy, ml_arrays):
         assert_bits_equal(d, want_d, "flow%d ppl%d" % (flow, ppl))
         assert np.array_equal(m, want_m)
     dev.set_option("flow", 0)
-    dev.set_option("pairs_per_lane", 2)
+    dev.set_option("pairs_per_lane", 1)
     # any k-range gives the matching slice (what multi-GPU sharding and tiling rely on)
     total = len(pairs)
     for g in range(3):

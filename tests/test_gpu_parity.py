@@ -40,7 +40,7 @@ def _both(dev, pairs):
             dev.set_option("lockstep", lockstep)
             out["canopy/ppl%d%s" % (ppl, "" if lockstep else "/index-climb")] = \
                 dev.distances_host(pairs, want_dist=True, want_mrca=True)
-        dev.set_option("pairs_per_lane", 2)
+        dev.set_option("pairs_per_lane", 1)
         dev.set_option("lockstep", 1)
         dev.set_option("flow", 0)
     dev.set_strategy("auto")
