@@ -6,8 +6,8 @@ distance path: the link table and link list (:2560-2874), subsetting
 (:2876-2898), ``linked_distances`` (:2900-2934) and the adjacency / Laplacian
 assembly (:3081-3145).  The O(L^2) pair enumeration of ``linked_distances``
 never exists in memory here: the kernels derive each pair from its index
-(``st_triangle_host``).  The stochastic sampler (``sample_linked_distances``,
-stateful xorshift RNG) and the igraph export are out of scope.
+(``st_triangle_host``).  ``sample_linked_distances`` keeps the reference's algorithm and
+stop rule with numpy's generator in place of its xorshift64*; the igraph export is out of scope.
 """
 from typing import Dict
 
@@ -196,6 +196,66 @@ class SuchLinkedTrees:
         ids_b = np.stack([ll[cols, 0], ll[rows, 0]], axis=1)
         return {"TreeA": d_a, "TreeB": d_b, "ids_A": ids_a, "ids_B": ids_b,
                 "n_pairs": size, "n_samples": size, "deviation_a": None, "deviation_b": None}
+
+    def sample_linked_distances(self, sigma=0.001, buckets=64, n=4096, maxcycles=100, seed=None):
+        """Monte-Carlo form of :meth:`linked_distances` (pyx:2952-3079): cycles of ``buckets`` x ``n``
+        random link pairs, distances in both trees, until the spread of the per-bucket standard
+        deviations falls below ``sigma`` in both trees (``None`` after ``maxcycles`` cycles).
+
+        Same algorithm and stop rule; what differs from the reference is the generator (numpy's
+        instead of its xorshift64*, so individual samples are not reproducible across the two)
+        and the batching: one cycle is a single launch per tree (``buckets*n`` pairs) instead of
+        ``buckets`` calls of ``n`` pairs.
+        """
+        rng = np.random.default_rng(seed)
+        ll = np.ascontiguousarray(self.linklist, dtype=np.int64)
+        L = ll.shape[0]
+        if L < 1:
+            raise ValueError("no links in the current subset")
+        sums_a, sums_b = np.zeros(buckets), np.zeros(buckets)
+        sumsq_a, sumsq_b = np.zeros(buckets), np.zeros(buckets)
+        samples = 0
+        all_a, all_b = [], []
+        cycles = 0
+        while True:
+            l1 = rng.integers(0, L, size=buckets * n)
+            l2 = rng.integers(0, L, size=buckets * n)
+            query_a = np.stack([ll[l1, 1], ll[l2, 1]], axis=1)
+            query_b = np.stack([ll[l1, 0], ll[l2, 0]], axis=1)
+            d_a = self._tree_a.distances_bulk(query_a).reshape(buckets, n)
+            d_b = self._tree_b.distances_bulk(query_b).reshape(buckets, n)
+            all_a.append(d_a.ravel())
+            all_b.append(d_b.ravel())
+            # running sums per bucket, accumulated element by element like the reference's loop
+            sums_a += np.cumsum(d_a, axis=1)[:, -1]
+            sums_b += np.cumsum(d_b, axis=1)[:, -1]
+            sumsq_a += np.cumsum(d_a ** 2, axis=1)[:, -1]
+            sumsq_b += np.cumsum(d_b ** 2, axis=1)[:, -1]
+            samples += n
+            with np.errstate(invalid="ignore"):
+                dev_a = (sumsq_a / samples - (sums_a / samples) ** 2) ** 0.5
+                dev_b = (sumsq_b / samples - (sums_b / samples) ** 2) ** 0.5
+            # the reference keeps these four accumulators in C floats
+            acc_a = acc_b = sq_a = sq_b = np.float32(0)
+            for i in range(buckets):
+                acc_a = np.float32(acc_a + np.float32(dev_a[i]))
+                acc_b = np.float32(acc_b + np.float32(dev_b[i]))
+                sq_a = np.float32(sq_a + np.float32(dev_a[i] ** 2))
+                sq_b = np.float32(sq_b + np.float32(dev_b[i] ** 2))
+            with np.errstate(invalid="ignore"):
+                deviation_a = np.float32((float(sq_a) / buckets - (float(acc_a) / buckets) ** 2) ** 0.5) \
+                    if (float(sq_a) / buckets - (float(acc_a) / buckets) ** 2) >= 0 else np.float32("nan")
+                deviation_b = np.float32((float(sq_b) / buckets - (float(acc_b) / buckets) ** 2) ** 0.5) \
+                    if (float(sq_b) / buckets - (float(acc_b) / buckets) ** 2) >= 0 else np.float32("nan")
+            cycles += 1
+            if deviation_a < sigma and deviation_b < sigma:
+                break
+            if cycles >= maxcycles:
+                return None
+        return {"TreeA": np.concatenate(all_a), "TreeB": np.concatenate(all_b),
+                "n_pairs": (self._subset_n_links * (self._subset_n_links - 1)) / 2,
+                "n_samples": n * buckets * cycles,
+                "deviation_a": float(deviation_a), "deviation_b": float(deviation_b)}
 
     # ------------------------------------------- adjacency / Laplacian assembly
     @staticmethod
