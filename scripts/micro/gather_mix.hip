@@ -10,7 +10,7 @@
 
 __device__ __forceinline__ uint32_t hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
-template <int MODE, bool NT>
+template <int MODE, bool NT, bool NTB = false>
 __global__ __launch_bounds__(1024) void k_mix(const uint8_t *__restrict__ ta, uint32_t mask_a, int stride_a,
                                               const uint8_t *__restrict__ tb, uint32_t mask_b, int stride_b,
                                               const longlong2 *__restrict__ pairs, long long n,
@@ -31,10 +31,40 @@ __global__ __launch_bounds__(1024) void k_mix(const uint8_t *__restrict__ ta, ui
             const uint2 v = *reinterpret_cast<const uint2 *>(pa);
             acc = v.x + v.y;
         }
-        const uint4 b0 = *reinterpret_cast<const uint4 *>(pb), b1 = *reinterpret_cast<const uint4 *>(pb + 16);
-        acc += b0.x + b1.w;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        if (NTB) {
+            const u4 b0 = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(pb));
+            const u4 b1 = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(pb + 16));
+            acc += b0.x + b1.w;
+        } else {
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(pb), b1 = *reinterpret_cast<const uint4 *>(pb + 16);
+            acc += b0.x + b1.w;
+        }
         if (NT) { __builtin_nontemporal_store((double)acc, &out_d[i]); __builtin_nontemporal_store((int)acc, &out_m[i]); }
         else { out_d[i] = (double)acc; out_m[i] = (int)acc; }
+    }
+}
+
+// What an XCD-partitioned second pass could reach: every workgroup reads a only from the
+// 1/8 slice and b only from the 1/8 (or 1/16) slice of its own XCD (HW_REG_XCC_ID), so both
+// slices fit that XCD's 4 MiB L2.  Pairs in: 8 B (int32 x2), results out: 8 B (f32 + i32).
+__global__ __launch_bounds__(1024) void k_sliced(const uint8_t *__restrict__ ta, uint32_t slice_mask_a, int shift_a,
+                                                 const uint8_t *__restrict__ tb, uint32_t slice_mask_b, int shift_b,
+                                                 const int2 *__restrict__ pairs, long long n,
+                                                 float *__restrict__ out_d, int *__restrict__ out_m)
+{
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & 7u;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int2 p = pairs[i];
+        const uint32_t ia = (hash((uint32_t)p.x) & slice_mask_a) | (xcc << shift_a);
+        const uint32_t ib = (hash((uint32_t)p.y) & slice_mask_b) | (xcc << shift_b);
+        const uint2 v = *reinterpret_cast<const uint2 *>(ta + (size_t)ia * 8);
+        const uint8_t *pb = tb + (size_t)ib * 32;
+        const uint4 b0 = *reinterpret_cast<const uint4 *>(pb), b1 = *reinterpret_cast<const uint4 *>(pb + 16);
+        const uint32_t acc = v.x + v.y + b0.x + b1.w;
+        out_d[i] = (float)acc;
+        out_m[i] = (int)acc;
     }
 }
 
@@ -69,7 +99,25 @@ int main()
     if (run("today + non-temporal stream loads/stores", k_mix<0, true>, M1, 64, ta, M1, 64)) return 1;
     if (run("split : a from 8 MiB (8 B), b from 32 MiB (32 B)", k_mix<1, false>, M1, 8, tb, M1, 32)) return 1;
     if (run("split + non-temporal stream loads/stores", k_mix<1, true>, M1, 8, tb, M1, 32)) return 1;
+    if (run("split + nt streams + nt b-record loads", k_mix<1, true, true>, M1, 8, tb, M1, 32)) return 1;
+    if (run("split + nt b-record loads only", k_mix<1, false, true>, M1, 8, tb, M1, 32)) return 1;
     if (run("split : a from 8 MiB (8 B), b from 64 MiB (64-B records)", k_mix<1, false>, M1, 8, tb, M1, 64)) return 1;
     if (run("floor : a and b from 2 MiB tables (L2 resident)", k_mix<1, false>, (1u << 15) - 1, 8, tb, (1u << 15) - 1, 32)) return 1;
+    {
+        // sliced pass: a slice = 2^17 entries x 8 B = 1 MiB, b slice = 2^17 x 32 B = 4 MiB (or 2^16: 2 MiB)
+        for (int bbits : {17, 16}) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 5; rep++) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_sliced, dim3(512), dim3(1024), 0, 0, ta, (1u << 17) - 1, 17, tb, (1u << bbits) - 1, bbits,
+                                   reinterpret_cast<const int2 *>(pairs), n, reinterpret_cast<float *>(od), om);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            printf("XCD-sliced pass 2: a 1 MiB slice, b %d MiB slice per XCD, 8 B in / 8 B out    %7.3f ms  %6.2f G pairs/s\n",
+                   bbits == 17 ? 4 : 2, best, n / best / 1e6);
+        }
+    }
     return 0;
 }

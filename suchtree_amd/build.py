@@ -15,6 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsuchtree_hip.so")
 SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep.cpp"),
            os.path.join(CSRC, "newick_parse.cpp")]
+MICRO_LIB = os.path.join(HERE, "libst_microbench.so")      # measurement helpers for bench.py, not the product
+MICRO_SRC = os.path.join(CSRC, "microbench.hip")
 HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
            os.path.join(CSRC, "host_pipe.h"),
            os.path.join(HERE, "..", "include", "suchtree_hip.h")]
@@ -40,6 +42,18 @@ def stale():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build_microbench(force=False, verbose=False):
+    """libst_microbench.so: the random-sector / stream-copy ceilings bench.py measures in-process."""
+    if not force and os.path.exists(MICRO_LIB) and os.path.getmtime(MICRO_LIB) >= os.path.getmtime(MICRO_SRC):
+        return MICRO_LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", MICRO_LIB, MICRO_SRC,
+           "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return MICRO_LIB
 
 
 def build(force=False, verbose=False, extra=()):

@@ -92,17 +92,25 @@ struct RecView {
     const int32_t *I;    // nb node ids, node itself first
 };
 
-ST_HD RecView rec_view(const uint8_t *records, int64_t slot, int32_t rec_bytes)
+// The three record tables (tree_prep.h) and the stride of rec_b / rec_i.
+struct RecTables {
+    const uint8_t *a;    // [n * 8]
+    const uint8_t *b;    // [n * half]
+    const uint8_t *i;    // [n * half]
+    int32_t half;        // record_bytes / 2
+};
+
+ST_HD RecView rec_view(const RecTables &R, int64_t slot)
 {
-    const uint8_t *r = records + slot * (int64_t)rec_bytes;
-    const uint8_t *h = r + rec_bytes / 2;
+    const uint8_t *rb = R.b + slot * (int64_t)R.half;
+    const uint8_t *ri = R.i + slot * (int64_t)R.half;
     RecView v;
-    const uint32_t w0 = *reinterpret_cast<const uint32_t *>(r);
+    const uint32_t w0 = *reinterpret_cast<const uint32_t *>(rb);
     v.portal = w0 & 0xFFFFu;
     v.nb = w0 >> 16;
-    v.pbot = *reinterpret_cast<const float *>(h);
-    v.D = reinterpret_cast<const float *>(r + 4);
-    v.I = reinterpret_cast<const int32_t *>(h + 4);
+    v.pbot = *reinterpret_cast<const float *>(ri);
+    v.D = reinterpret_cast<const float *>(rb + 4);
+    v.I = reinterpret_cast<const int32_t *>(ri + 4);
     return v;
 }
 

@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void k_quartet_pick(const long long *__restric
 struct CanopyParams {
     const CanopyEntry *canopy;     // [canopy_nodes] global copy, staged to LDS
     const int32_t *canopy_id;      // [canopy_nodes]
-    const uint8_t *records;        // [n_nodes * rec_bytes]
+    const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
+    const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
+    const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
     long long n_nodes;
     long long n_leaves;
     int32_t canopy_nodes;
@@ -365,12 +367,12 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
         }
         const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
         const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
-        const uint8_t *ra = P.records + sa * rec_bytes;
-        const uint8_t *rb = P.records + sb * rec_bytes;
+        const uint8_t *rb = P.rec_b + sb * (rec_bytes / 2);
 
-        // a: word0 and pbot.  b: the whole first half (word0 + chain lengths).
-        const uint32_t wa = *reinterpret_cast<const uint32_t *>(ra);
-        const float pbot_a = *reinterpret_cast<const float *>(ra + rec_bytes / 2);
+        // a: word0 and pbot (8 bytes of rec_a).  b: word0 + chain lengths (rec_b).
+        const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+        const uint32_t wa = va.x;
+        const float pbot_a = __uint_as_float(va.y);
         uint32_t wb;
         float Db[CAP > 0 ? CAP : 1];
         if (CAP == 1) {
@@ -397,9 +399,8 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
             const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
             r = pair_canopy_split<CAP>(can, P.canopy_id, pa, pbot_a, pb, dptr, wb >> 16);
         } else {
-            const RecView A = rec_view(P.records, sa, rec_bytes);
-            const RecView B = rec_view(P.records, sb, rec_bytes);
-            r = pair_canopy_same_portal(P.canopy_id, A, B);
+            const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
+            r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
         }
         store_result(out_d, out_m, i, r.dist, r.mrca);
     }
@@ -453,10 +454,10 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
         float s[PPL], Db[PPL][CAP];
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
-            const uint8_t *ra = P.records + sa[j] * rec_bytes;
-            const uint8_t *rb = P.records + sb[j] * rec_bytes;
-            const uint32_t wa = *reinterpret_cast<const uint32_t *>(ra);
-            s[j] = *reinterpret_cast<const float *>(ra + rec_bytes / 2);
+            const uint8_t *rb = P.rec_b + sb[j] * (rec_bytes / 2);
+            const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa[j]];
+            const uint32_t wa = va.x;
+            s[j] = __uint_as_float(va.y);
             uint32_t wb;
             if (CAP == 1) {
                 const uint2 q = *reinterpret_cast<const uint2 *>(rb);
@@ -545,9 +546,8 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             if (pa[j] == pb[j]) {
-                const RecView A = rec_view(P.records, sa[j], rec_bytes);
-                const RecView B = rec_view(P.records, sb[j], rec_bytes);
-                const PairResult r = pair_canopy_same_portal(P.canopy_id, A, B);
+                const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
+                const PairResult r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
                 s[j] = r.dist;
                 m[j] = r.mrca;
             }
@@ -627,10 +627,10 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Sr
                 } else {
                     const long long sa = record_slot(a, parity, P.n_leaves);
                     const long long sb = record_slot(b, parity, P.n_leaves);
-                    const uint8_t *ra = P.records + sa * rec_bytes;
-                    const uint8_t *rb = P.records + sb * rec_bytes;
-                    const uint32_t wa = *reinterpret_cast<const uint32_t *>(ra);
-                    s = *reinterpret_cast<const float *>(ra + rec_bytes / 2);
+                    const uint8_t *rb = P.rec_b + sb * (rec_bytes / 2);
+                    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+                    const uint32_t wa = va.x;
+                    s = __uint_as_float(va.y);
                     uint32_t wb;
                     if (CAP == 1) {
                         const uint2 q = *reinterpret_cast<const uint2 *>(rb);
@@ -652,9 +652,8 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Sr
                     pbv = v;
                     nbv = wb >> 16;
                     if (u == v) {   // shared portal: the MRCA is the portal or below it
-                        const RecView A = rec_view(P.records, sa, rec_bytes);
-                        const RecView B = rec_view(P.records, sb, rec_bytes);
-                        const PairResult r = pair_canopy_same_portal(P.canopy_id, A, B);
+                        const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
+                        const PairResult r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
                         store_result(out_d, out_m, cur_idx, r.dist, r.mrca);
                     } else {
                         ph = CLIMB1;
@@ -754,7 +753,7 @@ struct st_tree {
     int32_t *d_depth = nullptr;
     CanopyEntry *d_canopy = nullptr;
     int32_t *d_canopy_id = nullptr;
-    uint8_t *d_records = nullptr;
+    uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
     Fault *d_fault = nullptr;
     // canopy geometry
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
@@ -859,7 +858,9 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     CanopyParams P;
     P.canopy = t->d_canopy;
     P.canopy_id = t->d_canopy_id;
-    P.records = t->d_records;
+    P.rec_a = t->d_rec_a;
+    P.rec_b = t->d_rec_b;
+    P.rec_i = t->d_rec_i;
     P.n_nodes = t->n_nodes;
     P.n_leaves = t->n_leaves;
     P.canopy_nodes = t->canopy_nodes;
@@ -1170,7 +1171,9 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
         if (T.canopy.size() & 1) T.canopy.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
         rc = upload(&t->d_canopy, T.canopy, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_records, T.records, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
     }
     if (rc == ST_OK) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), sizeof(Fault));
@@ -1205,7 +1208,9 @@ void st_tree_destroy(st_tree *t)
     (void)hipFree(t->d_depth);
     (void)hipFree(t->d_canopy);
     (void)hipFree(t->d_canopy_id);
-    (void)hipFree(t->d_records);
+    (void)hipFree(t->d_rec_a);
+    (void)hipFree(t->d_rec_b);
+    (void)hipFree(t->d_rec_i);
     (void)hipFree(t->d_fault);
     t->pipe.destroy();
     (void)hipFree(t->q_tmp);

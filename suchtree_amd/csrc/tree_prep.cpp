@@ -135,16 +135,21 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     T.record_cap = cap;
 
     // records, parents first so a chain is "self + parent's chain"
-    T.records.assign((size_t)n * (size_t)rec_bytes, 0);
+    const size_t half = (size_t)rec_bytes / 2;
+    T.rec_a.assign((size_t)n * 8, 0);
+    T.rec_b.assign((size_t)n * half, 0);
+    T.rec_i.assign((size_t)n * half, 0);
     for (int64_t k = 0; k < n; k++) {
         int32_t x = T.bfs_order[(size_t)k];
-        uint8_t *rec = T.records.data() + (size_t)record_slot(x, T.parity_layout, T.n_leaves) * (size_t)rec_bytes;
-        uint32_t *w = reinterpret_cast<uint32_t *>(rec);
-        float *D = reinterpret_cast<float *>(rec + 4);
-        int32_t *I = reinterpret_cast<int32_t *>(rec + rec_bytes / 2 + 4);
+        const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
+        uint8_t *rb = T.rec_b.data() + slot * half;
+        uint8_t *ri = T.rec_i.data() + slot * half;
+        float *D = reinterpret_cast<float *>(rb + 4);
+        int32_t *I = reinterpret_cast<int32_t *>(ri + 4);
+        uint32_t w0;
         float pbot = 0.0f;
         if (cidx[(size_t)x] >= 0) {
-            w[0] = (uint32_t)cidx[(size_t)x];   // chain length 0: the node is its own portal
+            w0 = (uint32_t)cidx[(size_t)x];   // chain length 0: the node is its own portal
         } else {
             int32_t p = parent[x];
             uint32_t portal, nb;
@@ -152,24 +157,30 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
                 portal = (uint32_t)cidx[(size_t)p];
                 nb = 1;
             } else {
-                const uint8_t *prec = T.records.data() + (size_t)record_slot(p, T.parity_layout, T.n_leaves) * (size_t)rec_bytes;
-                const uint32_t *pw = reinterpret_cast<const uint32_t *>(prec);
-                portal = pw[0] & 0xFFFFu;
-                uint32_t pnb = pw[0] >> 16;
+                const size_t pslot = (size_t)record_slot(p, T.parity_layout, T.n_leaves);
+                const uint8_t *prb = T.rec_b.data() + pslot * half;
+                const uint8_t *pri = T.rec_i.data() + pslot * half;
+                uint32_t pw0;
+                std::memcpy(&pw0, prb, 4);
+                portal = pw0 & 0xFFFFu;
+                uint32_t pnb = pw0 >> 16;
                 nb = pnb + 1;
-                std::memcpy(D + 1, prec + 4, 4 * (size_t)pnb);
-                std::memcpy(I + 1, prec + rec_bytes / 2 + 4, 4 * (size_t)pnb);
+                std::memcpy(D + 1, prb + 4, 4 * (size_t)pnb);
+                std::memcpy(I + 1, pri + 4, 4 * (size_t)pnb);
             }
             if ((int32_t)nb > cap) return false;   // cannot happen: nb <= H <= cap
             D[0] = distance[x];
             I[0] = x;
-            w[0] = portal | (nb << 16);
+            w0 = portal | (nb << 16);
             // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
             volatile float acc = 0.0f;
             for (uint32_t i = 0; i < nb; i++) acc = acc + D[i];
             pbot = acc;
         }
-        std::memcpy(rec + rec_bytes / 2, &pbot, 4);
+        std::memcpy(rb, &w0, 4);
+        std::memcpy(ri, &pbot, 4);
+        std::memcpy(T.rec_a.data() + slot * 8, &w0, 4);
+        std::memcpy(T.rec_a.data() + slot * 8 + 4, &pbot, 4);
     }
     T.has_canopy = true;
     return true;

@@ -41,13 +41,15 @@ struct CanopyEntry {
 constexpr uint32_t kCanopyParentMask = 0xFFFFu;
 static_assert(sizeof(CanopyEntry) == 8, "CanopyEntry must be 8 bytes");
 
-// Understory record of R bytes, two halves of R/2:
-//   first half : word0 = portal (canopy index, bits 0..15) | chain length << 16,
-//                then cap float32 branch lengths, the node's own first
-//   second half: pbot (float32 running sum of that chain from 0), then the cap
-//                int32 node ids of the same chain
-// with cap = R/8 - 1.  A pair reads word0 + pbot of `a` and the first half of
-// `b`; the second-half ids are only needed when both lineages share a portal.
+// Understory record of a node, cap = R/8 - 1 chain slots, kept in three tables so that
+// each side of a pair touches the fewest bytes (all indexed by record slot):
+//   rec_a  8 bytes  : word0 = portal (canopy index, bits 0..15) | chain length << 16,
+//                     pbot (float32 running sum of the chain from 0)
+//   rec_b  R/2 bytes: word0 again, then cap float32 branch lengths, the node's own first
+//   rec_i  R/2 bytes: pbot again, then the cap int32 node ids of the same chain
+// A pair reads rec_a[a] (8 B of a table small enough to be partly L2 resident) and
+// rec_b[b]; rec_i is only needed when both lineages share a portal.  R ("record_bytes")
+// is kept as the name of the geometry: rec_b and rec_i have stride R/2.
 constexpr int kMaxCanopyNodes = 16384;   // 16384 * 8 B = 128 KiB of the 160 KiB LDS
 constexpr int kMaxRecordBytes = 512;
 constexpr int kMinRecordBytes = 16;
@@ -71,7 +73,9 @@ struct TreeTables {
     int32_t record_cap = 0;             // chain slots per record
     std::vector<CanopyEntry> canopy;    // [canopy_nodes]
     std::vector<int32_t> canopy_id;     // [canopy_nodes] canopy index -> node id
-    std::vector<uint8_t> records;       // [n * record_bytes], slot order
+    std::vector<uint8_t> rec_a;         // [n * 8], slot order
+    std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
+    std::vector<uint8_t> rec_i;         // [n * record_bytes/2]
 };
 
 // Record slot of node id x.  With the parity layout leaf records come first

@@ -38,6 +38,121 @@ def triangle_row_of(k):
     return i
 
 
+class ShardPlan:
+    """Who computes what, and in which pieces the results travel.
+
+    ``n`` pairs are cut into ``world`` contiguous slices (``shard_bounds``); every
+    slice is cut again into ``chunks`` contiguous pieces so that the transfer of
+    piece c to the root overlaps the kernel of piece c+1 (the all-at-once gather
+    of an 8-GPU run costs ~4x the kernel time it follows).
+    """
+
+    def __init__(self, n: int, world: int, rank: int, chunks: int = 4, root: int = 0):
+        if n < 0 or chunks < 1 or not (0 <= root < world):
+            raise ValueError("bad plan")
+        self.n, self.world, self.rank, self.chunks, self.root = int(n), int(world), int(rank), int(chunks), int(root)
+        shard_bounds(n, world, rank)   # validates world / rank
+
+    def bounds(self, g: int) -> Tuple[int, int]:
+        return shard_bounds(self.n, self.world, g)
+
+    def piece(self, g: int, c: int) -> Tuple[int, int]:
+        """Global pair range of piece ``c`` of rank ``g``'s slice (may be empty)."""
+        lo, hi = self.bounds(g)
+        plo, phi = shard_bounds(hi - lo, self.chunks, c)
+        return lo + plo, lo + phi
+
+    def pieces(self, g: int):
+        return [self.piece(g, c) for c in range(self.chunks)]
+
+
+def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=None, wire_m=None,
+                group=None):
+    """One pass of the hot path over ``plan.n`` pairs, sharded over the process group, with
+    the result assembled on ``plan.root``: the north star's "pair batches shard across the
+    GPUs, RCCL over xGMI only for the final gather".  The same code runs on ``nccl`` (RCCL,
+    device tensors, asynchronous on streams) and on ``gloo`` (CPU tensors, the test-suite).
+
+    ``compute(lo, hi, dst_d, dst_m)`` performs (or enqueues on the current stream) the pair
+    computation for the global pair range ``[lo, hi)``: distances into the 1-D tensor
+    ``dst_d`` (float64 or float32 -- the values are float32 sums either way), MRCA ids into
+    the int32 tensor ``dst_m``, both of length ``hi - lo``.
+
+    Root:   ``result_d`` float64[n] and ``result_m`` int32[n] receive everything: its own
+            slice is computed in place, the peers' pieces arrive by point-to-point receives
+            -- MRCA ids straight into ``result_m``, distances as float32 into ``wire_d``
+            (float32[n], root only) and are widened into ``result_d`` piece by piece.
+            A gather to one root uses every peer's own xGMI link to the root at once; a
+            ring all-gather would push (G-1)/G of all bytes through every single link.
+    Peers:  compute piece c into ``wire_d`` / ``wire_m`` (float32 / int32, slice length)
+            and send it while piece c+1 is being computed.  8 bytes per pair on the wire.
+    Returns the list of pending communication handles, already waited on (stream-ordered
+    for RCCL: the caller's current stream is made to wait, the host is not blocked).
+    """
+    import torch.distributed as dist
+
+    world, rank, root = plan.world, plan.rank, plan.root
+    lo, hi = plan.bounds(rank)
+    if world == 1:
+        if hi > lo:
+            compute(lo, hi, result_d[lo:hi], result_m[lo:hi])
+        return []
+    pending = []
+    if rank == root:
+        # receives first: they only depend on the peers, so they run under the root's own kernels
+        for c in range(plan.chunks):
+            ops = []
+            for g in range(world):
+                if g == root:
+                    continue
+                plo, phi = plan.piece(g, c)
+                if phi > plo:
+                    ops.append(dist.P2POp(dist.irecv, wire_d[plo:phi], g, group))
+                    ops.append(dist.P2POp(dist.irecv, result_m[plo:phi], g, group))
+            pending.append(dist.batch_isend_irecv(ops) if ops else [])
+        for plo, phi in plan.pieces(rank):
+            if phi > plo:
+                compute(plo, phi, result_d[plo:phi], result_m[plo:phi])
+        for c in range(plan.chunks):
+            for w in pending[c]:
+                w.wait()
+            for g in range(world):
+                if g == root:
+                    continue
+                plo, phi = plan.piece(g, c)
+                if phi > plo:
+                    result_d[plo:phi].copy_(wire_d[plo:phi])     # float32 -> float64, exact
+        return pending
+    for c in range(plan.chunks):
+        plo, phi = plan.piece(rank, c)
+        if phi <= plo:
+            continue
+        dst_d, dst_m = wire_d[plo - lo:phi - lo], wire_m[plo - lo:phi - lo]
+        compute(plo, phi, dst_d, dst_m)
+        pending.append(dist.batch_isend_irecv([dist.P2POp(dist.isend, dst_d, root, group),
+                                               dist.P2POp(dist.isend, dst_m, root, group)]))
+    for works in pending:
+        for w in works:
+            w.wait()     # the wire buffers may be overwritten by the next pass after this
+    return pending
+
+
+def sharded_buffers(plan: ShardPlan, device=None):
+    """(result_d, result_m, wire_d, wire_m) torch tensors of the sizes ``run_sharded`` needs on
+    this rank: results only on the root, wire buffers only where something travels."""
+    import torch
+
+    lo, hi = plan.bounds(plan.rank)
+    root = plan.rank == plan.root
+    result_d = torch.empty(plan.n if root else 0, dtype=torch.float64, device=device)
+    result_m = torch.empty(plan.n if root else 0, dtype=torch.int32, device=device)
+    if plan.world == 1:
+        return result_d, result_m, None, None
+    wire_d = torch.empty(plan.n if root else hi - lo, dtype=torch.float32, device=device)
+    wire_m = None if root else torch.empty(hi - lo, dtype=torch.int32, device=device)
+    return result_d, result_m, wire_d, wire_m
+
+
 def distances_sharded(tree, pairs, group=None, gather: bool = True,
                       compute: Optional[Callable] = None):
     """Distances and MRCA ids for ``pairs`` with the work split over the process group.

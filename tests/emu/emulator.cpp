@@ -56,10 +56,20 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
         } else {
             const int64_t sa = record_slot(a, T.parity_layout, T.n_leaves);
             const int64_t sb = record_slot(b, T.parity_layout, T.n_leaves);
-            const RecView A = rec_view(T.records.data(), sa, T.record_bytes);
-            const RecView B = rec_view(T.records.data(), sb, T.record_bytes);
+            const RecTables R{T.rec_a.data(), T.rec_b.data(), T.rec_i.data(), T.record_bytes / 2};
+            const RecView A = rec_view(R, sa);
+            const RecView B = rec_view(R, sb);
+            // the a side of a kernel reads only rec_a: {word0, pbot}
+            uint32_t wa;
+            float pbot_a;
+            std::memcpy(&wa, R.a + sa * 8, 4);
+            std::memcpy(&pbot_a, R.a + sa * 8 + 4, 4);
+            if (wa != (A.portal | (A.nb << 16)) || std::memcmp(&pbot_a, &A.pbot, 4) != 0) {
+                g_err = "rec_a disagrees with rec_b / rec_i";
+                return 3;
+            }
             if (A.portal != B.portal)
-                r = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), A.portal, A.pbot,
+                r = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), wa & 0xFFFFu, pbot_a,
                                          B.portal, B.D, B.nb);
             else
                 r = pair_canopy_same_portal(T.canopy_id.data(), A, B);

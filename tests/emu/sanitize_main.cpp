@@ -61,8 +61,9 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
         const PairResult w = pair_walk(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
         if (pair_walk_mrca(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b) != w.mrca) return 2;
         if (!canopy) continue;
-        const RecView A = rec_view(T.records.data(), record_slot(a, T.parity_layout, T.n_leaves), T.record_bytes);
-        const RecView B = rec_view(T.records.data(), record_slot(b, T.parity_layout, T.n_leaves), T.record_bytes);
+        const RecTables R{T.rec_a.data(), T.rec_b.data(), T.rec_i.data(), T.record_bytes / 2};
+        const RecView A = rec_view(R, record_slot(a, T.parity_layout, T.n_leaves));
+        const RecView B = rec_view(R, record_slot(b, T.parity_layout, T.n_leaves));
         const PairResult c = A.portal != B.portal
             ? pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), A.portal, A.pbot, B.portal, B.D, B.nb)
             : pair_canopy_same_portal(T.canopy_id.data(), A, B);

@@ -64,6 +64,70 @@ def _worker(rank, world, port, n_pairs, q):
         dist.destroy_process_group()
 
 
+def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q):
+    """bench.py's step, verbatim (sharding.run_sharded), on gloo/CPU tensors with the oracle
+    injected as the compute step: slices, pieces, float32 wire format, assembly on the root."""
+    import torch
+    import torch.distributed as dist
+    from oracle.oracle import OracleTree
+    from suchtree_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        parent, dist_ = synth.balanced_tree(9)
+        O = OracleTree(parent, dist_)
+        pairs = np.random.default_rng(5).integers(0, len(parent), (n_pairs, 2))
+        plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, root=root)
+        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan)
+        calls = []
+
+        def compute(lo, hi, dst_d, dst_m):
+            calls.append((lo, hi, dst_d.dtype))
+            dst_d.copy_(torch.from_numpy(O.distances(pairs[lo:hi])).to(dst_d.dtype))
+            dst_m.copy_(torch.from_numpy(O.mrca_bulk(pairs[lo:hi])))
+
+        for _ in range(2):     # twice: buffers are reused from pass to pass, as in the bench loop
+            sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
+        ok = sum(hi - lo for lo, hi, _ in calls) == 2 * (plan.bounds(rank)[1] - plan.bounds(rank)[0])
+        if rank == root:
+            ok = ok and np.array_equal(out_d.numpy().view(np.int64), O.distances(pairs).view(np.int64))
+            ok = ok and np.array_equal(out_m.numpy(), O.mrca_bulk(pairs))
+            ok = ok and all(dt == torch.float64 for _, _, dt in calls)
+        else:
+            ok = ok and out_d.numel() == 0 and all(dt == torch.float32 for _, _, dt in calls)
+        q.put((rank, bool(ok), len(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs,chunks,root", [(1001, 3, 0), (4, 4, 0), (777, 1, 1)])
+def test_run_sharded_world_size_2_gloo(n_pairs, chunks, root):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_run_sharded, args=(r, 2, port, n_pairs, chunks, root, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert [r[1] for r in res] == [True, True]
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_shard_plan_pieces_tile_the_batch():
+    for n in (0, 5, 1000, 12345):
+        for world in (1, 2, 8):
+            for chunks in (1, 3, 4):
+                seen = []
+                for g in range(world):
+                    plan = sharding.ShardPlan(n, world, g, chunks=chunks)
+                    assert plan.pieces(g)[0][0] == plan.bounds(g)[0] and plan.pieces(g)[-1][1] == plan.bounds(g)[1]
+                    seen += plan.pieces(g)
+                assert seen[0][0] == 0 and seen[-1][1] == n
+                assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+
+
 @pytest.mark.parametrize("n_pairs", [1001, 4])
 def test_world_size_2_gloo(n_pairs):
     import torch.multiprocessing as mp
