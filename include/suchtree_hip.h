@@ -57,7 +57,7 @@ typedef struct st_tree_info {
     int32_t canopy_nodes;     /* nodes staged in LDS (0 for walk) */
     int32_t understory_max;   /* longest chain below the canopy, in nodes */
     int32_t record_bytes;     /* stride of one understory record */
-    int32_t reserved;
+    int32_t n_devices;        /* GPUs holding a replica (1 unless st_tree_create_multi) */
     int64_t device_bytes;     /* HBM held by this tree */
 } st_tree_info;
 
@@ -77,6 +77,31 @@ int st_device_count(int *count);
  */
 int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes,
                    int device, int strategy, st_tree **out);
+
+/*
+ * Same tree replicated on several GPUs of one node, driven from ONE process: the reference's
+ * user calls T.distances(ids) from a single process (SuchTree/MuchTree.pyx:872-909) and
+ * parallelises with a fork pool over contiguous chunks
+ * (docs/examples/SuchTree_examples.md:462-497); here the "_host" entry points deal their
+ * pipeline chunks round-robin over `devices` (one host thread, one staging pipe and one
+ * PCIe link per GPU; st_host_chunk_plan / st_host_chunk_owner state the map).  The tables
+ * are built once and uploaded to every listed device.  Device-pointer entry points, the
+ * small-batch mailbox and st_quartets_host use devices[0].
+ */
+int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n_nodes,
+                         const int *devices, int n_devices, int strategy, st_tree **out);
+
+/* Devices of a handle, devices[0] first (devices may be NULL to ask for the count only). */
+int st_tree_devices(const st_tree *tree, int *devices, int capacity, int *n_devices);
+
+/*
+ * How a host batch of n pairs is cut into pipeline chunks and which device of a
+ * multi-device handle gets which chunk (no GPU needed): chunk c covers
+ * [c * chunk_pairs, min(n, (c+1) * chunk_pairs)) and is computed by devices[c % n_devices].
+ */
+int st_host_chunk_plan(int64_t n, int n_devices, int64_t *chunk_pairs, int64_t *n_chunks);
+int st_host_chunk_owner(int64_t n, int n_devices, int64_t chunk_index, int *device_index,
+                        int64_t *first_pair, int64_t *n_pairs);
 
 /* Replaces SuchTree.__dealloc__ (MuchTree.pyx:230-232). */
 void st_tree_destroy(st_tree *tree);
@@ -106,7 +131,8 @@ int st_distances_host_i32(st_tree *tree, const int32_t *pairs, int64_t n,
  * Same computation on device-resident buffers, enqueued on `stream`
  * (a hipStream_t; NULL = default stream).  Does not synchronise.  Out-of-range
  * ids never dereference the tree: such pairs produce NaN / -1 and are
- * recorded in the tree's fault word, read back by st_fault_check.
+ * recorded in the tree's device-path fault word, read back by st_fault_check
+ * (the "_host" entry points keep a fault word of their own).
  */
 int st_distances_device(st_tree *tree, const int64_t *d_pairs, int64_t n,
                         int64_t stride0, int64_t stride1,
@@ -143,6 +169,35 @@ int st_triangle_host(st_tree *tree, const int64_t *ids, int64_t m, int64_t id_st
                      double *out_dist, int32_t *out_mrca, int64_t *bad_id);
 
 /*
+ * Grid generator: for id lists row_ids[0..n_rows) and col_ids[0..n_cols) (contiguous int64)
+ * computes element e = r * n_cols + c, the pair (row_ids[r], col_ids[c]), for e in
+ * [e_begin, e_begin + e_count); out[e - e_begin] receives the result.  With `symmetric` != 0
+ * (same list on both sides) elements below the diagonal take their mirror image's argument
+ * order, so the whole range [0, n^2) IS the symmetric matrix of SuchTree.pairwise_distances
+ * (SuchTree/MuchTree.pyx:1084-1124: pairs (ids[i], ids[j]), i < j, scattered to [i,j] and
+ * [j,i]; zero diagonal), written straight into the caller's (n,n) float64 array -- the
+ * reference's Python pair list and its scatter loop (:1106-1122) have no counterpart.
+ * A rectangular grid is the distance block of nearest_neighbors (:1069-1072).
+ */
+int st_grid_host(st_tree *tree, const int64_t *row_ids, int64_t n_rows,
+                 const int64_t *col_ids, int64_t n_cols, int symmetric,
+                 int64_t e_begin, int64_t e_count,
+                 double *out_dist, int32_t *out_mrca, int64_t *bad_id);
+
+/*
+ * k nearest candidates of every query: distances query -> cands on the device, then a
+ * per-row selection of the k smallest (ties: lower candidate index first), both on the GPU.
+ * Replaces the pair list, distances_bulk call and np.argsort of SuchTree.nearest_neighbors
+ * (SuchTree/MuchTree.pyx:1069-1082) for many queries at once.  out_index (n_queries, k) holds
+ * positions in `cands` (-1 where fewer than k candidates exist), out_dist (n_queries, k) the
+ * distances, ascending.  skip_self != 0 ignores candidates equal to the query id (the
+ * reference drops a leaf query from its default candidate list, :1058-1062).  1 <= k <= 256.
+ */
+int st_knn_host(st_tree *tree, const int64_t *queries, int64_t n_queries,
+                const int64_t *cands, int64_t n_cands, int k, int skip_self,
+                int64_t *out_index, double *out_dist, int64_t *bad_id);
+
+/*
  * Quartet topologies: for each row (a,b,c,d) of the int64 (n,4) view the row re-ordered so
  * that columns (0,1) and (2,3) are the sister pairs.  Replaces
  * SuchTree._quartet_topologies (SuchTree/MuchTree.pyx:1331-1376) as called by
@@ -168,13 +223,9 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
  * ST_ERR_ARG if the tree was built without that family's tables. */
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
-/* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the
- * canopy kernel keeps in flight: 1 (default) or 2; 0 = scalar, branchy form (default for deep canopies).
- * "lockstep": 1 (default) = the climb inside the canopy uses the depth cut (max(ka,kb)
- * rounds), 0 = "larger index moves up" (ka+kb rounds, one LDS read per round).
- * "flow": 1 = per-lane flow kernel (lanes advance through their own pairs without waiting
- * for the wave), 0 (default) = wave-synchronous kernels.
- * "flow_batch": lanes that must be waiting before the flow kernel refills (default 16).
+/* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the canopy
+ * kernel keeps in flight: 1 (default) or 2 (explicit pair arrays only); 0 = scalar, branchy
+ * form (default for deep canopies).
  * "small_batch_path": 1 (default) = host batches of <= 2048 pairs go through a pinned,
  * device-mapped mailbox (one launch + one synchronisation), 0 = through the staged pipe. */
 int st_tree_set_option(st_tree *tree, const char *name, int64_t value);

@@ -213,3 +213,65 @@ def py_distances(parent, distance, pairs):
             n = int(parent[n])
         out[i] = float(d)
     return out
+
+
+# ---- graph matrices of the two-tree graph (dense, numpy; small inputs only) ----
+# Independent restatement of the reference's own dense-block construction; shares no code
+# with suchtree_amd.linked (which builds an edge list for the GPU assembly).
+
+def tree_adjacency(parent, left, right, distance, start_node, epsilon):
+    """SuchTree.adjacency_matrix, MuchTree.pyx:1750-1813: breadth-first node list of the
+    subtree below ``start_node`` and the dense symmetric matrix of its edge lengths
+    (float32 branch lengths widened to float64; a zero length becomes ``epsilon``)."""
+    to_visit = [int(start_node)]                      # :1777-1788
+    for current_id in to_visit:
+        if int(left[current_id]) != -1:
+            to_visit.append(int(left[current_id]))
+            to_visit.append(int(right[current_id]))
+    node_ids = np.array(to_visit)
+    node_count = len(to_visit)
+    adj_matrix = np.zeros((node_count, node_count), dtype=float)   # :1790-1791
+    for i in range(node_count):                       # :1794-1811
+        node_id = node_ids[i]
+        parent_id = int(parent[node_id])
+        if parent_id == -1:
+            continue
+        d = float(np.float32(distance[node_id]))
+        if d == 0:
+            d += epsilon
+        parent_idx = np.where(node_ids == parent_id)[0]
+        if len(parent_idx) > 0:
+            parent_idx = parent_idx[0]
+            adj_matrix[i, parent_idx] = d
+            adj_matrix[parent_idx, i] = d
+    return adj_matrix, node_ids
+
+
+def linked_adjacency(tree_a, tree_b, linklist, root_a, root_b, epsilon_a, epsilon_b):
+    """SuchLinkedTrees.adjacency with deletions = additions = swaps = 0, MuchTree.pyx:3081-3131.
+    ``tree_x`` = (parent, left, right, distance) flat arrays; ``linklist`` rows are
+    [TreeB leaf id, TreeA leaf id] (MuchTree.pyx:2862-2874)."""
+    ta_aj, ta_ids = tree_adjacency(*tree_a, root_a, epsilon_a)
+    tb_aj, tb_ids = tree_adjacency(*tree_b, root_b, epsilon_b)
+    ta_node_ids, tb_node_ids = ta_ids.tolist(), tb_ids.tolist()
+    ll = np.array(linklist)
+    ta_links = [ta_node_ids.index(x) for x in ll[:, 1]]                       # :3106
+    tb_links = [tb_node_ids.index(x) + ta_aj.shape[0] for x in ll[:, 0]]      # :3107
+    aj = np.zeros((ta_aj.shape[0] + tb_aj.shape[0], ta_aj.shape[1] + tb_aj.shape[1]))   # :3110-3111
+    aj[0:ta_aj.shape[0], 0:ta_aj.shape[1]] = ta_aj / ta_aj.max()              # :3114
+    aj[ta_aj.shape[0]:, ta_aj.shape[1]:] = tb_aj / tb_aj.max()                # :3115
+    ta_mean = np.mean(ta_aj.flatten()[ta_aj.flatten() > epsilon_a])           # :3118
+    tb_mean = np.mean(tb_aj.flatten()[tb_aj.flatten() > epsilon_b])           # :3119
+    link_mean = (ta_mean / ta_aj.max() + tb_mean / tb_aj.max()) / 2.0         # :3120
+    for i, j in zip(tb_links, ta_links):                                      # :3125-3127
+        aj[i, j] = link_mean
+        aj[j, i] = link_mean
+    return aj
+
+
+def linked_laplacian(aj):
+    """SuchLinkedTrees.laplacian, MuchTree.pyx:3133-3145."""
+    lp = np.zeros(aj.shape)
+    np.fill_diagonal(lp, aj.sum(axis=0))
+    lp = lp - aj
+    return lp

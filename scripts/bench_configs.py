@@ -111,7 +111,7 @@ def main():
 
     if "4" in todo:
         m = args.tri_leaves
-        parent, dist = synth.random_binary_tree(m, seed=44)
+        parent, dist = synth.complete_tree(m, seed=44)
         tree = _capi.DeviceTree(parent, dist)
         ids = np.arange(0, 2 * m, 2, dtype=np.int64)
         ids_t = torch.from_numpy(ids).to(dev)

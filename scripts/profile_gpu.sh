@@ -1,22 +1,25 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel trace + the PMC passes the
-# roofline.traffic figure comes from.  Each counter set gets its own run, with
-# --kernel-trace only (no sys/hip/hsa tracing next to --pmc).
+# roofline.traffic figure comes from, and the calibration passes that give the bytes per
+# fabric request for the two access patterns involved.  Each counter set gets its own run,
+# with --kernel-trace only (no sys/hip/hsa tracing next to --pmc).
 # usage: scripts/profile_gpu.sh <round-tag> [bench args...]
 set -u
-TAG=${1:-r01}; shift || true
-ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path"}
+TAG=${1:-r02}; shift || true
+ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-microbench"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" ; do
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" ; do
   N=$(echo $C | tr ' ' '_')
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
   echo "pmc $N rc=$?"
+  # the same counters on two launches of exactly known traffic (scripts/micro/calib_requests.hip)
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cal_$N -- $REPO/scripts/micro/bin/calib_requests > $OUT/cal_$N.log 2>&1
+  echo "cal $N rc=$?"
 done
 cd $REPO
-find $OUT -name "*.csv" | head -40
 python3 scripts/summarize_profile.py $OUT $TAG || true

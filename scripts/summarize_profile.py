@@ -77,15 +77,52 @@ def main():
             means, counts = counter_means(d, full or kernel)
             counters.update(means)
     summary["counters_mean_per_launch"] = counters
+    # calibration: the same counters on launches of exactly known traffic
+    # (scripts/micro/calib_requests.hip): bytes per read request of a coalesced 16-B-per-lane
+    # stream and of random 32-byte reads that touch one 64-byte sector each
+    cal = {}
+    for d in sorted(glob.glob(os.path.join(out_dir, "cal_*"))):
+        if os.path.isdir(d):
+            for kern, key in (("k_copy", "copy"), ("k_gather", "gather")):
+                means, _ = counter_means(d, kern)
+                for k, v in means.items():
+                    cal["%s.%s" % (key, k)] = v
+    COPY_BYTES, GATHER_READS = float(1 << 30), 512.0 * 1024 * 256
+    if cal.get("copy.TCC_EA0_RDREQ_sum") and cal.get("gather.TCC_EA0_RDREQ_sum"):
+        cal["stream_bytes_per_read_request"] = COPY_BYTES / cal["copy.TCC_EA0_RDREQ_sum"]
+        cal["gather_read_requests_per_read"] = cal["gather.TCC_EA0_RDREQ_sum"] / GATHER_READS
+    if cal.get("copy.FETCH_SIZE"):
+        cal["copy_bytes_per_FETCH_SIZE_KiB"] = COPY_BYTES / cal["copy.FETCH_SIZE"]
+    if cal.get("gather.FETCH_SIZE") and cal.get("gather.TCC_EA0_RDREQ_sum"):
+        cal["gather_FETCH_SIZE_bytes_per_request"] = cal["gather.FETCH_SIZE"] * 1024.0 / cal["gather.TCC_EA0_RDREQ_sum"]
+    if cal.get("copy.WRITE_SIZE"):
+        cal["copy_bytes_per_WRITE_SIZE_KiB"] = COPY_BYTES / cal["copy.WRITE_SIZE"]
+    if cal:
+        with open(os.path.join(prof, "calibration_%s.json" % tag), "w") as fh:
+            json.dump(cal, fh, indent=1, sort_keys=True)
+    summary["calibration"] = {k: v for k, v in cal.items() if not k.startswith(("copy.", "gather."))}
+    pairs = summary["pairs_per_launch"]
     if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-        # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
-        # so it is doubled (MI355X_MICROARCH.md, section HBM) before comparing with byte counts
+        # rocprofv3 reports both in KiB.  The guide's gfx950 rule (FETCH_SIZE x2) holds for wide
+        # coalesced streams only: FETCH_SIZE is TCC_EA0_RDREQ x 64 B, a streamed request carries
+        # 128 B, a single-sector record request 64 B.  Kept for reference:
         fetch = counters["FETCH_SIZE"] * 1024.0
         write = counters["WRITE_SIZE"] * 1024.0
-        summary["hbm_bytes_per_launch"] = 2.0 * fetch + write
+        summary["hbm_bytes_per_launch_x2_rule"] = 2.0 * fetch + write
         summary["fetch_bytes_raw"] = fetch
         summary["write_bytes"] = write
-        summary["correction"] = "FETCH_SIZE x2 (gfx950), KiB -> bytes"
+    if "TCC_EA0_RDREQ_sum" in counters and "WRITE_SIZE" in counters:
+        # fabric bytes by request size: the pair stream (16 B per pair, coalesced) leaves L2 as
+        # requests of the calibrated stream size (128 B on gfx950); every other read request is
+        # a single 64-byte sector of a record table; writes are coalesced streams (WRITE_SIZE exact)
+        stream_req_bytes = cal.get("stream_bytes_per_read_request", 128.0)
+        stream_requests = 16.0 * pairs / stream_req_bytes
+        record_requests = max(0.0, counters["TCC_EA0_RDREQ_sum"] - stream_requests)
+        summary["hbm_bytes_per_launch"] = stream_requests * stream_req_bytes + record_requests * 64.0 + counters["WRITE_SIZE"] * 1024.0
+        summary["traffic_model"] = {"stream_read_requests": stream_requests, "stream_bytes_per_request": stream_req_bytes,
+                                    "record_read_requests": record_requests, "record_bytes_per_request": 64.0,
+                                    "write_bytes": counters["WRITE_SIZE"] * 1024.0,
+                                    "record_requests_per_pair": record_requests / pairs}
     with open(os.path.join(prof, "kernel_stats_%s.csv" % tag), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     with open(os.path.join(prof, "traffic_%s.json" % tag), "w") as fh:

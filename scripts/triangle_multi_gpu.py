@@ -40,7 +40,7 @@ def main():
 
     from suchtree_amd import _capi, sharding, synth
     m = args.leaves
-    parent, dist_ = synth.random_binary_tree(m, seed=44)
+    parent, dist_ = synth.complete_tree(m, seed=44)
     tree = _capi.DeviceTree(parent, dist_, device=local)
     ids = np.arange(0, 2 * m, 2, dtype=np.int64)
     lo, hi = sharding.triangle_shard_bounds(m, world, rank)

@@ -20,9 +20,10 @@ STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
 
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
-    "st_last_error", "st_device_count", "st_tree_create", "st_tree_destroy", "st_tree_info_get",
+    "st_last_error", "st_device_count", "st_tree_create", "st_tree_create_multi", "st_tree_devices",
+    "st_host_chunk_plan", "st_host_chunk_owner", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_fault_check", "st_tree_set_strategy",
-    "st_tree_set_option", "st_triangle_device", "st_triangle_host",
+    "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
@@ -40,18 +41,33 @@ class TreeInfo(ctypes.Structure):
         ("canopy_nodes", ctypes.c_int32),
         ("understory_max", ctypes.c_int32),
         ("record_bytes", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("n_devices", ctypes.c_int32),
         ("device_bytes", ctypes.c_int64),
     ]
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_}
         d["strategy"] = STRATEGY_NAME.get(d["strategy"], str(d["strategy"]))
         return d
 
 
 _lib = None
 _lock = threading.Lock()
+_gpu_pid = None     # pid of the process in which this module first put a tree on a GPU
+
+
+def _check_fork():
+    """HIP cannot be used in a child forked after the parent initialised the GPU runtime (its
+    worker threads and its device context do not survive fork).  The reference's documented
+    recipe -- module-level trees used from multiprocessing.Pool workers
+    (docs/examples/SuchTree_examples.md:462-497) -- therefore works when the parent has not
+    touched the GPU before the pool forks (uploads are lazy: each worker uploads at its first
+    query), or with the 'spawn' start method (trees pickle as their flat arrays)."""
+    if _gpu_pid is not None and _gpu_pid != os.getpid():
+        raise HipBackendError(
+            "this process was forked after its parent (pid %d) had initialised the GPU; HIP cannot be used "
+            "in a forked child. Use multiprocessing.get_context('spawn'), or fork the workers before the "
+            "first GPU query (a SuchTree uploads lazily, at its first query in each process)." % _gpu_pid)
 
 
 def _preload_hip_runtime():
@@ -86,8 +102,15 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH) and os.environ.get("SUCHTREE_AMD_AUTOBUILD", "1") != "0":
-            # source checkout without the built library: compile it once (hipcc, gfx950)
+        autobuild = os.environ.get("SUCHTREE_AMD_AUTOBUILD", "1") != "0"
+        try:
+            from . import build as _build
+            is_stale = os.path.exists(LIB_PATH) and _build.stale()
+        except OSError:      # sources not shipped: nothing to compare with
+            is_stale = False
+        if (not os.path.exists(LIB_PATH) or is_stale) and autobuild:
+            # source checkout without the built library, or sources newer than it (the C ABI's
+            # struct layout and argtypes are mirrored by hand below): compile (hipcc, gfx950)
             try:
                 from . import build as _build
                 _build.build()
@@ -97,6 +120,10 @@ def load():
                 build_error = None
         else:
             build_error = None
+        if os.path.exists(LIB_PATH) and is_stale and build_error is not None:
+            import warnings
+            warnings.warn("libsuchtree_hip.so is older than its sources and rebuilding failed (%s); "
+                          "loading the stale library" % build_error, RuntimeWarning)
         if not os.path.exists(LIB_PATH):
             if build_error is not None:
                 raise HipBackendError("libsuchtree_hip.so is not built and building it failed: %s" % build_error)
@@ -113,6 +140,10 @@ def load():
         L.st_last_error.restype = ctypes.c_char_p
         L.st_device_count.argtypes = [ctypes.POINTER(i32)]
         L.st_tree_create.argtypes = [vp, vp, i64, i32, i32, ctypes.POINTER(vp)]
+        L.st_tree_create_multi.argtypes = [vp, vp, i64, ctypes.POINTER(i32), i32, i32, ctypes.POINTER(vp)]
+        L.st_tree_devices.argtypes = [vp, ctypes.POINTER(i32), i32, ctypes.POINTER(i32)]
+        L.st_host_chunk_plan.argtypes = [i64, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.st_host_chunk_owner.argtypes = [i64, i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.st_tree_destroy.argtypes = [vp]
         L.st_tree_destroy.restype = None
         L.st_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
@@ -125,6 +156,8 @@ def load():
         L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
         L.st_triangle_device.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, vp]
         L.st_triangle_host.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
+        L.st_grid_host.argtypes = [vp, vp, i64, vp, i64, i32, i64, i64, vp, vp, ctypes.POINTER(i64)]
+        L.st_knn_host.argtypes = [vp, vp, i64, vp, i64, i32, i32, vp, vp, ctypes.POINTER(i64)]
         L.st_quartets_host.argtypes = [vp, vp, i64, i64, i64, vp, ctypes.POINTER(i64)]
         L.st_graph_matrices_host.argtypes = [i32, i64, i64, vp, vp, vp, vp, vp]
         L.st_newick_open.argtypes = [ctypes.c_char_p, i64, ctypes.POINTER(vp), ctypes.POINTER(i64),
@@ -216,6 +249,20 @@ def newick_native(text):
         L.st_newick_close(h)
 
 
+def host_chunk_map(n, n_devices):
+    """[(device_index, first_pair, n_pairs)] for every pipeline chunk of an n-pair host batch
+    dealt over n_devices GPUs (st_host_chunk_plan / st_host_chunk_owner; no GPU needed)."""
+    L = load()
+    chunk, count = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(L.st_host_chunk_plan(int(n), int(n_devices), ctypes.byref(chunk), ctypes.byref(count)))
+    out = []
+    for c in range(count.value):
+        d, first, m = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(L.st_host_chunk_owner(int(n), int(n_devices), c, ctypes.byref(d), ctypes.byref(first), ctypes.byref(m)))
+        out.append((int(d.value), int(first.value), int(m.value)))
+    return out
+
+
 def device_count():
     c = ctypes.c_int(0)
     rc = load().st_device_count(ctypes.byref(c))
@@ -229,9 +276,13 @@ def _ptr(a):
 
 
 class DeviceTree:
-    """Owner of one ``st_tree`` handle (the tree resident in one GPU's HBM)."""
+    """Owner of one ``st_tree`` handle: the tree resident in one GPU's HBM, or -- with
+    ``devices=[...]`` -- replicated on several GPUs of the node (``st_tree_create_multi``),
+    the host-buffer entry points then dealing their chunks over all of them."""
 
-    def __init__(self, parent, distance, device=0, strategy="auto"):
+    def __init__(self, parent, distance, device=0, strategy="auto", devices=None):
+        global _gpu_pid
+        _check_fork()
         L = load()
         self._lib = L
         self._h = ctypes.c_void_p()
@@ -242,14 +293,28 @@ class DeviceTree:
         if strategy not in STRATEGY:
             raise ValueError("strategy must be one of %s" % sorted(STRATEGY))
         self.size = int(parent.shape[0])
-        rc = L.st_tree_create(_ptr(parent), _ptr(distance), self.size, int(device),
-                              STRATEGY[strategy], ctypes.byref(self._h))
+        self._pid = os.getpid()
+        if devices is not None:
+            devices = [int(d) for d in devices]
+            if not devices:
+                raise ValueError("devices must not be empty")
+            arr = (ctypes.c_int * len(devices))(*devices)
+            rc = L.st_tree_create_multi(_ptr(parent), _ptr(distance), self.size, arr, len(devices),
+                                        STRATEGY[strategy], ctypes.byref(self._h))
+            device = devices[0]
+        else:
+            rc = L.st_tree_create(_ptr(parent), _ptr(distance), self.size, int(device),
+                                  STRATEGY[strategy], ctypes.byref(self._h))
+            devices = [int(device)]
         check(rc)
         self.device = int(device)
+        self.devices = list(devices)
+        if _gpu_pid is None:
+            _gpu_pid = self._pid
 
     def close(self):
         h, self._h = self._h, ctypes.c_void_p()
-        if h:
+        if h and self._pid == os.getpid():     # a handle inherited through fork is not ours to destroy
             self._lib.st_tree_destroy(h)
 
     def __del__(self):
@@ -262,6 +327,9 @@ class DeviceTree:
     def handle(self):
         if not self._h:
             raise HipBackendError("tree handle is closed")
+        if self._pid != os.getpid():
+            _check_fork()
+            raise HipBackendError("tree handle belongs to another process (pid %d)" % self._pid)
         return self._h
 
     def info(self):
@@ -331,6 +399,45 @@ class DeviceTree:
                                         _ptr(out_d), _ptr(out_m), ctypes.byref(bad))
         check(rc, tree_size=self.size, bad_id=int(bad.value))
         return out_d, out_m
+
+    def grid_host(self, row_ids, col_ids, symmetric=False, e_begin=0, e_count=None, want_dist=True,
+                  want_mrca=False, out_dist=None, out_mrca=None):
+        """Element e = r * len(col_ids) + c of the grid is the pair (row_ids[r], col_ids[c]);
+        ``symmetric`` (same list twice): below the diagonal the mirror image's argument order,
+        i.e. the full range is the symmetric matrix of pairwise_distances, flattened."""
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        col_ids = np.ascontiguousarray(col_ids, dtype=np.int64)
+        if row_ids.ndim != 1 or col_ids.ndim != 1:
+            raise ValueError("id lists must be 1-D")
+        total = int(row_ids.shape[0]) * int(col_ids.shape[0])
+        if e_count is None:
+            e_count = total - e_begin
+        out_d = self._out(out_dist, e_count, np.float64, want_dist)
+        out_m = self._out(out_mrca, e_count, np.int32, want_mrca)
+        bad = ctypes.c_int64(0)
+        rc = self._lib.st_grid_host(self.handle, _ptr(row_ids) if len(row_ids) else None, len(row_ids),
+                                    _ptr(col_ids) if len(col_ids) else None, len(col_ids), int(bool(symmetric)),
+                                    int(e_begin), int(e_count), _ptr(out_d), _ptr(out_m), ctypes.byref(bad))
+        check(rc, tree_size=self.size, bad_id=int(bad.value))
+        return out_d, out_m
+
+    KNN_MAX_K = 256
+
+    def knn_host(self, queries, cands, k, skip_self=False):
+        """(index int64 (q,k) into cands, dist float64 (q,k)): the k nearest candidates of every
+        query, selected on the GPU; -1 / NaN where fewer than k candidates exist."""
+        queries = np.ascontiguousarray(queries, dtype=np.int64)
+        cands = np.ascontiguousarray(cands, dtype=np.int64)
+        if queries.ndim != 1 or cands.ndim != 1:
+            raise ValueError("queries and cands must be 1-D")
+        q = int(queries.shape[0])
+        idx = np.empty((q, int(k)), dtype=np.int64)
+        dist = np.empty((q, int(k)), dtype=np.float64)
+        bad = ctypes.c_int64(0)
+        rc = self._lib.st_knn_host(self.handle, _ptr(queries) if q else None, q, _ptr(cands) if len(cands) else None,
+                                   len(cands), int(k), int(bool(skip_self)), _ptr(idx), _ptr(dist), ctypes.byref(bad))
+        check(rc, tree_size=self.size, bad_id=int(bad.value))
+        return idx, dist
 
     def quartets_host(self, quartets):
         """quartets: int64 (n,4) ndarray (any non-negative strides); returns int64 (n,4)."""

@@ -18,7 +18,7 @@ SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep
 MICRO_LIB = os.path.join(HERE, "libst_microbench.so")      # measurement helpers for bench.py, not the product
 MICRO_SRC = os.path.join(CSRC, "microbench.hip")
 HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
-           os.path.join(CSRC, "host_pipe.h"),
+           os.path.join(CSRC, "host_pipe.h"), os.path.join(CSRC, "host_copy.h"),
            os.path.join(HERE, "..", "include", "suchtree_hip.h")]
 
 FLAGS = [

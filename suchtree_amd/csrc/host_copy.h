@@ -1,0 +1,120 @@
+// host_copy.h -- the CPU side of the host-buffer path: the three memory passes that
+// every pair pays on the host (pack ids -> pinned, unpack distances, unpack MRCA ids)
+// and the pre-faulting of freshly allocated result arrays.
+//
+// The host path is CPU-memory-bound (the GPU and PCIe have headroom),
+// so each pass moves as few bytes as it can: results are written with non-temporal
+// stores (no read-for-ownership of lines that are overwritten whole), ids are narrowed
+// to int32 while they are copied, and pages of a fresh result array are populated by
+// the copy pool (MADV_POPULATE_WRITE on huge-page-advised ranges) while the GPU works,
+// instead of one 4 KiB fault at a time inside the unpack loop.
+#pragma once
+#include <emmintrin.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstring>
+#include <limits>
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23   // Linux 5.14
+#endif
+
+namespace st {
+
+// float32 -> float64, dst written with streaming stores.
+inline void widen_f32_to_f64(double *dst, const float *src, int64_t n)
+{
+    int64_t k = 0;
+    while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 15)) { dst[k] = (double)src[k]; k++; }
+    for (; k + 4 <= n; k += 4) {
+        const __m128 v = _mm_loadu_ps(src + k);
+        _mm_stream_pd(dst + k, _mm_cvtps_pd(v));
+        _mm_stream_pd(dst + k + 2, _mm_cvtps_pd(_mm_movehl_ps(v, v)));
+    }
+    for (; k < n; k++) dst[k] = (double)src[k];
+    _mm_sfence();
+}
+
+// plain copy with streaming stores (dst is written once and read much later)
+inline void copy_stream(void *dst_, const void *src_, int64_t bytes)
+{
+    char *dst = static_cast<char *>(dst_);
+    const char *src = static_cast<const char *>(src_);
+    int64_t k = 0;
+    const int64_t head = (16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15;
+    if (head && head <= bytes) { std::memcpy(dst, src, (size_t)head); k = head; }
+    for (; k + 64 <= bytes; k += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k + 16));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k + 32));
+        const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + k), a);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + k + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + k + 32), c);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + k + 48), d);
+    }
+    if (k < bytes) std::memcpy(dst + k, src + k, (size_t)(bytes - k));
+    _mm_sfence();
+}
+
+// C-order int64 (m,2) -> int32 (m,2).  Values outside int32 are clamped to INT32_MAX /
+// INT32_MIN (still out of range for the kernel) and their exact extremes are reported in
+// hi / lo, so the id the caller finally reports is the reference's (MuchTree.pyx:897-903).
+inline void narrow_pairs_i64(int32_t *dst, const int64_t *src, int64_t m, long long &hi, long long &lo)
+{
+    const int64_t n = 2 * m;          // scalars
+    constexpr int64_t kBlock = 2048;  // scalars per checked block
+    for (int64_t base = 0; base < n; base += kBlock) {
+        const int64_t end = base + kBlock < n ? base + kBlock : n;
+        int64_t k = base;
+        __m128i bad = _mm_setzero_si128();
+        if ((reinterpret_cast<uintptr_t>(dst + k) & 15) == 0) {
+            for (; k + 4 <= end; k += 4) {
+                const __m128 v0 = _mm_castsi128_ps(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k)));
+                const __m128 v1 = _mm_castsi128_ps(_mm_loadu_si128(reinterpret_cast<const __m128i *>(src + k + 2)));
+                const __m128i low = _mm_castps_si128(_mm_shuffle_ps(v0, v1, _MM_SHUFFLE(2, 0, 2, 0)));
+                const __m128i high = _mm_castps_si128(_mm_shuffle_ps(v0, v1, _MM_SHUFFLE(3, 1, 3, 1)));
+                // fits int32  <=>  high word == sign extension of the low word
+                bad = _mm_or_si128(bad, _mm_xor_si128(high, _mm_srai_epi32(low, 31)));
+                _mm_stream_si128(reinterpret_cast<__m128i *>(dst + k), low);
+            }
+        }
+        const bool redo = _mm_movemask_epi8(_mm_cmpeq_epi32(bad, _mm_setzero_si128())) != 0xFFFF;
+        for (int64_t q = redo ? base : k; q < end; q++) {
+            const long long v = src[q];
+            int32_t w = (int32_t)v;
+            if (v > INT32_MAX) { w = INT32_MAX; if (v > hi) hi = v; }
+            else if (v < INT32_MIN) { w = INT32_MIN; if (v < lo) lo = v; }
+            dst[q] = w;
+        }
+    }
+    _mm_sfence();
+}
+
+// Make [p, p + bytes) resident and writable without taking one page fault per 4 KiB inside
+// the copy loops.  Safe on any memory the caller is about to overwrite anyway.
+inline void populate_for_write(void *p, int64_t bytes)
+{
+    static const long page = sysconf(_SC_PAGESIZE);
+    const uintptr_t b = (reinterpret_cast<uintptr_t>(p) + (uintptr_t)page - 1) & ~((uintptr_t)page - 1);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes) & ~((uintptr_t)page - 1);
+    if (e <= b) return;
+    static int have_populate = 1;
+    if (have_populate) {
+        if (madvise(reinterpret_cast<void *>(b), e - b, MADV_POPULATE_WRITE) == 0) return;
+        have_populate = 0;   // old kernel: touch the pages instead
+    }
+    for (uintptr_t q = b; q < e; q += (uintptr_t)page) *reinterpret_cast<volatile char *>(q) = 0;
+}
+
+inline void advise_huge(void *p, int64_t bytes)
+{
+    const uintptr_t huge = (uintptr_t)2 << 20;
+    const uintptr_t b = (reinterpret_cast<uintptr_t>(p) + huge - 1) & ~(huge - 1);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes) & ~(huge - 1);
+    if (e > b) (void)madvise(reinterpret_cast<void *>(b), e - b, MADV_HUGEPAGE);
+}
+
+}  // namespace st

@@ -1,22 +1,29 @@
-// host_pipe.h -- the host-buffer path of the C ABI: pinned, double-buffered, overlapped.
+// host_pipe.h -- the host-buffer path of the C ABI: pinned, double-buffered, zero-copy.
 //
 // Callers of st_distances_host / st_triangle_host own ordinary (pageable) memory, which
-// the HIP runtime copies at ~10 GB/s.  The pipe keeps two slots of pinned staging +
-// device buffers on two streams and a small pool of copy threads:
+// the HIP runtime copies at ~10 GB/s.  The pipe keeps two slots of pinned staging memory
+// that the GPU reads and writes DIRECTLY over PCIe, two streams and a pool of copy threads:
 //
-//   pack(c)   : caller's pairs  -> pinned (parallel memcpy / strided gather)
-//   gpu(c)    : H2D, kernel, D2H into pinned, on stream c&1   (async); distances travel
-//               as float32 (they are float32 sums), MRCA ids as int32
-//   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / memcpy)
+//   pack(c)   : caller's pairs  -> pinned (parallel narrowing copy / strided gather)
+//   gpu(c)    : one kernel on stream c&1 that loads its pairs from the pinned slot and
+//               stores its results into the pinned slot; distances travel as float32
+//               (they are float32 sums), MRCA ids as int32
+//   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / copy)
 //
-// unpack(c-1) and pack(c+1) run on the CPU while gpu(c) is in flight, and the two
-// streams let the H2D of one chunk overlap the D2H of the other (PCIe is full duplex).
+// unpack(c-1) and pack(c+1) run on the CPU while gpu(c) is in flight.  There are no
+// hipMemcpyAsync calls and no device staging buffers: a kernel that reads 8 B and writes
+// 8 B per lane from / to pinned host memory moves 96 GB/s over the link (both directions at
+// once), the same as one large H2D and one large D2H copy running concurrently, while
+// per-chunk H2D -> kernel -> D2H sequences on two streams fall into lock step (both
+// streams copy in the same direction at the same time) and reach 59 GB/s
+// (scripts/micro/pcie_bench.hip, profiles/pcie_bench_r02.log).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -116,8 +123,8 @@ private:
 };
 
 struct PipeSlot {
-    void *h_in = nullptr, *h_d = nullptr, *h_m = nullptr;   // pinned
-    void *d_in = nullptr, *d_d = nullptr, *d_m = nullptr;   // device
+    void *h_in = nullptr, *h_d = nullptr, *h_m = nullptr;   // pinned host memory, read / written by the kernels
+    void *d_in = nullptr;                                   // device copy of h_in (quartet path only, see ensure_device_in)
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     int64_t off = 0, m = 0;
@@ -140,15 +147,32 @@ struct HostPipe {
             if ((e = hipHostMalloc(&s.h_in, (size_t)pairs * 16, hipHostMallocDefault)) != hipSuccess) return e;
             if ((e = hipHostMalloc(&s.h_d, (size_t)pairs * 4, hipHostMallocDefault)) != hipSuccess) return e;   // float32 transport
             if ((e = hipHostMalloc(&s.h_m, (size_t)pairs * 4, hipHostMallocDefault)) != hipSuccess) return e;
-            if ((e = hipMalloc(&s.d_in, (size_t)pairs * 16)) != hipSuccess) return e;
-            if ((e = hipMalloc(&s.d_d, (size_t)pairs * 4)) != hipSuccess) return e;
-            if ((e = hipMalloc(&s.d_m, (size_t)pairs * 4)) != hipSuccess) return e;
             if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
             if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
         }
         cap = pairs;
+        // copy threads: a quarter of the hardware threads, at most 16 (the three memory passes
+        // of the host path saturate the host's memory system well before they run out of cores);
+        // SUCHTREE_AMD_COPY_THREADS overrides
         const unsigned hw = std::thread::hardware_concurrency();
-        pool.start((int)std::min<unsigned>(16, std::max<unsigned>(1, hw / 4)));
+        int n_threads = (int)std::min<unsigned>(16, std::max<unsigned>(1, hw / 4));
+        if (const char *env = std::getenv("SUCHTREE_AMD_COPY_THREADS")) {
+            const int v = std::atoi(env);
+            if (v >= 1 && v <= 256) n_threads = v;
+        }
+        pool.start(n_threads);
+        return hipSuccess;
+    }
+
+    // device-resident copies of the input slots: only the quartet path wants them (every
+    // quartet row is read by six lanes; over PCIe that would be six fetches)
+    hipError_t ensure_device_in()
+    {
+        for (auto &s : slot) {
+            if (s.d_in) continue;
+            const hipError_t e = hipMalloc(&s.d_in, (size_t)cap * 16);
+            if (e != hipSuccess) return e;
+        }
         return hipSuccess;
     }
 
@@ -167,8 +191,8 @@ struct HostPipe {
     {
         for (auto &s : slot) {
             (void)hipHostFree(s.h_in); (void)hipHostFree(s.h_d); (void)hipHostFree(s.h_m);
-            (void)hipFree(s.d_in); (void)hipFree(s.d_d); (void)hipFree(s.d_m);
-            s.h_in = s.h_d = s.h_m = s.d_in = s.d_d = s.d_m = nullptr;
+            (void)hipFree(s.d_in);
+            s.h_in = s.h_d = s.h_m = s.d_in = nullptr;
             s.busy = false;
         }
         cap = 0;

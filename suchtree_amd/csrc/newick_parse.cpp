@@ -166,8 +166,8 @@ int parse(const char *text, int64_t len, Parsed &P)
             while (j < len) {
                 const unsigned char d = (unsigned char)text[j];
                 if (d == ' ' || d == '\t' || d == '\n' || d == '\r' || d == '\f' || d == '\v' || d == '(' ||
-                    d == ')' || d == '[' || d == ']' || d == ',' || d == ':' || d == ';' || d == '\'')
-                    break;
+                    d == ')' || d == '[' || d == ']' || d == ',' || d == ':' || d == ';')
+                    break;     // (a quote inside an unquoted token is an ordinary character, as in dendropy's tokenizer)
                 if (d >= 0x80) return 1;
                 j++;
             }

@@ -8,11 +8,11 @@
 //           cut; works for any rooted tree.
 //   canopy  the top of the tree lives in LDS (BFS-numbered, 8 B per node);
 //           everything below it is folded into one fixed-stride understory
-//           record per node, so a pair costs two record reads from HBM plus an
-//           LDS climb instead of ~h dependent global gathers.
+//           record per node (split into an 8-byte a-side table and a b-side table), so
+//           a pair costs two record reads plus an LDS climb instead of ~h dependent
+//           global gathers.
 //           k_canopy      scalar, branchy (default for deep canopies)
 //           k_canopy_ilp  1-2 pairs per lane, predicated (default otherwise)
-//           k_canopy_flow per-lane state machine (selectable)
 //
 // Every kernel is templated on a pair source (SrcContig / SrcContig32 / SrcStrided /
 // SrcTriangle / SrcQuartet): an explicit (n,2) array in HBM, or pairs derived from their
@@ -31,12 +31,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/suchtree_hip.h"
+#include "host_copy.h"
 #include "host_pipe.h"
 #include "pair_math.h"
 #include "tree_prep.h"
@@ -155,6 +159,27 @@ struct SrcTriangle {
         const long long col = k - row * (row - 1) / 2;
         a = ids[col * stride];
         b = ids[row * stride];
+    }
+};
+
+// Grid generator: element e = e0 + i of an n_rows x n_cols grid (C order) is the pair
+// (rows[r], cols[c]), r = e / n_cols, c = e % n_cols.  `symmetric` (rows and cols are the same
+// id list): below the diagonal the pair is taken in the order of its mirror image above it,
+// (ids[c], ids[r]) for c < r, so the square is exactly the mirrored upper triangle that
+// pairwise_distances builds (MuchTree.pyx:1106-1124: d(ids[i], ids[j]) for i < j, stored at
+// [i,j] and [j,i]); the diagonal comes out as d(x,x) = 0.  Consecutive lanes share one endpoint
+// and walk the id list with the other, so record reads coalesce as in the triangle.
+struct SrcGrid {
+    const long long *rows, *cols;
+    long long n_cols, e0;
+    int symmetric;
+    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
+    {
+        const long long e = e0 + i;
+        const long long r = e / n_cols, c = e - r * n_cols;
+        a = rows[r];
+        b = cols[c];
+        if (symmetric && c < r) { const long long t = a; a = b; b = t; }
     }
 };
 
@@ -330,7 +355,6 @@ struct CanopyParams {
 };
 
 constexpr int kCanopyBlock = 1024;
-constexpr int kFlowRounds = 8;   // climb rounds between two control points of the flow kernel
 
 // stage the canopy image into LDS: 16 bytes (two entries) per lane per step, coalesced
 __device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned char *lds_raw)
@@ -411,7 +435,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
 // the same loop iteration as independent ds_read_b64 (low word = dist bits, high word =
 // parent index).  All updates are predicated selects (a finished climb keeps re-reading its
 // meeting node), so the PPL chains never serialise behind a branch.
-template <int CAP, int PPL, bool LOCKSTEP, typename Src>
+template <int CAP, int PPL, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              DistSink out_d,
                                                              int *__restrict__ out_m, Fault *fault)
@@ -489,28 +513,17 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             go = false;
 #pragma unroll
             for (int j = 0; j < PPL; j++) {
-                if (LOCKSTEP) {
-                    // depth cut inside the canopy: both entries are read every round, the deeper
-                    // side moves (both on a tie), so the climb takes max(ka,kb) rounds, not ka+kb
-                    const unsigned long long eu = can[u[j]], ev = can[v[j]];
-                    const uint32_t lu = (uint32_t)(eu >> 32), lv = (uint32_t)(ev >> 32);
-                    const bool act = u[j] != v[j];
-                    const bool mu = act && (lu >> 16) >= (lv >> 16);
-                    const bool mv = act && (lv >> 16) >= (lu >> 16);
-                    const float s_next = s[j] + __uint_as_float((uint32_t)eu);
-                    s[j] = mu ? s_next : s[j];
-                    u[j] = mu ? (lu & kCanopyParentMask) : u[j];
-                    v[j] = mv ? (lv & kCanopyParentMask) : v[j];
-                } else {
-                    const bool act = u[j] != v[j];
-                    const bool up_a = u[j] > v[j];
-                    const unsigned long long e = can[up_a ? u[j] : v[j]];
-                    const uint32_t e_parent = (uint32_t)(e >> 32) & kCanopyParentMask;
-                    const float s_next = s[j] + __uint_as_float((uint32_t)e);
-                    s[j] = up_a ? s_next : s[j];
-                    u[j] = up_a ? e_parent : u[j];
-                    v[j] = (act && !up_a) ? e_parent : v[j];
-                }
+                // depth cut inside the canopy: both entries are read every round, the deeper
+                // side moves (both on a tie), so the climb takes max(ka,kb) rounds, not ka+kb
+                const unsigned long long eu = can[u[j]], ev = can[v[j]];
+                const uint32_t lu = (uint32_t)(eu >> 32), lv = (uint32_t)(ev >> 32);
+                const bool act = u[j] != v[j];
+                const bool mu = act && (lu >> 16) >= (lv >> 16);
+                const bool mv = act && (lv >> 16) >= (lu >> 16);
+                const float s_next = s[j] + __uint_as_float((uint32_t)eu);
+                s[j] = mu ? s_next : s[j];
+                u[j] = mu ? (lu & kCanopyParentMask) : u[j];
+                v[j] = mv ? (lv & kCanopyParentMask) : v[j];
                 go |= u[j] != v[j];
             }
         }
@@ -562,140 +575,67 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
     }
 }
 
-// "Flow" form for deep canopies (selectable with the "flow" option, off by default).  On
-// trees like data/bigtrees/ml.tree the climb is hundreds of LDS rounds per pair and its
-// length varies 10x between pairs, so in the kernels above a wave idles ~70 % of its lanes
-// waiting for its longest lineage.  Measured on ml.tree (rocprofv3 SQ counters, 5e7 pairs):
-// this form issues 45 % fewer LDS instructions but 22 % more VALU and ends 7 % slower than
-// k_canopy_ilp (5.6e9 vs 6.0e9 pairs/s): both sit at ~45 % VALU issue and ~55 % LDS-pipe
-// occupancy with half of the LDS cycles lost to bank conflicts of the random climbs.  Here
-// every lane runs its own sequence of pairs (pair index = wave tile + 64*t + lane) as a
-// small state machine -- NEED -> CLIMB1 -> CLIMB2 -> DONE -- and moves on without
-// waiting for its neighbours; one unified, branch-free round serves both climbs.  The
-// memory-touching stages (store a finished pair, fetch the next pair and its records) run
-// for a batch of waiting lanes at a time so that their latency is paid once per batch and
-// hidden by the other waves of the SIMD.
-template <int CAP, typename Src>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy_flow(CanopyParams P, Src src, long long n,
-                                                              DistSink out_d,
-                                                              int *__restrict__ out_m, Fault *fault,
-                                                              int batch)
+// ---- k nearest candidates per query row (nearest_neighbors, MuchTree.pyx:1032-1082) ----------
+// dist[row * n_c + c] are the float32 distances query(row) -> cands[c].  One workgroup per row
+// selects the k smallest in k rounds: round r finds the smallest key greater than the one
+// chosen in round r-1, key = (order-preserving image of the float) << 32 | candidate index, so
+// ties resolve to the lower candidate index (the reference's argsort leaves tie order
+// unspecified).  O(k * n_c) per row, for small k; the facade sorts on the host beyond kKnnMaxK.
+constexpr int kKnnMaxK = 256;
+
+__device__ __forceinline__ unsigned long long knn_key(float d, unsigned idx)
 {
-    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
-    stage_canopy(P, lds_raw);
+    unsigned u = __float_as_uint(d);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | idx;
+}
 
-    constexpr int rec_bytes = 8 * (CAP + 1);
-    const bool parity = P.parity != 0;
-    const int lane = threadIdx.x & 63;
-    const long long waves_per_block = blockDim.x >> 6;
-    const long long n_waves = (long long)gridDim.x * waves_per_block;
-    const long long wave_id = (long long)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-    const long long per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;   // contiguous tile
-    const long long w_begin = wave_id * per_wave;
-    const long long w_end = w_begin + per_wave < n ? w_begin + per_wave : n;
-
-    enum { NEED = 0, CLIMB1 = 1, CLIMB2 = 2, DONE = 3 };
-    long long my_idx = w_begin + lane;   // my next pair, stride 64
-    long long cur_idx = 0;
-    int ph = NEED;
-    uint32_t u = 0, v = 0, pbv = 0, nbv = 0;
-    float s = 0.0f;
-    float Db[CAP];
-#pragma unroll
-    for (int q = 0; q < CAP; q++) Db[q] = 0.0f;
-
-    for (;;) {
-        const unsigned long long act_mask = __ballot(ph == CLIMB1 || ph == CLIMB2);
-        const unsigned long long wait_mask = __ballot(ph == DONE || (ph == NEED && my_idx < w_end));
-        if (act_mask == 0 && wait_mask == 0) break;
-        if ((int)__popcll(wait_mask) >= batch || act_mask == 0) {
-            if (ph == DONE) {
-                store_result(out_d, out_m, cur_idx, s, P.canopy_id[u]);
-                ph = NEED;
-            }
-            if (ph == NEED && my_idx < w_end) {
-                cur_idx = my_idx;
-                my_idx += 64;
-                long long a, b;
-                src.load(cur_idx, a, b);
-                if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-                    (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-                    record_fault(fault, a, b, P.n_nodes);
-                    store_result(out_d, out_m, cur_idx, __builtin_nanf(""), -1);
-                } else {
-                    const long long sa = record_slot(a, parity, P.n_leaves);
-                    const long long sb = record_slot(b, parity, P.n_leaves);
-                    const uint8_t *rb = P.rec_b + sb * (rec_bytes / 2);
-                    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-                    const uint32_t wa = va.x;
-                    s = __uint_as_float(va.y);
-                    uint32_t wb;
-                    if (CAP == 1) {
-                        const uint2 q = *reinterpret_cast<const uint2 *>(rb);
-                        wb = q.x;
-                        Db[0] = __uint_as_float(q.y);
-                    } else {
-                        uint32_t w[CAP + 1];
-#pragma unroll
-                        for (int q = 0; q < (CAP + 1) / 4; q++) {
-                            const uint4 x = reinterpret_cast<const uint4 *>(rb)[q];
-                            w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
-                        }
-                        wb = w[0];
-#pragma unroll
-                        for (int q = 0; q < CAP; q++) Db[q] = __uint_as_float(w[q + 1]);
-                    }
-                    u = wa & 0xFFFFu;
-                    v = wb & 0xFFFFu;
-                    pbv = v;
-                    nbv = wb >> 16;
-                    if (u == v) {   // shared portal: the MRCA is the portal or below it
-                        const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
-                        const PairResult r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
-                        store_result(out_d, out_m, cur_idx, r.dist, r.mrca);
-                    } else {
-                        ph = CLIMB1;
-                    }
-                }
-            }
+__global__ __launch_bounds__(256) void k_knn_select(const float *__restrict__ dist, long long n_c,
+                                                    const long long *__restrict__ queries,
+                                                    const long long *__restrict__ cands, int skip_self, int k,
+                                                    long long *__restrict__ out_index, double *__restrict__ out_dist)
+{
+    __shared__ unsigned long long wave_min[4];
+    __shared__ unsigned long long chosen;
+    const long long row = blockIdx.x;
+    const float *d = dist + row * n_c;
+    const long long q = queries[row];
+    unsigned long long prev = 0;
+    bool first = true;
+    for (int r = 0; r < k; r++) {
+        unsigned long long best = ~0ull;
+        for (long long c = threadIdx.x; c < n_c; c += blockDim.x) {
+            if (skip_self && cands[c] == q) continue;
+            const unsigned long long key = knn_key(d[c], (unsigned)c);
+            if ((first || key > prev) && key < best) best = key;
         }
-        // kFlowRounds rounds of whichever climb the lane is in (both entries are always read;
-        // in CLIMB2 u is the meeting node and stays put).  The phase only changes at the
-        // control points around this block, so a lane that meets early idles < kFlowRounds.
-        {
-            const bool c1 = ph == CLIMB1;
-            const bool climbing = c1 || ph == CLIMB2;
 #pragma unroll
-            for (int r = 0; r < kFlowRounds; r++) {
-                const unsigned long long eu = can[u], ev = can[v];
-                const uint32_t lu = (uint32_t)(eu >> 32), lv = (uint32_t)(ev >> 32);
-                const bool act = climbing && u != v;
-                const bool mu = act && c1 && (lu >> 16) >= (lv >> 16);
-                const bool mv = act && (!c1 || (lv >> 16) >= (lu >> 16));
-                const float addend = __uint_as_float(c1 ? (uint32_t)eu : (uint32_t)ev);
-                const float s_next = s + addend;
-                s = (c1 ? mu : act) ? s_next : s;
-                u = mu ? (lu & kCanopyParentMask) : u;
-                v = mv ? (lv & kCanopyParentMask) : v;
-            }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long other = __shfl_xor(best, off);
+            best = other < best ? other : best;
         }
-        // CLIMB1 met: add b's understory, restart v at b's portal for CLIMB2
-        const bool met1 = ph == CLIMB1 && u == v;
-        if (__ballot(met1)) {
-            if (met1) {
-#pragma unroll
-                for (int q = 0; q < CAP; q++) {
-                    const float s_next = s + Db[q];
-                    s = (uint32_t)q < nbv ? s_next : s;
-                }
-                v = pbv;
-                ph = v == u ? DONE : CLIMB2;
-            }
-        } else if (ph == CLIMB2 && v == u) {
-            ph = DONE;
+        if ((threadIdx.x & 63) == 0) wave_min[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long m = wave_min[0];
+            for (int w = 1; w < 4; w++) m = wave_min[w] < m ? wave_min[w] : m;
+            chosen = m;
+            const long long c = (long long)(m & 0xFFFFFFFFull);
+            const bool found = m != ~0ull;
+            out_index[row * k + r] = found ? c : -1;
+            out_dist[row * k + r] = found ? (double)d[c] : __builtin_nan("");
         }
+        __syncthreads();
+        prev = chosen;
+        first = false;
+        if (prev == ~0ull) {     // fewer than k candidates: the remaining slots stay -1 / NaN
+            for (int rr = r + 1 + (int)threadIdx.x; rr < k; rr += blockDim.x) {
+                out_index[row * k + rr] = -1;
+                out_dist[row * k + rr] = __builtin_nan("");
+            }
+            break;
+        }
+        __syncthreads();
     }
 }
 
@@ -742,6 +682,41 @@ __global__ void k_graph_laplacian(const double *__restrict__ A, const double *__
 // --------------------------------------------------------------------------
 using namespace st;
 
+// One staging pipe (pinned + device buffers, two streams, copy pool) per GPU, shared by every
+// tree of the process on that GPU: SuchLinkedTrees holds two trees, applications hold many,
+// and the staging is ~200 MB of pinned memory and up to 15 threads per pipe.  Reference
+// counted; the mutex admits one host-path call at a time per device.
+struct DevicePipe {
+    std::mutex m;
+    HostPipe pipe;
+    int refs = 0;
+};
+static std::mutex g_pipes_mutex;
+static std::map<int, DevicePipe *> g_pipes;
+
+static DevicePipe *pipe_acquire(int device)
+{
+    std::lock_guard<std::mutex> g(g_pipes_mutex);
+    DevicePipe *&p = g_pipes[device];
+    if (!p) p = new DevicePipe();
+    p->refs++;
+    return p;
+}
+
+static void pipe_release(int device)
+{
+    std::lock_guard<std::mutex> g(g_pipes_mutex);
+    auto it = g_pipes.find(device);
+    if (it == g_pipes.end()) return;
+    if (--it->second->refs > 0) return;
+    {
+        DeviceScope scope(device);
+        it->second->pipe.destroy();
+    }
+    delete it->second;
+    g_pipes.erase(it);
+}
+
 struct st_tree {
     int device = 0;
     int strategy = ST_STRATEGY_WALK;       // family in use
@@ -754,26 +729,30 @@ struct st_tree {
     CanopyEntry *d_canopy = nullptr;
     int32_t *d_canopy_id = nullptr;
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
-    Fault *d_fault = nullptr;
+    // two fault words: the device-pointer entry points are not serialised against anything,
+    // so the host path keeps its own (reset at the start of every host call, read under the
+    // device pipe's mutex) and is never confused by a caller who skipped st_fault_check
+    Fault *d_fault = nullptr;        // st_distances_device / st_triangle_device / st_fault_check
+    Fault *d_fault_host = nullptr;   // st_*_host
     // canopy geometry
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
-    int lockstep = 1;         // tuning: canopy climb 1 by depth cut (1) or by "larger index moves" (0)
-    int flow = 0;             // tuning: per-lane flow kernel 1 / 0 (measured: no faster than the ILP form, kept selectable)
-    int flow_batch = 16;      // lanes that must be waiting before the flow kernel refills
     int canopy_depth = 0;     // deepest canopy node (edges)
     int small_batch_path = 1; // tuning: batches <= kMailboxPairs go through the pinned mailbox
-    // staging of the host entry points (one caller at a time per handle)
-    std::mutex ws_mutex;
-    HostPipe pipe;
+    // staging of the host entry points: the device's shared pipe
+    DevicePipe *dp = nullptr;
     void *q_tmp = nullptr;        // MRCA ids of the quartet path (6 int32 per quartet)
     int64_t q_tmp_cap = 0;
     // mailbox of the small-batch path: pinned host memory the kernel reads and writes directly
+    std::mutex mb_mutex;
     void *mb_host = nullptr;      // [pairs int64 x2 | dist double | mrca int32] x kMailboxPairs
     void *mb_dev = nullptr;       // device alias of mb_host
     Fault *d_fault_mb = nullptr;  // scratch fault word of that path (ids are checked on the host there)
     hipStream_t mb_stream = nullptr;
+    // multi-device handle (st_tree_create_multi): replicas of this tree on the other devices.
+    // Host-path calls deal their chunks over {this, peers...}; everything else uses this tree.
+    std::vector<st_tree *> peers;
 };
 
 static const Fault kFaultInit = {std::numeric_limits<long long>::min(),
@@ -787,7 +766,7 @@ static size_t canopy_lds_bytes(const st_tree *t)
 template <typename Kern, typename Src>
 static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
                                   const Src &src, int64_t n, DistSink out_d, int32_t *out_m,
-                                  hipStream_t stream)
+                                  Fault *fault, hipStream_t stream)
 {
     const size_t lds = canopy_lds_bytes(t);
     if (lds > 64 * 1024) {
@@ -803,57 +782,30 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
-                       (long long)n, out_d, out_m, t->d_fault);
-    return hipGetLastError();
-}
-
-template <int CAP, typename Src>
-static hipError_t launch_canopy_flow(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                     DistSink out_d, int32_t *out_m, hipStream_t stream)
-{
-    const size_t lds = canopy_lds_bytes(t);
-    auto kern = k_canopy_flow<CAP, Src>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
-    // every wave should own at least a few pairs per lane
-    int64_t blocks = (n + (int64_t)kCanopyBlock * 8 - 1) / ((int64_t)kCanopyBlock * 8);
-    blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
-    blocks = std::max<int64_t>(blocks, 1);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
-                       (long long)n, out_d, out_m, t->d_fault, t->flow_batch);
+                       (long long)n, out_d, out_m, fault);
     return hipGetLastError();
 }
 
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                  DistSink out_d, int32_t *out_m, hipStream_t stream)
+                                  DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
 {
-    if constexpr (CAP != 0) {
-        if (t->flow == 1) return launch_canopy_flow<CAP>(t, P, src, n, out_d, out_m, stream);
-    }
     if constexpr (CAP == 0) {
-        return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, stream);
+        return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     } else {
-        const int ppl = std::min(t->pairs_per_lane, 2);
-        if (ppl == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, stream);
-        if (t->lockstep) {
-            if (ppl == 1) return launch_canopy_k(k_canopy_ilp<CAP, 1, true, Src>, 1, t, P, src, n, out_d, out_m, stream);
-            return launch_canopy_k(k_canopy_ilp<CAP, 2, true, Src>, 2, t, P, src, n, out_d, out_m, stream);
-        } else {
-            if (ppl == 1) return launch_canopy_k(k_canopy_ilp<CAP, 1, false, Src>, 1, t, P, src, n, out_d, out_m, stream);
-            return launch_canopy_k(k_canopy_ilp<CAP, 2, false, Src>, 2, t, P, src, n, out_d, out_m, stream);
+        if (t->pairs_per_lane == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+        // two pairs per lane: a measured-equal variant kept selectable for explicit pair arrays only
+        if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
+            if (t->pairs_per_lane == 2)
+                return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, fault, stream);
         }
-        return hipErrorInvalidValue;
+        return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     }
 }
 
 template <typename Src>
 static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                                int32_t *out_m, hipStream_t stream)
+                                int32_t *out_m, Fault *fault, hipStream_t stream)
 {
     CanopyParams P;
     P.canopy = t->d_canopy;
@@ -867,17 +819,17 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.rec_bytes = t->rec_bytes;
     P.parity = t->parity;
     switch (t->rec_cap) {
-        case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, stream);
-        case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, stream);
-        case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, stream);
-        case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, stream);
-        default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, stream);
+        case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream);
+        case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream);
+        case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, fault, stream);
+        case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, fault, stream);
+        default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, fault, stream);
     }
 }
 
 template <typename Src>
 static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                              int32_t *out_m, hipStream_t stream)
+                              int32_t *out_m, Fault *fault, hipStream_t stream)
 {
     WalkParams P;
     P.nodes = t->d_nodes;
@@ -887,7 +839,7 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(k_walk<Src>, dim3((unsigned)blocks), dim3(256), 0, stream, P, src,
-                       (long long)n, out_d, out_m, t->d_fault);
+                       (long long)n, out_d, out_m, fault);
     return hipGetLastError();
 }
 
@@ -896,14 +848,14 @@ constexpr int64_t kCanopyMinPairs = 4096;
 
 template <typename Src>
 static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, int32_t *d_mrca,
-                       hipStream_t stream)
+                       Fault *fault, hipStream_t stream)
 {
     if (n == 0) return ST_OK;
     // MRCA-only requests (d_out == NULL) also go through the canopy kernels: the id comes out
     // of the same climb, and that is ~7x faster than walking the global table
     const bool canopy = t->strategy == ST_STRATEGY_CANOPY && n >= kCanopyMinPairs;
-    const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, stream)
-                                : launch_walk(t, src, n, d_out, d_mrca, stream);
+    const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, fault, stream)
+                                : launch_walk(t, src, n, d_out, d_mrca, fault, stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     return ST_OK;
 }
@@ -913,28 +865,36 @@ static int enqueue(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s0, in
 {
     const long long *p = reinterpret_cast<const long long *>(d_pairs);
     if (s0 == 2 && s1 == 1 && (reinterpret_cast<uintptr_t>(d_pairs) & 15) == 0)
-        return enqueue_src(t, SrcContig{p}, n, d_out, d_mrca, stream);
-    return enqueue_src(t, SrcStrided{p, (long long)s0, (long long)s1}, n, d_out, d_mrca, stream);
+        return enqueue_src(t, SrcContig{p}, n, d_out, d_mrca, t->d_fault, stream);
+    return enqueue_src(t, SrcStrided{p, (long long)s0, (long long)s1}, n, d_out, d_mrca, t->d_fault, stream);
 }
 
-// host_max / host_min: exact extremes of ids the host path had to clamp to 32 bits.
-static int read_fault(st_tree *t, hipStream_t stream, int64_t *bad_id,
-                      long long host_max = std::numeric_limits<long long>::min(),
-                      long long host_min = std::numeric_limits<long long>::max())
+// Copy a fault word back (synchronises `stream`) and re-arm it if it had fired.
+static int fetch_fault(Fault *d_word, hipStream_t stream, Fault &f)
 {
-    Fault f;
-    ST_HIP(hipMemcpyAsync(&f, t->d_fault, sizeof(Fault), hipMemcpyDeviceToHost, stream));
+    ST_HIP(hipMemcpyAsync(&f, d_word, sizeof(Fault), hipMemcpyDeviceToHost, stream));
     ST_HIP(hipStreamSynchronize(stream));
     if (f.max_bad == kFaultInit.max_bad && f.min_bad == kFaultInit.min_bad) return ST_OK;
-    f.max_bad = std::max(f.max_bad, host_max);
-    f.min_bad = std::min(f.min_bad, host_min);
-    ST_HIP(hipMemcpyAsync(t->d_fault, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream));
+    ST_HIP(hipMemcpyAsync(d_word, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream));
     ST_HIP(hipStreamSynchronize(stream));
-    // the reference reports max_id when it is too large, else min_id (MuchTree.pyx:897-903)
-    const long long bad = f.max_bad >= t->n_nodes ? f.max_bad : f.min_bad;
+    return ST_OK;
+}
+
+static void merge_fault(Fault &into, const Fault &f)
+{
+    into.max_bad = std::max(into.max_bad, f.max_bad);
+    into.min_bad = std::min(into.min_bad, f.min_bad);
+}
+
+// ST_OK, or ST_ERR_BOUNDS with the id the reference reports: max_id when it is too large,
+// else min_id (MuchTree.pyx:897-903)
+static int report_fault(int64_t n_nodes, const Fault &f, int64_t *bad_id)
+{
+    if (f.max_bad == kFaultInit.max_bad && f.min_bad == kFaultInit.min_bad) return ST_OK;
+    const long long bad = f.max_bad >= n_nodes ? f.max_bad : f.min_bad;
     if (bad_id) *bad_id = bad;
     return fail(ST_ERR_BOUNDS, "Node ID " + std::to_string(bad) + " out of bounds (tree size: " +
-                                   std::to_string(t->n_nodes) + ")");
+                                   std::to_string(n_nodes) + ")");
 }
 
 template <typename T>
@@ -947,10 +907,27 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
     return ST_OK;
 }
 
-constexpr int64_t kHostChunk = (int64_t)1 << 22;   // pairs per pipeline chunk
+constexpr int64_t kHostChunk = (int64_t)1 << 22;      // most pairs per pipeline chunk
+constexpr int64_t kHostChunkMin = (int64_t)1 << 18;   // fewest, when a batch is dealt over several GPUs
 constexpr int kDeepCanopyDepth = 100;     // canopies deeper than this (edges) are "deep"
 constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
 constexpr int64_t kMailboxPairs = 2048;   // largest batch served through the mailbox
+
+// How a host batch of n pairs is cut into pipeline chunks and dealt over n_dev devices:
+// chunk c covers [c*chunk, min(n, (c+1)*chunk)) and belongs to device index c % n_dev.  With
+// several devices the chunk shrinks (down to kHostChunkMin) so that every device gets work.
+static int64_t host_chunk_pairs(int64_t n, int n_dev)
+{
+    if (n_dev <= 1) return std::max<int64_t>(std::min<int64_t>(n, kHostChunk), 1);
+    int64_t chunk = (n + 2 * (int64_t)n_dev - 1) / (2 * (int64_t)n_dev);   // two rounds per device
+    chunk = std::min(std::max(chunk, kHostChunkMin), kHostChunk);
+    return (chunk + 1023) / 1024 * 1024;
+}
+
+struct ChunkSeq {
+    int64_t n, chunk;
+    int first, step;    // this device handles chunks first, first + step, ...
+};
 
 // Small batches (a scalar distance(a,b) call is a batch of one) are all latency: instead of
 // H2D copy + kernel + D2H copy + fault read-back, the walk kernel reads the pairs from and
@@ -961,6 +938,7 @@ template <typename Id>
 static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, int64_t stride1,
                        double *out_dist, int32_t *out_mrca, int64_t *bad_id)
 {
+    std::lock_guard<std::mutex> lock(t->mb_mutex);
     if (!t->mb_host) {
         const size_t bytes = (size_t)kMailboxPairs * (16 + 8 + 4);
         ST_HIP(hipHostMalloc(&t->mb_host, bytes, hipHostMallocMapped));
@@ -1003,18 +981,18 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
     return ST_OK;
 }
 
-// Push n pairs through the two-slot pipe (host_pipe.h).  pack(slot, off, m) fills
-// slot.h_in for chunk [off, off+m) with in_bytes_per_pair bytes per pair (0: generated pairs, no input);
-// launch(slot, off, m) enqueues the kernel on slot.stream reading slot.d_in and writing
-// slot.d_d / slot.d_m.  Caller holds ws_mutex.
+// Push this device's chunks of a batch through the two-slot pipe (host_pipe.h).
+// pack(slot, off, m) fills slot.h_in for chunk [off, off+m); launch(slot, off, m) enqueues
+// the kernel on slot.stream, reading slot.h_in and writing slot.h_d / slot.h_m -- pinned
+// host memory, accessed by the kernel over PCIe (see host_pipe.h).  Caller holds the device
+// pipe's mutex.
 template <typename Pack, typename Launch>
-static int run_pipe(st_tree *t, int64_t n, int in_bytes_per_pair, Pack pack, Launch launch,
+static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch,
                     double *out_dist, int32_t *out_mrca)
 {
-    HostPipe &P = t->pipe;
-    const int64_t chunk = std::min<int64_t>(n, kHostChunk);
+    HostPipe &P = t->dp->pipe;
     {
-        const hipError_t e = P.ensure(std::max<int64_t>(chunk, 1024));
+        const hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
         if (e != hipSuccess) {
             P.release_buffers();
             return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
@@ -1029,12 +1007,22 @@ static int run_pipe(st_tree *t, int64_t n, int in_bytes_per_pair, Pack pack, Lau
             // distances crossed PCIe as float32; widen into the caller's float64 array
             const float *src = static_cast<const float *>(s.h_d);
             double *dst = out_dist + s.off;
-            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) {
-                for (int64_t k = b; k < e; k++) dst[k] = (double)src[k];
-            });
+            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) { widen_f32_to_f64(dst + b, src + b, e - b); });
         }
-        if (out_mrca) P.pool.copy(out_mrca + s.off, s.h_m, s.m * 4);
+        if (out_mrca) {
+            const int32_t *src = static_cast<const int32_t *>(s.h_m);
+            int32_t *dst = out_mrca + s.off;
+            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) { copy_stream(dst + b, src + b, (e - b) * 4); });
+        }
         return hipSuccess;
+    };
+    // pages of a freshly allocated result array are populated here, by the pool, while the
+    // chunk is on the GPU -- not one fault at a time inside the unpack loops
+    auto prefault = [&](int64_t off, int64_t m) {
+        P.pool.parallel_for(m, [=](int64_t b, int64_t e) {
+            if (out_dist) populate_for_write(out_dist + off + b, (e - b) * 8);
+            if (out_mrca) populate_for_write(out_mrca + off + b, (e - b) * 4);
+        });
     };
     auto bail = [&](int code, const std::string &msg) {
         for (auto &s : P.slot) {
@@ -1043,35 +1031,173 @@ static int run_pipe(st_tree *t, int64_t n, int in_bytes_per_pair, Pack pack, Lau
         }
         return fail(code, msg);
     };
-    int64_t c = 0;
-    for (int64_t off = 0; off < n; off += chunk, c++) {
-        const int64_t m = std::min(chunk, n - off);
-        PipeSlot &s = P.slot[c & 1];
+    int64_t k = 0;
+    for (int64_t c = seq.first; c * seq.chunk < seq.n; c += seq.step, k++) {
+        const int64_t off = c * seq.chunk;
+        const int64_t m = std::min(seq.chunk, seq.n - off);
+        PipeSlot &s = P.slot[k & 1];
         hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
-        if (in_bytes_per_pair > 0) {
-            pack(s, off, m);
-            e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * (size_t)in_bytes_per_pair, hipMemcpyHostToDevice, s.stream);
-            if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("H2D: ") + hipGetErrorString(e));
-        }
+        pack(s, off, m);
         const int rc = launch(s, off, m);
         if (rc != ST_OK) return bail(rc, g_last_error);
-        if (out_dist && e == hipSuccess)
-            e = hipMemcpyAsync(s.h_d, s.d_d, (size_t)m * 4, hipMemcpyDeviceToHost, s.stream);
-        if (out_mrca && e == hipSuccess)
-            e = hipMemcpyAsync(s.h_m, s.d_m, (size_t)m * 4, hipMemcpyDeviceToHost, s.stream);
-        if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
-        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("D2H: ") + hipGetErrorString(e));
+        e = hipEventRecord(s.done, s.stream);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         s.busy = true;
         s.off = off;
         s.m = m;
-        e = drain(P.slot[(c + 1) & 1]);   // unpack the previous chunk while this one is in flight
+        prefault(off, m);
+        e = drain(P.slot[(k + 1) & 1]);   // unpack the previous chunk while this one is in flight
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
     for (auto &s : P.slot) {
         const hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
+    return ST_OK;
+}
+
+// Run `work(tree, seq, fault)` for every replica of a (possibly multi-device) handle, each
+// on its own host thread with its own device's pipe locked, and merge the fault words.
+// work returns ST_OK or an error code (message in that thread's g_last_error).
+template <typename Work>
+static int for_each_replica(st_tree *t, int64_t n, Fault &fault, Work work)
+{
+    const int n_dev = 1 + (int)t->peers.size();
+    const int64_t chunk = host_chunk_pairs(n, n_dev);
+    fault = kFaultInit;
+    auto one = [&](st_tree *r, int index, Fault &f, std::string &err) -> int {
+        DeviceScope scope(r->device);
+        if (scope.error() != hipSuccess) {
+            err = std::string("hipSetDevice: ") + hipGetErrorString(scope.error());
+            return ST_ERR_HIP;
+        }
+        std::lock_guard<std::mutex> lock(r->dp->m);
+        const ChunkSeq seq{n, chunk, index, n_dev};
+        f = kFaultInit;
+        const int rc = work(r, seq, f);
+        if (rc != ST_OK) err = g_last_error;
+        return rc;
+    };
+    if (n_dev == 1) {
+        std::string err;
+        const int rc = one(t, 0, fault, err);
+        return rc == ST_OK ? ST_OK : fail(rc, err);
+    }
+    std::vector<int> rcs((size_t)n_dev, ST_OK);
+    std::vector<Fault> faults((size_t)n_dev, kFaultInit);
+    std::vector<std::string> errs((size_t)n_dev);
+    std::vector<std::thread> threads;
+    for (int d = 1; d < n_dev; d++)
+        threads.emplace_back([&, d] { rcs[(size_t)d] = one(t->peers[(size_t)d - 1], d, faults[(size_t)d], errs[(size_t)d]); });
+    rcs[0] = one(t, 0, faults[0], errs[0]);
+    for (auto &th : threads) th.join();
+    for (int d = 0; d < n_dev; d++) {
+        if (rcs[(size_t)d] != ST_OK) return fail(rcs[(size_t)d], "device " + std::to_string(d == 0 ? t->device : t->peers[(size_t)d - 1]->device) + ": " + errs[(size_t)d]);
+        merge_fault(fault, faults[(size_t)d]);
+    }
+    return ST_OK;
+}
+
+// Tables are built once on the host, then uploaded to every device of the handle.
+struct BuiltTables {
+    TreeTables T;
+    bool canopy_ok = false;
+    bool deep = false;
+};
+
+static int build_tables(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
+{
+    std::string err;
+    if (!prepare_basic(parent, distance, n_nodes, B.T, err)) return fail(ST_ERR_TREE, err);
+    int max_canopy = 0;
+    if (const char *env = std::getenv("SUCHTREE_AMD_CANOPY_NODES")) max_canopy = std::atoi(env);   // tuning experiments
+    if (strategy != ST_STRATEGY_WALK) {
+        B.canopy_ok = prepare_canopy(parent, distance, B.T, max_canopy);
+        // Deep canopies (real, unbalanced phylogenies: hundreds of levels) spend their time in
+        // the LDS climb, not in memory.  There a canopy image small enough for two workgroups
+        // per CU, a longer understory (more of each lineage pre-summed in its record) and the
+        // branchy scalar kernel (finished lanes stop issuing LDS reads) measured 13-30 % faster.
+        if (B.canopy_ok && max_canopy == 0) {
+            int cdepth = 0;
+            for (const CanopyEntry &e : B.T.canopy) cdepth = std::max<int>(cdepth, (int)(e.link >> 16));
+            if (cdepth > kDeepCanopyDepth) {
+                B.deep = true;
+                if (B.T.canopy_nodes > kDeepCanopyNodes) {
+                    TreeTables T2 = B.T;
+                    if (prepare_canopy(parent, distance, T2, kDeepCanopyNodes)) B.T = std::move(T2);
+                }
+            }
+        }
+    }
+    if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
+        return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
+    return ST_OK;
+}
+
+static int upload_tree(BuiltTables &B, int device, st_tree **out)
+{
+    TreeTables &T = B.T;
+    int n_dev = 0;
+    ST_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev)
+        return fail(ST_ERR_HIP, "device " + std::to_string(device) + " not available (" +
+                                    std::to_string(n_dev) + " visible)");
+    ST_DEVICE(device);
+    hipDeviceProp_t prop;
+    ST_HIP(hipGetDeviceProperties(&prop, device));
+
+    st_tree *t = new (std::nothrow) st_tree();
+    if (!t) return fail(ST_ERR_NOMEM, "out of host memory");
+    t->device = device;
+    t->dp = pipe_acquire(device);
+    t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    t->n_nodes = T.n;
+    t->n_leaves = T.n_leaves;
+    if (B.deep) t->pairs_per_lane = 0;
+    int64_t bytes = 0;
+    int rc = upload(&t->d_nodes, T.nodes, &bytes);
+    if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
+    if (rc == ST_OK && B.canopy_ok) {
+        t->has_canopy = true;
+        t->canopy_nodes = T.canopy_nodes;
+        t->rec_bytes = T.record_bytes;
+        t->rec_cap = T.record_cap;
+        t->parity = T.parity_layout ? 1 : 0;
+        for (const CanopyEntry &e : T.canopy) t->canopy_depth = std::max<int>(t->canopy_depth, (int)(e.link >> 16));
+        std::vector<CanopyEntry> image = T.canopy;
+        if (image.size() & 1) image.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
+        rc = upload(&t->d_canopy, image, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
+    }
+    if (rc == ST_OK) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), 2 * sizeof(Fault));
+        const Fault init2[2] = {kFaultInit, kFaultInit};
+        if (e == hipSuccess) e = hipMemcpy(t->d_fault, init2, sizeof(init2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
+        else t->d_fault_host = t->d_fault + 1;
+    }
+    if (rc != ST_OK) {
+        std::string keep = g_last_error;
+        st_tree_destroy(t);
+        g_last_error = keep;
+        return rc;
+    }
+    t->strategy = B.canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
+    t->info.n_nodes = T.n;
+    t->info.n_leaves = T.n_leaves;
+    t->info.root = T.root;
+    t->info.depth = T.tree_depth;
+    t->info.device = device;
+    t->info.canopy_nodes = B.canopy_ok ? T.canopy_nodes : 0;
+    t->info.understory_max = B.canopy_ok ? T.understory_max : 0;
+    t->info.record_bytes = B.canopy_ok ? T.record_bytes : 0;
+    t->info.n_devices = 1;
+    t->info.device_bytes = bytes;
+    *out = t;
     return ST_OK;
 }
 
@@ -1105,118 +1231,101 @@ int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths, 
     return ST_OK;
 }
 
-int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes, int device,
-                   int strategy, st_tree **out)
+int st_host_chunk_plan(int64_t n, int n_devices, int64_t *chunk_pairs, int64_t *n_chunks)
+{
+    if (n < 0 || n_devices < 1) return fail(ST_ERR_ARG, "n < 0 or n_devices < 1");
+    const int64_t chunk = host_chunk_pairs(n, n_devices);
+    if (chunk_pairs) *chunk_pairs = chunk;
+    if (n_chunks) *n_chunks = (n + chunk - 1) / chunk;
+    return ST_OK;
+}
+
+int st_host_chunk_owner(int64_t n, int n_devices, int64_t chunk_index, int *device_index,
+                        int64_t *first_pair, int64_t *n_pairs)
+{
+    if (n < 0 || n_devices < 1 || chunk_index < 0) return fail(ST_ERR_ARG, "bad arguments");
+    const int64_t chunk = host_chunk_pairs(n, n_devices);
+    if (chunk_index * chunk >= n) return fail(ST_ERR_ARG, "chunk index past the end of the batch");
+    // the same arithmetic as ChunkSeq / run_pipe
+    if (device_index) *device_index = (int)(chunk_index % n_devices);
+    if (first_pair) *first_pair = chunk_index * chunk;
+    if (n_pairs) *n_pairs = std::min(chunk, n - chunk_index * chunk);
+    return ST_OK;
+}
+
+static int check_create_args(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, st_tree **out)
 {
     if (!out) return fail(ST_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!parent || !distance || n_nodes <= 0) return fail(ST_ERR_ARG, "parent/distance NULL or n_nodes <= 0");
     if (strategy != ST_STRATEGY_AUTO && strategy != ST_STRATEGY_WALK && strategy != ST_STRATEGY_CANOPY)
         return fail(ST_ERR_ARG, "unknown strategy " + std::to_string(strategy));
+    return ST_OK;
+}
 
-    TreeTables T;
-    std::string err;
-    if (!prepare_basic(parent, distance, n_nodes, T, err)) return fail(ST_ERR_TREE, err);
-    bool canopy_ok = false;
-    int max_canopy = 0;
-    bool deep = false;
-    if (const char *env = std::getenv("SUCHTREE_AMD_CANOPY_NODES")) max_canopy = std::atoi(env);   // tuning experiments
-    if (strategy != ST_STRATEGY_WALK) {
-        canopy_ok = prepare_canopy(parent, distance, T, max_canopy);
-        // Deep canopies (real, unbalanced phylogenies: hundreds of levels) spend their time in
-        // the LDS climb, not in memory.  There a canopy image small enough for two workgroups
-        // per CU, a longer understory (more of each lineage pre-summed in its record) and the
-        // branchy scalar kernel (finished lanes stop issuing LDS reads) measured 13-30 % faster.
-        if (canopy_ok && max_canopy == 0) {
-            int cdepth = 0;
-            for (const CanopyEntry &e : T.canopy) cdepth = std::max<int>(cdepth, (int)(e.link >> 16));
-            if (cdepth > kDeepCanopyDepth) {
-                deep = true;
-                if (T.canopy_nodes > kDeepCanopyNodes) {
-                    TreeTables T2 = T;
-                    if (prepare_canopy(parent, distance, T2, kDeepCanopyNodes)) T = std::move(T2);
-                }
-            }
+int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes, int device,
+                   int strategy, st_tree **out)
+{
+    int rc = check_create_args(parent, distance, n_nodes, strategy, out);
+    if (rc != ST_OK) return rc;
+    BuiltTables B;
+    rc = build_tables(parent, distance, n_nodes, strategy, B);
+    if (rc != ST_OK) return rc;
+    return upload_tree(B, device, out);
+}
+
+int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n_nodes,
+                         const int *devices, int n_devices, int strategy, st_tree **out)
+{
+    int rc = check_create_args(parent, distance, n_nodes, strategy, out);
+    if (rc != ST_OK) return rc;
+    if (!devices || n_devices < 1) return fail(ST_ERR_ARG, "devices is NULL or n_devices < 1");
+    for (int i = 0; i < n_devices; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j]) return fail(ST_ERR_ARG, "device " + std::to_string(devices[i]) + " listed twice");
+    BuiltTables B;
+    rc = build_tables(parent, distance, n_nodes, strategy, B);
+    if (rc != ST_OK) return rc;
+    st_tree *primary = nullptr;
+    rc = upload_tree(B, devices[0], &primary);
+    if (rc != ST_OK) return rc;
+    for (int i = 1; i < n_devices; i++) {
+        st_tree *peer = nullptr;
+        rc = upload_tree(B, devices[i], &peer);
+        if (rc != ST_OK) {
+            std::string keep = g_last_error;
+            st_tree_destroy(primary);
+            g_last_error = keep;
+            return rc;
         }
+        primary->peers.push_back(peer);
     }
-    if (strategy == ST_STRATEGY_CANOPY && !canopy_ok)
-        return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
-
-    int n_dev = 0;
-    ST_HIP(hipGetDeviceCount(&n_dev));
-    if (device < 0 || device >= n_dev)
-        return fail(ST_ERR_HIP, "device " + std::to_string(device) + " not available (" +
-                                    std::to_string(n_dev) + " visible)");
-    ST_DEVICE(device);
-    hipDeviceProp_t prop;
-    ST_HIP(hipGetDeviceProperties(&prop, device));
-
-    st_tree *t = new (std::nothrow) st_tree();
-    if (!t) return fail(ST_ERR_NOMEM, "out of host memory");
-    t->device = device;
-    t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    t->n_nodes = T.n;
-    t->n_leaves = T.n_leaves;
-    if (deep) t->pairs_per_lane = 0;
-    int64_t bytes = 0;
-    int rc = upload(&t->d_nodes, T.nodes, &bytes);
-    if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
-    if (rc == ST_OK && canopy_ok) {
-        t->has_canopy = true;
-        t->canopy_nodes = T.canopy_nodes;
-        t->rec_bytes = T.record_bytes;
-        t->rec_cap = T.record_cap;
-        t->parity = T.parity_layout ? 1 : 0;
-        for (const CanopyEntry &e : T.canopy) t->canopy_depth = std::max<int>(t->canopy_depth, (int)(e.link >> 16));
-        if (T.canopy.size() & 1) T.canopy.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
-        rc = upload(&t->d_canopy, T.canopy, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
-    }
-    if (rc == ST_OK) {
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), sizeof(Fault));
-        if (e == hipSuccess) e = hipMemcpy(t->d_fault, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
-    }
-    if (rc != ST_OK) {
-        std::string keep = g_last_error;
-        st_tree_destroy(t);
-        g_last_error = keep;
-        return rc;
-    }
-    t->strategy = canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
-    t->info.n_nodes = T.n;
-    t->info.n_leaves = T.n_leaves;
-    t->info.root = T.root;
-    t->info.depth = T.tree_depth;
-    t->info.device = device;
-    t->info.canopy_nodes = canopy_ok ? T.canopy_nodes : 0;
-    t->info.understory_max = canopy_ok ? T.understory_max : 0;
-    t->info.record_bytes = canopy_ok ? T.record_bytes : 0;
-    t->info.device_bytes = bytes;
-    *out = t;
+    primary->info.n_devices = n_devices;
+    *out = primary;
     return ST_OK;
 }
 
 void st_tree_destroy(st_tree *t)
 {
     if (!t) return;
-    DeviceScope scope(t->device);
-    (void)hipFree(t->d_nodes);
-    (void)hipFree(t->d_depth);
-    (void)hipFree(t->d_canopy);
-    (void)hipFree(t->d_canopy_id);
-    (void)hipFree(t->d_rec_a);
-    (void)hipFree(t->d_rec_b);
-    (void)hipFree(t->d_rec_i);
-    (void)hipFree(t->d_fault);
-    t->pipe.destroy();
-    (void)hipFree(t->q_tmp);
-    if (t->mb_host) (void)hipHostFree(t->mb_host);
-    (void)hipFree(t->d_fault_mb);
-    if (t->mb_stream) (void)hipStreamDestroy(t->mb_stream);
+    for (st_tree *p : t->peers) st_tree_destroy(p);
+    t->peers.clear();
+    {
+        DeviceScope scope(t->device);
+        (void)hipFree(t->d_nodes);
+        (void)hipFree(t->d_depth);
+        (void)hipFree(t->d_canopy);
+        (void)hipFree(t->d_canopy_id);
+        (void)hipFree(t->d_rec_a);
+        (void)hipFree(t->d_rec_b);
+        (void)hipFree(t->d_rec_i);
+        (void)hipFree(t->d_fault);
+        (void)hipFree(t->q_tmp);
+        if (t->mb_host) (void)hipHostFree(t->mb_host);
+        (void)hipFree(t->d_fault_mb);
+        if (t->mb_stream) (void)hipStreamDestroy(t->mb_stream);
+    }
+    if (t->dp) pipe_release(t->device);
     delete t;
 }
 
@@ -1225,6 +1334,16 @@ int st_tree_info_get(const st_tree *t, st_tree_info *info)
     if (!t || !info) return fail(ST_ERR_ARG, "tree or info is NULL");
     *info = t->info;
     info->strategy = t->strategy;
+    return ST_OK;
+}
+
+int st_tree_devices(const st_tree *t, int *devices, int capacity, int *n_devices)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    const int n = 1 + (int)t->peers.size();
+    if (n_devices) *n_devices = n;
+    if (devices)
+        for (int i = 0; i < n && i < capacity; i++) devices[i] = i == 0 ? t->device : t->peers[(size_t)i - 1]->device;
     return ST_OK;
 }
 
@@ -1237,12 +1356,12 @@ int st_tree_set_strategy(st_tree *t, int strategy)
     if (strategy != ST_STRATEGY_CANOPY && strategy != ST_STRATEGY_WALK)
         return fail(ST_ERR_ARG, "unknown strategy " + std::to_string(strategy));
     t->strategy = strategy;
+    for (st_tree *p : t->peers) p->strategy = strategy;
     return ST_OK;
 }
 
-int st_tree_set_option(st_tree *t, const char *name, int64_t value)
+static int set_option_one(st_tree *t, const char *name, int64_t value)
 {
-    if (!t || !name) return fail(ST_ERR_ARG, "tree or name is NULL");
     if (std::strcmp(name, "pairs_per_lane") == 0) {
         if (value != 0 && value != 1 && value != 2)
             return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1 or 2");
@@ -1253,22 +1372,16 @@ int st_tree_set_option(st_tree *t, const char *name, int64_t value)
         t->small_batch_path = value != 0;
         return ST_OK;
     }
-    if (std::strcmp(name, "flow") == 0) {
-        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "flow must be 0 or 1");
-        t->flow = (int)value;
-        return ST_OK;
-    }
-    if (std::strcmp(name, "flow_batch") == 0) {
-        if (value < 1 || value > 64) return fail(ST_ERR_ARG, "flow_batch must be in [1, 64]");
-        t->flow_batch = (int)value;
-        return ST_OK;
-    }
-    if (std::strcmp(name, "lockstep") == 0) {
-        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "lockstep must be 0 or 1");
-        t->lockstep = (int)value;
-        return ST_OK;
-    }
     return fail(ST_ERR_ARG, std::string("unknown option ") + name);
+}
+
+int st_tree_set_option(st_tree *t, const char *name, int64_t value)
+{
+    if (!t || !name) return fail(ST_ERR_ARG, "tree or name is NULL");
+    int rc = set_option_one(t, name, value);
+    for (st_tree *p : t->peers)
+        if (rc == ST_OK) rc = set_option_one(p, name, value);
+    return rc;
 }
 
 int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0,
@@ -1299,7 +1412,10 @@ int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)
 {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     ST_DEVICE(t->device);
-    return read_fault(t, reinterpret_cast<hipStream_t>(stream), bad_id);
+    Fault f;
+    const int rc = fetch_fault(t->d_fault, reinterpret_cast<hipStream_t>(stream), f);
+    if (rc != ST_OK) return rc;
+    return report_fault(t->n_nodes, f, bad_id);
 }
 
 }  // extern "C"
@@ -1314,51 +1430,77 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
     if (n > 0 && !pairs) return fail(ST_ERR_ARG, "pairs is NULL");
     if (!out_dist && !out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
     if (n == 0) return ST_OK;
-    ST_DEVICE(t->device);
-    std::lock_guard<std::mutex> lock(t->ws_mutex);
-    if (n <= kMailboxPairs && t->small_batch_path)
+    if (n <= kMailboxPairs && t->small_batch_path) {
+        ST_DEVICE(t->device);
         return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
+    }
+    // fresh result arrays: ask for huge pages before the first touch (a no-op on resident memory)
+    if (out_dist) advise_huge(out_dist, n * 8);
+    if (out_mrca) advise_huge(out_mrca, n * 4);
 
     // Ids cross PCIe as int32 (half the H2D bytes).  Values that do not fit are clamped to
     // INT32_MAX / INT32_MIN -- still out of range for the kernel -- and their exact extremes
     // are kept here so that the reported id is the one the reference would report.
-    CopyPool &pool = t->pipe.pool;
-    std::mutex wide_mutex;
-    long long wide_max = std::numeric_limits<long long>::min();
-    long long wide_min = std::numeric_limits<long long>::max();
-    auto pack = [&](PipeSlot &s, int64_t off, int64_t m) {
-        const Id *src = pairs + off * stride0;
-        int32_t *dst = static_cast<int32_t *>(s.h_in);
-        if (sizeof(Id) == 4 && stride0 == 2 && stride1 == 1) {   // int32 C-order: already the wire format
-            pool.copy(dst, src, m * 8);
-            return;
-        }
-        pool.parallel_for(m, [&, src, dst](int64_t b, int64_t e) {
-            long long hi = std::numeric_limits<long long>::min(), lo = std::numeric_limits<long long>::max();
-            for (int64_t k = b; k < e; k++) {
-                for (int c = 0; c < 2; c++) {
-                    const long long v = src[k * stride0 + c * stride1];
-                    int32_t w = (int32_t)v;
-                    if (v > INT32_MAX) { w = INT32_MAX; hi = std::max(hi, v); }
-                    else if (v < INT32_MIN) { w = INT32_MIN; lo = std::min(lo, v); }
-                    dst[2 * k + c] = w;
+    auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
+        CopyPool &pool = r->dp->pipe.pool;
+        hipStream_t s0 = nullptr;
+        std::mutex wide_mutex;
+        Fault wide = kFaultInit;
+        auto pack = [&](PipeSlot &s, int64_t off, int64_t m) {
+            const Id *src = pairs + off * stride0;
+            int32_t *dst = static_cast<int32_t *>(s.h_in);
+            const bool c_order = stride0 == 2 && stride1 == 1;
+            if (sizeof(Id) == 4 && c_order) {   // int32 C-order: already the wire format
+                pool.parallel_for(m, [=](int64_t b, int64_t e) { copy_stream(dst + 2 * b, src + 2 * b, (e - b) * 8); });
+                return;
+            }
+            pool.parallel_for(m, [&, src, dst](int64_t b, int64_t e) {
+                long long hi = kFaultInit.max_bad, lo = kFaultInit.min_bad;
+                if (sizeof(Id) == 8 && c_order) {
+                    narrow_pairs_i64(dst + 2 * b, reinterpret_cast<const int64_t *>(src) + 2 * b, e - b, hi, lo);
+                } else {
+                    for (int64_t k = b; k < e; k++) {
+                        for (int c = 0; c < 2; c++) {
+                            const long long v = src[k * stride0 + c * stride1];
+                            int32_t w = (int32_t)v;
+                            if (v > INT32_MAX) { w = INT32_MAX; hi = std::max(hi, v); }
+                            else if (v < INT32_MIN) { w = INT32_MIN; lo = std::min(lo, v); }
+                            dst[2 * k + c] = w;
+                        }
+                    }
                 }
-            }
-            if (hi != std::numeric_limits<long long>::min() || lo != std::numeric_limits<long long>::max()) {
-                std::lock_guard<std::mutex> g(wide_mutex);
-                wide_max = std::max(wide_max, hi);
-                wide_min = std::min(wide_min, lo);
-            }
-        });
+                if (hi != kFaultInit.max_bad || lo != kFaultInit.min_bad) {
+                    std::lock_guard<std::mutex> g(wide_mutex);
+                    wide.max_bad = std::max(wide.max_bad, hi);
+                    wide.min_bad = std::min(wide.min_bad, lo);
+                }
+            });
+        };
+        auto launch = [&](PipeSlot &s, int64_t, int64_t m) {
+            return enqueue_src(r, SrcContig32{static_cast<const int *>(s.h_in)}, m,
+                               DistSink{nullptr, out_dist ? static_cast<float *>(s.h_d) : nullptr},
+                               out_mrca ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+        };
+        {   // (the pipe may not exist yet: ensure() inside run_pipe creates the streams)
+            const hipError_t e = r->dp->pipe.ensure(std::max<int64_t>(seq.chunk, 1024));
+            if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
+            s0 = r->dp->pipe.slot[0].stream;
+        }
+        // a fresh word for this call (an earlier call that failed half-way may have left it set)
+        ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
+        ST_HIP(hipStreamSynchronize(s0));
+        int rc = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
+        if (rc != ST_OK) return rc;
+        rc = fetch_fault(r->d_fault_host, s0, fault);
+        if (rc != ST_OK) return rc;
+        // a clamped id always trips the device check as well; its exact value replaces the clamp
+        if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) merge_fault(fault, wide);
+        return ST_OK;
     };
-    auto launch = [&](PipeSlot &s, int64_t, int64_t m) {
-        return enqueue_src(t, SrcContig32{static_cast<const int *>(s.d_in)}, m,
-                           DistSink{nullptr, out_dist ? static_cast<float *>(s.d_d) : nullptr},
-                           out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
-    };
-    const int rc = run_pipe(t, n, 8, pack, launch, out_dist, out_mrca);
+    Fault fault;
+    const int rc = for_each_replica(t, n, fault, work);
     if (rc != ST_OK) return rc;
-    return read_fault(t, t->pipe.slot[0].stream, bad_id, wide_max, wide_min);
+    return report_fault(t->n_nodes, fault, bad_id);
 }
 
 extern "C" {
@@ -1396,7 +1538,7 @@ int st_triangle_device(st_tree *t, const int64_t *d_ids, int64_t m, int64_t id_s
     if (rc != ST_OK) return rc;
     ST_DEVICE(t->device);
     const SrcTriangle src{reinterpret_cast<const long long *>(d_ids), (long long)id_stride, (long long)k_begin};
-    return enqueue_src(t, src, k_count, DistSink{d_out_dist, nullptr}, d_out_mrca,
+    return enqueue_src(t, src, k_count, DistSink{d_out_dist, nullptr}, d_out_mrca, t->d_fault,
                        reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1406,14 +1548,9 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
-    ST_DEVICE(t->device);
-    std::lock_guard<std::mutex> lock(t->ws_mutex);
-    {
-        hipError_t e = t->pipe.ensure(std::max<int64_t>(std::min<int64_t>(k_count, kHostChunk), 1024));
-        if (e == hipSuccess) e = t->pipe.ensure_ids(m);
-        if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
-    }
-    // the id list goes up once (packed); results stream back through the pipe
+    if (out_dist) advise_huge(out_dist, k_count * 8);
+    if (out_mrca) advise_huge(out_mrca, k_count * 4);
+    // the id list goes up once per device (packed); results stream back through the pipe
     std::vector<int64_t> packed;
     const int64_t *src_ids = ids;
     if (id_stride != 1) {
@@ -1421,16 +1558,133 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
         for (int64_t i = 0; i < m; i++) packed[(size_t)i] = ids[i * id_stride];
         src_ids = packed.data();
     }
-    ST_HIP(hipMemcpy(t->pipe.d_ids, src_ids, (size_t)m * 8, hipMemcpyHostToDevice));
-    auto pack = [](PipeSlot &, int64_t, int64_t) {};
-    auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
-        const SrcTriangle src{static_cast<const long long *>(t->pipe.d_ids), 1, (long long)(k_begin + off)};
-        return enqueue_src(t, src, c, DistSink{nullptr, out_dist ? static_cast<float *>(s.d_d) : nullptr},
-                           out_mrca ? static_cast<int32_t *>(s.d_m) : nullptr, s.stream);
+    auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
+        HostPipe &P = r->dp->pipe;
+        hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
+        if (e == hipSuccess) e = P.ensure_ids(m);
+        if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
+        hipStream_t s0 = P.slot[0].stream;
+        ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
+        ST_HIP(hipStreamSynchronize(s0));
+        ST_HIP(hipMemcpy(P.d_ids, src_ids, (size_t)m * 8, hipMemcpyHostToDevice));
+        auto pack = [](PipeSlot &, int64_t, int64_t) {};
+        auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
+            const SrcTriangle src{static_cast<const long long *>(P.d_ids), 1, (long long)(k_begin + off)};
+            return enqueue_src(r, src, c, DistSink{nullptr, out_dist ? static_cast<float *>(s.h_d) : nullptr},
+                               out_mrca ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+        };
+        const int rc2 = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
+        if (rc2 != ST_OK) return rc2;
+        return fetch_fault(r->d_fault_host, s0, fault);
     };
-    rc = run_pipe(t, k_count, 0, pack, launch, out_dist, out_mrca);
+    Fault fault;
+    rc = for_each_replica(t, k_count, fault, work);
     if (rc != ST_OK) return rc;
-    return read_fault(t, t->pipe.slot[0].stream, bad_id);
+    return report_fault(t->n_nodes, fault, bad_id);
+}
+
+static int grid_args(st_tree *t, const int64_t *rows, int64_t n_rows, const int64_t *cols, int64_t n_cols,
+                     int64_t e_begin, int64_t e_count, const void *out_d, const void *out_m)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n_rows < 0 || n_cols < 0 || e_begin < 0 || e_count < 0) return fail(ST_ERR_ARG, "negative size");
+    if (n_rows > 3000000000LL || n_cols > 3000000000LL) return fail(ST_ERR_ARG, "grid too large");
+    if (e_begin + e_count > n_rows * n_cols) return fail(ST_ERR_ARG, "element range exceeds n_rows * n_cols");
+    if (e_count > 0 && (!rows || !cols)) return fail(ST_ERR_ARG, "id list is NULL");
+    if (!out_d && !out_m) return fail(ST_ERR_ARG, "both outputs are NULL");
+    return ST_OK;
+}
+
+int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64_t *col_ids, int64_t n_cols,
+                 int symmetric, int64_t e_begin, int64_t e_count, double *out_dist, int32_t *out_mrca,
+                 int64_t *bad_id)
+{
+    int rc = grid_args(t, row_ids, n_rows, col_ids, n_cols, e_begin, e_count, out_dist, out_mrca);
+    if (rc != ST_OK) return rc;
+    if (symmetric && (n_rows != n_cols)) return fail(ST_ERR_ARG, "symmetric grid needs n_rows == n_cols");
+    if (e_count == 0) return ST_OK;
+    if (out_dist) advise_huge(out_dist, e_count * 8);
+    if (out_mrca) advise_huge(out_mrca, e_count * 4);
+    auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
+        HostPipe &P = r->dp->pipe;
+        hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
+        if (e == hipSuccess) e = P.ensure_ids(n_rows + n_cols);
+        if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
+        hipStream_t s0 = P.slot[0].stream;
+        ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
+        ST_HIP(hipStreamSynchronize(s0));
+        long long *d_rows = static_cast<long long *>(P.d_ids), *d_cols = d_rows + n_rows;
+        ST_HIP(hipMemcpy(d_rows, row_ids, (size_t)n_rows * 8, hipMemcpyHostToDevice));
+        ST_HIP(hipMemcpy(d_cols, col_ids, (size_t)n_cols * 8, hipMemcpyHostToDevice));
+        auto pack = [](PipeSlot &, int64_t, int64_t) {};
+        auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
+            const SrcGrid src{d_rows, d_cols, (long long)n_cols, (long long)(e_begin + off), symmetric};
+            return enqueue_src(r, src, c, DistSink{nullptr, out_dist ? static_cast<float *>(s.h_d) : nullptr},
+                               out_mrca ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+        };
+        const int rc2 = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
+        if (rc2 != ST_OK) return rc2;
+        return fetch_fault(r->d_fault_host, s0, fault);
+    };
+    Fault fault;
+    rc = for_each_replica(t, e_count, fault, work);
+    if (rc != ST_OK) return rc;
+    return report_fault(t->n_nodes, fault, bad_id);
+}
+
+int st_knn_host(st_tree *t, const int64_t *queries, int64_t n_queries, const int64_t *cands, int64_t n_cands,
+                int k, int skip_self, int64_t *out_index, double *out_dist, int64_t *bad_id)
+{
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n_queries < 0 || n_cands < 0) return fail(ST_ERR_ARG, "negative size");
+    if (k < 1 || k > kKnnMaxK) return fail(ST_ERR_ARG, "k must be in [1, " + std::to_string(kKnnMaxK) + "]");
+    if (n_cands > 0xFFFFFFFFLL) return fail(ST_ERR_ARG, "too many candidates");
+    if (n_queries > 0 && (!queries || !out_index || !out_dist)) return fail(ST_ERR_ARG, "queries or output is NULL");
+    if (n_cands > 0 && !cands) return fail(ST_ERR_ARG, "cands is NULL");
+    if (n_queries == 0) return ST_OK;
+    if (n_cands == 0) {
+        for (int64_t i = 0; i < n_queries * k; i++) { out_index[i] = -1; out_dist[i] = std::numeric_limits<double>::quiet_NaN(); }
+        return ST_OK;
+    }
+    ST_DEVICE(t->device);
+    std::lock_guard<std::mutex> lock(t->dp->m);
+    // rows per launch: the distance block (float32, device only) stays under 256 MiB
+    const int64_t rows_per_block = std::max<int64_t>(1, std::min<int64_t>(n_queries, ((int64_t)1 << 26) / n_cands));
+    long long *d_q = nullptr, *d_c = nullptr, *d_oi = nullptr;
+    float *d_tmp = nullptr;
+    double *d_od = nullptr;
+    hipStream_t stream = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_q); (void)hipFree(d_c); (void)hipFree(d_oi); (void)hipFree(d_tmp); (void)hipFree(d_od);
+        if (stream) (void)hipStreamDestroy(stream);
+    };
+    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_q), (size_t)n_queries * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_c), (size_t)n_cands * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_tmp), (size_t)rows_per_block * (size_t)n_cands * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_oi), (size_t)n_queries * k * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_od), (size_t)n_queries * k * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)n_queries * 8, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, cands, (size_t)n_cands * 8, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { cleanup(); return fail(ST_ERR_HIP, std::string("knn setup: ") + hipGetErrorString(e)); }
+    for (int64_t r0 = 0; r0 < n_queries; r0 += rows_per_block) {
+        const int64_t rows = std::min(rows_per_block, n_queries - r0);
+        const SrcGrid src{d_q + r0, d_c, (long long)n_cands, 0, 0};
+        const int rc = enqueue_src(t, src, rows * n_cands, DistSink{nullptr, d_tmp}, nullptr, t->d_fault_host, stream);
+        if (rc != ST_OK) { (void)hipStreamSynchronize(stream); cleanup(); return rc; }
+        hipLaunchKernelGGL(k_knn_select, dim3((unsigned)rows), dim3(256), 0, stream, d_tmp, (long long)n_cands,
+                           d_q + r0, d_c, skip_self, k, d_oi + r0 * k, d_od + r0 * k);
+        e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipStreamSynchronize(stream); cleanup(); return fail(ST_ERR_HIP, std::string("knn launch: ") + hipGetErrorString(e)); }
+    }
+    e = hipMemcpyAsync(out_index, d_oi, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_dist, d_od, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost, stream);
+    Fault f = kFaultInit;
+    int rc = e == hipSuccess ? fetch_fault(t->d_fault_host, stream, f) : fail(ST_ERR_HIP, std::string("knn D2H: ") + hipGetErrorString(e));
+    cleanup();
+    if (rc != ST_OK) return rc;
+    return report_fault(t->n_nodes, f, bad_id);
 }
 
 int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t stride0, int64_t stride1,
@@ -1441,15 +1695,18 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     if (n > 0 && (!quartets || !out_topologies)) return fail(ST_ERR_ARG, "quartets or output is NULL");
     if (n == 0) return ST_OK;
     ST_DEVICE(t->device);
-    std::lock_guard<std::mutex> lock(t->ws_mutex);
+    std::lock_guard<std::mutex> lock(t->dp->m);
+    HostPipe &pipe = t->dp->pipe;
     // (n,4) int64 in and out are each the size of two pair rows: reuse the pipe's slots,
-    // input in d_in/h_in of slot 0 and 1 back to back is not possible, so stage by halves:
+    // input through slot 0, output through slot 1
     const int64_t chunk = std::min<int64_t>(n, kHostChunk / 2);
     {
-        const hipError_t e = t->pipe.ensure(std::max<int64_t>(2 * chunk, 1024));
+        hipError_t e = pipe.ensure(std::max<int64_t>(2 * chunk, 1024));
+        if (e == hipSuccess) e = pipe.ensure_device_in();
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
     }
-    PipeSlot &in = t->pipe.slot[0], &out = t->pipe.slot[1];
+    PipeSlot &in = pipe.slot[0], &out = pipe.slot[1];
+    ST_HIP(hipMemcpyAsync(t->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, in.stream));
     WalkParams P;
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
@@ -1458,7 +1715,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         const int64_t m = std::min(chunk, n - off);
         int64_t *h = static_cast<int64_t *>(in.h_in);
         const int64_t *src = quartets + off * stride0;
-        t->pipe.pool.parallel_for(m, [=](int64_t b, int64_t e) {
+        pipe.pool.parallel_for(m, [=](int64_t b, int64_t e) {
             for (int64_t k = b; k < e; k++)
                 for (int c = 0; c < 4; c++) h[4 * k + c] = src[k * stride0 + c * stride1];
         });
@@ -1474,22 +1731,25 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
                 t->q_tmp_cap = chunk;
             }
             const int rc = enqueue_src(t, SrcQuartet{static_cast<const long long *>(in.d_in)}, 6 * m,
-                                       DistSink{nullptr, nullptr}, static_cast<int32_t *>(t->q_tmp), in.stream);
+                                       DistSink{nullptr, nullptr}, static_cast<int32_t *>(t->q_tmp),
+                                       t->d_fault_host, in.stream);
             if (rc != ST_OK) return rc;
             hipLaunchKernelGGL(k_quartet_pick, dim3((unsigned)blocks), dim3(256), 0, in.stream,
                                static_cast<const long long *>(in.d_in), static_cast<const int *>(t->q_tmp),
-                               (long long)m, static_cast<long long *>(out.d_in));
+                               (long long)m, static_cast<long long *>(out.h_in));
         } else {
             hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, in.stream, P,
                                static_cast<const long long *>(in.d_in), (long long)m, 4LL, 1LL,
-                               static_cast<long long *>(out.d_in), t->d_fault);
+                               static_cast<long long *>(out.h_in), t->d_fault_host);
         }
         ST_HIP(hipGetLastError());
-        ST_HIP(hipMemcpyAsync(out.h_in, out.d_in, (size_t)m * 32, hipMemcpyDeviceToHost, in.stream));
-        ST_HIP(hipStreamSynchronize(in.stream));
-        t->pipe.pool.copy(out_topologies + off * 4, out.h_in, m * 32);
+        ST_HIP(hipStreamSynchronize(in.stream));    // topologies were written straight into pinned out.h_in
+        pipe.pool.copy(out_topologies + off * 4, out.h_in, m * 32);
     }
-    return read_fault(t, in.stream, bad_id);
+    Fault f;
+    const int rc = fetch_fault(t->d_fault_host, in.stream, f);
+    if (rc != ST_OK) return rc;
+    return report_fault(t->n_nodes, f, bad_id);
 }
 
 int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t *u, const int32_t *v,

@@ -41,7 +41,7 @@ _TOKEN = re.compile(
         (?P<comment>\[[^\]]*\])
       | (?P<quoted>'(?:[^']|'')*')
       | (?P<punct>[(),:;])
-      | (?P<word>[^\s()\[\],:;']+)
+      | (?P<word>[^\s()\[\],:;'][^\s()\[\],:;]*)
     )""",
     re.X,
 )

@@ -8,6 +8,7 @@ arithmetic happens in libsuchtree_hip.so on the GPU; nothing here computes a
 distance or an MRCA on the CPU, and a missing library or GPU raises
 ``HipBackendError``.
 """
+import os
 from itertools import chain
 from numbers import Integral
 from typing import Dict, List, Tuple, Union
@@ -40,10 +41,13 @@ class SuchTree:
     tuple of flat arrays in the reference's in-order numbering.
 
     ``device``: HIP device index the tree is uploaded to (on first use).
+    ``devices``: list of HIP device indices instead: the tree is replicated on all of them and
+    the bulk methods taking host arrays (``distances_bulk``, ``pairwise_distances``, ...) deal
+    their work over every listed GPU from this one process.
     ``strategy``: ``'auto'`` | ``'canopy'`` | ``'walk'`` kernel family.
     """
 
-    def __init__(self, tree_input, device: int = 0, strategy: str = "auto"):
+    def __init__(self, tree_input, device: int = 0, strategy: str = "auto", devices=None):
         self._epsilon = EPSILON
         if isinstance(tree_input, FlatTree):
             flat = tree_input
@@ -66,7 +70,10 @@ class SuchTree:
         else:
             raise TypeError("tree_input must be a str, FlatTree or (parent, distance) tuple")
         self._flat = flat
-        self._device = int(device)
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and not self._devices:
+            raise ValueError("devices must not be empty")
+        self._device = int(device) if self._devices is None else self._devices[0]
         if strategy not in _capi.STRATEGY:
             raise ValueError("strategy must be one of %s" % sorted(_capi.STRATEGY))
         self._strategy = strategy
@@ -75,9 +82,15 @@ class SuchTree:
     # ------------------------------------------------------------------ device
     def _device_tree(self) -> "_capi.DeviceTree":
         """Upload on first use; raises HipBackendError without a usable GPU."""
+        if self._dev_tree is not None and self._dev_tree._pid != os.getpid():
+            # inherited through fork: the handle belongs to the parent's GPU context.  Drop it
+            # (without destroying it); the upload below raises the explanatory HipBackendError
+            # if the parent had initialised the GPU, which a resident tree implies.
+            self._dev_tree = None
         if self._dev_tree is None:
             self._dev_tree = _capi.DeviceTree(self._flat.parent, self._flat.distance,
-                                              device=self._device, strategy=self._strategy)
+                                              device=self._device, strategy=self._strategy,
+                                              devices=self._devices)
         return self._dev_tree
 
     def to_device(self) -> "SuchTree":
@@ -95,8 +108,11 @@ class SuchTree:
             self._dev_tree.close()
             self._dev_tree = None
 
-    # trees travel between processes as their flat arrays; every process uploads its own copy
-    # (the reference's users parallelise with fork pools, docs/examples/SuchTree_examples.md:462-497)
+    # trees travel between processes (spawn / pickle) as their flat arrays; every process uploads
+    # its own copy.  The reference's users parallelise with fork pools
+    # (docs/examples/SuchTree_examples.md:462-497): that works here as long as the pool forks
+    # before the parent's first GPU query (uploads are lazy); a child forked later gets a
+    # HipBackendError saying so instead of a hang (see _capi._check_fork).
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_dev_tree"] = None
@@ -343,19 +359,19 @@ class SuchTree:
     def pairwise_distances(self, nodes: List[Union[int, str]] = None) -> np.ndarray:
         """Symmetric matrix of all pairwise distances (MuchTree.pyx:1084-1124).
 
-        The reference materialises the n(n-1)/2 pairs as a Python list and calls
-        ``distances_bulk``; here the pairs are generated on the device
-        (``st_triangle_host``).  Entry [i, j] with i < j is d(ids[i], ids[j]) in that
-        argument order, exactly as the reference computes it, mirrored to [j, i].
+        The reference materialises the n(n-1)/2 pairs as a Python list, calls
+        ``distances_bulk`` and scatters the result into the matrix in a Python loop.  Here the
+        whole (n, n) matrix is generated on the device (``st_grid_host``, symmetric grid) and
+        streamed straight into the result array: entry [i, j] with i < j is d(ids[i], ids[j])
+        in that argument order, exactly as the reference computes it, entry [j, i] is the same
+        value, the diagonal is d(x, x) = 0.
         """
         node_ids = self._node_ids(nodes)
         n = len(node_ids)
         distance_matrix = np.zeros((n, n), dtype=float)
         if n > 1:
-            tri, _ = self._device_tree().triangle_host(np.asarray(node_ids, dtype=np.int64))
-            rows, cols = np.tril_indices(n, -1)       # k = i(i-1)/2 + j order
-            distance_matrix[rows, cols] = tri
-            distance_matrix[cols, rows] = tri
+            ids = np.asarray(node_ids, dtype=np.int64)
+            self._device_tree().grid_host(ids, ids, symmetric=True, out_dist=distance_matrix.reshape(-1))
         return distance_matrix
 
     def distance_matrix(self, nodes: list = None) -> dict:
@@ -383,10 +399,38 @@ class SuchTree:
         else:
             from_node_ids = [self._validate_node(n) for n in from_nodes]
             from_nodes_orig = from_nodes.copy()
-        pairs = [(query_node_id, nid) for nid in from_node_ids]
-        distances = self.distances_bulk(np.array(pairs, dtype=np.int64))
-        sorted_indices = np.argsort(distances)
+        if len(from_node_ids) == 0:
+            return []
+        cands = np.asarray(from_node_ids, dtype=np.int64)
+        dev = self._device_tree()
+        if k <= dev.KNN_MAX_K:
+            # distances and the selection of the k smallest both happen on the GPU (st_knn_host);
+            # ties go to the candidate listed first (the reference's argsort leaves them unspecified)
+            idx, dist = dev.knn_host(np.array([query_node_id], dtype=np.int64), cands, k)
+            return [(from_nodes_orig[int(i)], d) for i, d in zip(idx[0], dist[0]) if i >= 0]
+        distances, _ = dev.grid_host(np.array([query_node_id], dtype=np.int64), cands)
+        sorted_indices = np.argsort(distances, kind="stable")
         return [(from_nodes_orig[i], distances[i]) for i in sorted_indices[:k]]
+
+    def nearest_neighbors_bulk(self, nodes, k: int = 1, from_nodes: list = None):
+        """``nearest_neighbors`` for many query nodes in one call (no reference counterpart):
+        returns ``(neighbor_ids int64 (q, k), distances float64 (q, k))``, neighbours ascending
+        by distance, -1 / NaN where a query has fewer than k candidates.  With the default
+        candidate set (all leaves) a leaf query is not its own neighbour, as in
+        ``nearest_neighbors`` (MuchTree.pyx:1058-1062)."""
+        if k <= 0:
+            raise ValueError("k must be positive")
+        queries = np.array([self._validate_node(n) for n in nodes], dtype=np.int64)
+        if from_nodes is None:
+            cands, skip_self = np.asarray(self.leaf_node_ids, dtype=np.int64), True
+        else:
+            cands, skip_self = np.array([self._validate_node(n) for n in from_nodes], dtype=np.int64), False
+        dev = self._device_tree()
+        if k > dev.KNN_MAX_K:
+            raise ValueError("k must be at most %d" % dev.KNN_MAX_K)
+        idx, dist = dev.knn_host(queries, cands, k, skip_self=skip_self)
+        ids = np.where(idx >= 0, cands[np.maximum(idx, 0)], -1) if len(cands) else idx
+        return ids, dist
 
     # --------------------------------------------------- quartet topologies (MRCA caller)
     def quartet_topologies_bulk(self, quartets) -> np.ndarray:

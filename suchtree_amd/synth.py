@@ -39,6 +39,40 @@ def balanced_tree(levels, seed=42, low=0.01, high=1.0, decimals=6):
     return parent.astype(np.int32), lengths.astype(np.float32)
 
 
+def complete_tree(n_leaves, seed=44, low=0.01, high=1.0, decimals=6):
+    """Complete binary tree with ``n_leaves`` leaves (BASELINE config 4: 100,000 leaves, seed
+    44): heap shape -- node k has children 2k and 2k+1, every level full except the last,
+    which is filled from the left -- numbered in order like every tree of the reference.
+    Branch lengths as in :func:`balanced_tree`.  Returns ``(parent:int32[N], distance:float32[N])``,
+    N = 2*n_leaves - 1."""
+    if n_leaves < 1:
+        raise ValueError("n_leaves must be >= 1")
+    n = 2 * n_leaves - 1
+    heap = np.arange(n + 1, dtype=np.int64)           # heap positions 1..n (0 unused)
+    size = np.zeros(2 * n + 2, dtype=np.int64)        # subtree sizes, zero beyond the heap
+    size[1:n + 1] = 1
+    level_lo = 1 << (int(n).bit_length() - 1)
+    while level_lo >= 1:                              # bottom-up, one level at a time
+        k = heap[level_lo:min(2 * level_lo, n + 1)]
+        size[k] = 1 + size[2 * k] + size[2 * k + 1]
+        level_lo >>= 1
+    start = np.zeros(n + 1, dtype=np.int64)           # first in-order id of each subtree
+    level_lo = 1
+    while level_lo <= n:                              # top-down
+        k = heap[level_lo:min(2 * level_lo, n + 1)]
+        k = k[2 * k + 1 <= n]                         # internal nodes have both children
+        start[2 * k] = start[k]
+        start[2 * k + 1] = start[k] + size[2 * k] + 1
+        level_lo <<= 1
+    ids = start[1:] + size[2 * heap[1:]]              # in-order id of heap node k (k = 1..n)
+    parent = np.full(n, -1, dtype=np.int64)
+    parent[ids[1:]] = ids[(heap[2:] >> 1) - 1]
+    rng = np.random.default_rng(seed)
+    lengths = np.round(rng.uniform(low, high, size=n), decimals)
+    lengths[ids[0]] = -1.0
+    return parent.astype(np.int32), lengths.astype(np.float32)
+
+
 def caterpillar_tree(n_leaves, seed=7):
     """Maximally unbalanced (ladder) tree: the worst case for depth.
 

@@ -22,6 +22,17 @@ def _check_pairs(pairs):
         raise ValueError("negative strides are not supported")
 
 
+def _check_out(buf, n, dtypes, device_index, name):
+    """A caller-supplied result tensor is written through its raw pointer: refuse anything that
+    is not exactly an (n,) contiguous tensor of the right dtype on the tree's GPU."""
+    import torch
+    if not isinstance(buf, torch.Tensor) or not buf.is_cuda or buf.device.index != device_index:
+        raise ValueError("%s must be a tensor on cuda:%d" % (name, device_index))
+    if buf.dtype not in dtypes or buf.dim() != 1 or buf.shape[0] != n or not buf.is_contiguous():
+        raise ValueError("%s must be a contiguous (%d,) tensor of dtype %s"
+                         % (name, n, " or ".join(str(d) for d in dtypes)))
+
+
 def distances_device(tree: SuchTree, pairs, want_dist: bool = True, want_mrca: bool = True,
                      out_dist=None, out_mrca=None, check: bool = True,
                      dist_dtype=None) -> Tuple[Optional[object], Optional[object]]:
@@ -42,8 +53,12 @@ def distances_device(tree: SuchTree, pairs, want_dist: bool = True, want_mrca: b
     n = int(pairs.shape[0])
     if want_dist and out_dist is None:
         out_dist = torch.empty(n, dtype=dist_dtype, device=pairs.device)
+    elif want_dist:
+        _check_out(out_dist, n, (torch.float64, torch.float32), dev.device, "out_dist")
     if want_mrca and out_mrca is None:
         out_mrca = torch.empty(n, dtype=torch.int32, device=pairs.device)
+    elif want_mrca:
+        _check_out(out_mrca, n, (torch.int32,), dev.device, "out_mrca")
     stream = torch.cuda.current_stream(pairs.device).cuda_stream
     if n:
         dev.distances_device(pairs.data_ptr(), n, out_dist.data_ptr() if want_dist else 0,
@@ -61,7 +76,11 @@ def triangle_device(tree: SuchTree, ids, k_begin: int = 0, k_count: Optional[int
     import torch
     if not isinstance(ids, torch.Tensor) or not ids.is_cuda or ids.dtype != torch.int64 or ids.dim() != 1:
         raise TypeError("ids must be a 1-D int64 CUDA/HIP torch tensor")
+    if ids.stride(0) < 0:
+        raise ValueError("negative strides are not supported")
     dev = tree._device_tree()
+    if ids.device.index != dev.device:
+        raise ValueError("ids live on cuda:%d but the tree is on device %d" % (ids.device.index, dev.device))
     m = int(ids.shape[0])
     total = m * (m - 1) // 2
     if k_count is None:

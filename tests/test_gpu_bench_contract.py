@@ -22,7 +22,7 @@ def test_bench_line_contract():
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["unit"] == "pairs/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["unit"] == "pairs/s" and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -32,3 +32,21 @@ def test_bench_line_contract():
     assert d["parity"]["distances_bit_exact"] and d["parity"]["mrca_bit_exact"]
     assert d["end_to_end_host_path"]["matches_device_results"]
     assert d["value"] > 1e9
+    assert r["required_bytes_per_pair"] == 156 and 0 < r["required_frac"] < 1
+    assert d["hardware_measured"]["table"]["Greads_per_s"] > 1 and d["hardware_measured"]["stream_copy_GBps"] > 100
+    e = d["end_to_end_host_path"]
+    assert e["pairs_per_s"] > 1e8 and e["pairs_per_s_fresh_arrays"] > 1e8
+
+
+def test_bench_under_torchrun_one_rank():
+    """The N > 1 code path (process group, sharded step, barriers) with world size 1 -- all a
+    1-GPU box can run of it; the slicing / gather itself is covered by the gloo tests."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "2000000", "--no-cpu-baseline",
+                          "--no-host-path", "--no-microbench"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 1e8

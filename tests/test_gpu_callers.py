@@ -9,7 +9,7 @@ import pytest
 from scipy.stats import pearsonr
 
 from conftest import assert_bits_equal, golden_path
-from oracle.oracle import OracleTree, linked_pairs
+from oracle.oracle import OracleTree, linked_adjacency, linked_laplacian, linked_pairs
 from suchtree_amd import InvalidNodeError, SuchTree, _capi, sharding, synth
 from suchtree_amd.linked import SuchLinkedTrees
 
@@ -31,14 +31,9 @@ def test_triangle_generator_equals_explicit_pairs(strategy, ml_arrays):
     ids = np.random.default_rng(4).choice(leaf_ids, size=700, replace=False)
     pairs = _tri_pairs(ids)
     want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
-    for flow, ppl in ((1, 2), (0, 0), (0, 1), (0, 2)):
-        dev.set_option("flow", flow)
-        dev.set_option("pairs_per_lane", ppl)
-        d, m = dev.triangle_host(ids, want_dist=True, want_mrca=True)
-        assert_bits_equal(d, want_d, "flow%d ppl%d" % (flow, ppl))
-        assert np.array_equal(m, want_m)
-    dev.set_option("flow", 0)
-    dev.set_option("pairs_per_lane", 1)
+    d, m = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+    assert_bits_equal(d, want_d)
+    assert np.array_equal(m, want_m)
     # any k-range gives the matching slice (what multi-GPU sharding and tiling rely on)
     total = len(pairs)
     for g in range(3):
@@ -62,7 +57,7 @@ def test_config4_all_pairs_reduced_size():
     """Config 4 is the full lower triangle of a 100k-leaf tree (5e9 pairs); here a
     6000-leaf slice of that workload (1.8e7 pairs) against the oracle on a sample, plus
     size-independent properties on the whole triangle."""
-    parent, dist = synth.random_binary_tree(100_000, seed=44)
+    parent, dist = synth.complete_tree(100_000, seed=44)
     dev = _capi.DeviceTree(parent, dist)
     O = OracleTree(parent, dist)
     ids = np.arange(0, 12_000, 2, dtype=np.int64) + 40_000          # 6000 consecutive leaves
@@ -108,6 +103,61 @@ def test_pairwise_distance_matrix_and_neighbors():
         T.nearest_neighbors("Ttal", k=0)
 
 
+def test_grid_generator_pairwise_matrix_and_knn_on_a_real_tree(ml_arrays):
+    """f2 on the device: the symmetric matrix written by the grid generator (no pair list, no
+    host scatter) and the per-row top-k, against the oracle on data/bigtrees/ml.tree."""
+    parent, dist, leaf_ids = ml_arrays
+    T = SuchTree((parent, dist))
+    O = OracleTree(parent, dist)
+    rng = np.random.default_rng(31)
+    ids = rng.choice(leaf_ids, size=1500, replace=False)
+    ids[7] = int(parent[ids[8]])                      # an internal node among them
+    D = T.pairwise_distances([int(x) for x in ids])
+    n = len(ids)
+    assert D.shape == (n, n) and np.array_equal(D, D.T) and np.all(np.diag(D) == 0)
+    iu, ju = np.triu_indices(n, 1)                    # the reference's pairs: (ids[i], ids[j]), i < j
+    assert_bits_equal(D[iu, ju], O.distances(np.stack([ids[iu], ids[ju]], 1)))
+    # rectangular grid, an element sub-range, MRCA ids
+    dev = T._device_tree()
+    rows, cols = ids[:37], ids[100:1100]
+    full_d, full_m = dev.grid_host(rows, cols, want_dist=True, want_mrca=True)
+    rr, cc = np.divmod(np.arange(len(rows) * len(cols)), len(cols))
+    rect_pairs = np.stack([rows[rr], cols[cc]], 1)
+    assert_bits_equal(full_d, O.distances(rect_pairs))
+    assert np.array_equal(full_m, O.mrca_bulk(rect_pairs))
+    part_d, _ = dev.grid_host(rows, cols, e_begin=12_345, e_count=5000)
+    assert_bits_equal(part_d, full_d[12_345:17_345])
+    for strategy in ("walk", "canopy"):
+        dev.set_strategy(strategy)
+        d2, _ = dev.grid_host(ids[:300], ids[:300], symmetric=True)
+        assert_bits_equal(d2, D[:300, :300].reshape(-1), strategy)
+    dev.set_strategy("auto")
+    with pytest.raises(ValueError):
+        dev.grid_host(rows, cols, symmetric=True)
+    with pytest.raises(InvalidNodeError):
+        dev.grid_host(np.array([0, len(parent)]), ids[:5000])
+    # k nearest leaves of many queries; selection on the GPU
+    queries = ids[:64]
+    k = 9
+    nb_ids, nb_d = T.nearest_neighbors_bulk([int(q) for q in queries], k=k)
+    leaves = np.asarray(T.leaf_node_ids, dtype=np.int64)
+    for qi, q in enumerate(queries[:16]):
+        cand = leaves[leaves != q]
+        row = O.distances(np.stack([np.full(len(cand), q), cand], 1))
+        assert_bits_equal(nb_d[qi], np.sort(row)[:k])                           # the k smallest, ascending
+        assert len(set(nb_ids[qi].tolist())) == k and q not in nb_ids[qi]
+        assert_bits_equal(O.distances(np.stack([np.full(k, q), nb_ids[qi]], 1)), nb_d[qi])   # ids match their distances
+        order = np.lexsort((np.arange(len(cand)), row))[:k]                     # ties: first listed first
+        assert np.array_equal(cand[order], nb_ids[qi])
+    one = T.nearest_neighbors(int(queries[3]), k=k)
+    assert [x[0] for x in one] == [T.leaf_nodes[int(i)] for i in nb_ids[3]] and [x[1] for x in one] == nb_d[3].tolist()
+    few_ids, few_d = T.nearest_neighbors_bulk([int(queries[0])], k=5, from_nodes=[int(x) for x in ids[:3]])
+    assert few_ids[0, 3:].tolist() == [-1, -1] and np.isnan(few_d[0, 3:]).all() and np.isfinite(few_d[0, :3]).all()
+    big = T.nearest_neighbors(int(queries[0]), k=300, from_nodes=[int(x) for x in ids])    # beyond the device's k: host sort
+    row = O.distances(np.stack([np.full(n, queries[0]), ids], 1))
+    assert [x[1] for x in big] == np.sort(row)[:300].tolist()
+
+
 @pytest.mark.parametrize("which", ["gopher_louse", "fish_worm"])
 def test_config5_linked_distances(which):
     d = golden_path(which)
@@ -123,13 +173,35 @@ def test_config5_linked_distances(which):
     OB = OracleTree(SLT.TreeB._flat.parent, SLT.TreeB._flat.distance)
     assert_bits_equal(res["TreeA"], OA.distances(ids_a))
     assert_bits_equal(res["TreeB"], OB.distances(ids_b))
-    # adjacency / Laplacian: dense assembly on the GPU equals the numpy assembly bit for bit
-    aj_gpu, aj_np = SLT.adjacency(), SLT.adjacency(on_gpu=False)
-    lp_gpu, lp_np = SLT.laplacian(), SLT.laplacian(on_gpu=False)
+    # adjacency / Laplacian: dense assembly on the GPU against the oracle's own dense-block
+    # restatement of MuchTree.pyx:1750-1813 + 3081-3145 (oracle/oracle.py, no shared code)
+    aj_gpu, lp_gpu = SLT.adjacency(), SLT.laplacian()
+    fa, fb = SLT.TreeA._flat, SLT.TreeB._flat
+    aj_o = linked_adjacency((fa.parent, fa.left, fa.right, fa.distance), (fb.parent, fb.left, fb.right, fb.distance),
+                            SLT.linklist, SLT.subset_a_root, SLT.subset_b_root,
+                            SLT.TreeA.polytomy_epsilon, SLT.TreeB.polytomy_epsilon)
+    lp_o = linked_laplacian(aj_o)
     n_graph = SLT.TreeA.size + SLT.TreeB.size
     assert aj_gpu.shape == lp_gpu.shape == (n_graph, n_graph)
-    assert np.array_equal(aj_gpu, aj_np) and np.array_equal(lp_gpu.view(np.int64), lp_np.view(np.int64))
+    assert np.array_equal(aj_gpu.view(np.int64), aj_o.view(np.int64))
+    assert np.array_equal(lp_gpu.view(np.int64), lp_o.view(np.int64))
+    assert np.array_equal(SLT.adjacency(on_gpu=False).view(np.int64), aj_o.view(np.int64))
     assert np.allclose(lp_gpu.sum(axis=0), 0)
+    # a subsetted graph (a clade of TreeB and the links into it)
+    sub_root = int(SLT.linklist[0, 0])
+    for _ in range(2):
+        up = int(SLT.TreeB.get_parent(sub_root))
+        if up == -1 or up == SLT.TreeB.root_node:
+            break
+        sub_root = up
+    SLT.subset_b(sub_root)
+    aj_s = linked_adjacency((fa.parent, fa.left, fa.right, fa.distance), (fb.parent, fb.left, fb.right, fb.distance),
+                            SLT.linklist, SLT.subset_a_root, SLT.subset_b_root,
+                            SLT.TreeA.polytomy_epsilon, SLT.TreeB.polytomy_epsilon)
+    assert aj_s.shape[0] < n_graph
+    assert np.array_equal(SLT.adjacency().view(np.int64), aj_s.view(np.int64))
+    assert np.array_equal(SLT.laplacian().view(np.int64), linked_laplacian(aj_s).view(np.int64))
+    SLT.subset_b(SLT.TreeB.root_node)
     if which == "gopher_louse":
         r = pearsonr(res["TreeA"], res["TreeB"])[0]
         assert abs(r - KNOWN["gopher_louse_linked_distances"]["pearson_r"]) < 1e-6
@@ -171,7 +243,7 @@ def test_config4_full_size_index_arithmetic():
     """The full 100k-leaf triangle has 4,999,950,000 pairs: pair indices beyond 2^32 must map to
     the right (row, column).  Slices at the far end and across the 2^31 / 2^32 boundaries."""
     m = 100_000
-    parent, dist = synth.random_binary_tree(m, seed=44)
+    parent, dist = synth.complete_tree(m, seed=44)
     dev = _capi.DeviceTree(parent, dist)
     O = OracleTree(parent, dist)
     ids = np.arange(0, 2 * m, 2, dtype=np.int64)

@@ -19,30 +19,15 @@ REL_TOL = 1e-6   # the stated tolerance; bit-equality below is stricter
 
 
 def _both(dev, pairs):
-    """Every kernel variant: the walk family and the canopy family at each pairs-per-lane setting."""
+    """Both kernel families with the settings the tree defaults to (the non-default canopy
+    variants have one sweep test of their own, test_non_default_canopy_variants)."""
     out = {}
     for strategy in ("walk", "canopy"):
         try:
             dev.set_strategy(strategy)
         except ValueError:
             continue
-        if strategy == "walk":
-            out["walk"] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
-            continue
-        dev.set_option("flow", 1)
-        for batch in (1, 16, 64):
-            dev.set_option("flow_batch", batch)
-            out["canopy/flow%d" % batch] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
-        dev.set_option("flow_batch", 16)
-        dev.set_option("flow", 0)
-        for ppl, lockstep in ((0, 1), (1, 0), (1, 1), (2, 0), (2, 1)):
-            dev.set_option("pairs_per_lane", ppl)
-            dev.set_option("lockstep", lockstep)
-            out["canopy/ppl%d%s" % (ppl, "" if lockstep else "/index-climb")] = \
-                dev.distances_host(pairs, want_dist=True, want_mrca=True)
-        dev.set_option("pairs_per_lane", 1)
-        dev.set_option("lockstep", 1)
-        dev.set_option("flow", 0)
+        out[strategy] = dev.distances_host(pairs, want_dist=True, want_mrca=True)
     dev.set_strategy("auto")
     return out
 
@@ -403,9 +388,32 @@ def test_general_trees_through_the_c_abi():
         dev.close()
 
 
+def test_non_default_canopy_variants(ml_arrays):
+    """The selectable forms of the canopy kernel -- scalar (pairs_per_lane 0), one and two
+    pairs per lane -- on a shallow and a deep tree, explicit pairs and the generated triangle."""
+    rng = np.random.default_rng(21)
+    trees = [synth.balanced_tree(16), (ml_arrays[0], ml_arrays[1])]
+    for parent, dist in trees:
+        O = OracleTree(parent, dist)
+        dev = _capi.DeviceTree(parent, dist, strategy="canopy")
+        pairs = rng.integers(0, len(parent), (150_000, 2))
+        ids = rng.choice(len(parent), size=500, replace=False).astype(np.int64)
+        i, j = np.tril_indices(len(ids), -1)
+        tri = np.stack([ids[j], ids[i]], 1)
+        want = (O.distances(pairs), O.mrca_bulk(pairs), O.distances(tri), O.mrca_bulk(tri))
+        for ppl in (0, 1, 2):
+            dev.set_option("pairs_per_lane", ppl)
+            d, m = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+            td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+            assert_bits_equal(d, want[0], "ppl%d" % ppl)
+            assert_bits_equal(td, want[2], "ppl%d triangle" % ppl)
+            assert np.array_equal(m, want[1]) and np.array_equal(tm, want[3])
+        dev.close()
+
+
 def test_argument_errors_on_a_live_handle(gopher_flat):
     dev = _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance)
-    for name, value in (("pairs_per_lane", 3), ("lockstep", 2), ("flow", 5), ("flow_batch", 0), ("nope", 1)):
+    for name, value in (("pairs_per_lane", 3), ("lockstep", 1), ("flow", 1), ("nope", 1)):
         with pytest.raises(ValueError):
             dev.set_option(name, value)
     with pytest.raises(ValueError):

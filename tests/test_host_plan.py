@@ -1,0 +1,68 @@
+"""Host-side logic of the multi-device handle and of the process model, no GPU needed:
+the chunk -> device map of the host path (st_host_chunk_plan / st_host_chunk_owner, the same
+arithmetic run_pipe uses) and the fork guard."""
+import os
+
+import numpy as np
+import pytest
+
+from suchtree_amd import _capi
+from suchtree_amd.exceptions import HipBackendError
+
+
+@pytest.mark.parametrize("n", [1, 2047, 262_144, 1_000_003, 4_194_304, 100_000_000, 4_999_950_000])
+@pytest.mark.parametrize("n_dev", [1, 2, 3, 8])
+def test_chunk_map_covers_the_batch_exactly_once(n, n_dev):
+    chunks = _capi.host_chunk_map(n, n_dev)
+    pos = 0
+    for c, (dev, first, m) in enumerate(chunks):
+        assert first == pos and m > 0          # contiguous, in order, no gaps, no overlap
+        assert dev == c % n_dev                # dealt round-robin
+        pos += m
+    assert pos == n
+    sizes = {m for _, _, m in chunks[:-1]}
+    assert len(sizes) <= 1                     # one chunk size (the last may be short)
+    assert max(m for _, _, m in chunks) <= 1 << 22
+    if n_dev > 1 and n >= n_dev * (1 << 18):
+        per_dev = np.bincount([d for d, _, _ in chunks], minlength=n_dev)
+        assert per_dev.min() >= 1              # nobody idles on a batch worth dealing
+
+
+def test_chunk_plan_argument_errors():
+    with pytest.raises(ValueError):
+        _capi.host_chunk_map(-1, 1)
+    with pytest.raises(ValueError):
+        _capi.host_chunk_map(10, 0)
+
+
+def test_fork_after_gpu_use_is_refused_with_a_clear_error(monkeypatch):
+    """A child forked after the parent initialised the GPU must get HipBackendError, not a
+    hang (the reference's fork-pool recipe, docs/examples/SuchTree_examples.md:462-497)."""
+    monkeypatch.setattr(_capi, "_gpu_pid", os.getpid())    # as if this process had uploaded a tree
+    _capi._check_fork()                                    # same process: fine
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                           # child: must refuse before any HIP call
+        os.close(r)
+        try:
+            _capi.DeviceTree(np.array([-1], np.int32), np.array([0], np.float32))
+            msg = b"no error"
+        except HipBackendError as e:
+            msg = b"refused:" + str(e).encode()
+        except BaseException as e:     # noqa: BLE001
+            msg = b"other:" + repr(e).encode()
+        os.write(w, msg)
+        os._exit(0)
+    os.close(w)
+    out = os.read(r, 4096)
+    os.waitpid(pid, 0)
+    assert out.startswith(b"refused:") and b"spawn" in out and b"forked" in out
+
+
+def test_lazy_upload_keeps_the_fork_pool_recipe_usable():
+    """Nothing touches the GPU until the first query, so trees created at module level can be
+    inherited by forked workers that do their own upload."""
+    from suchtree_amd import SuchTree
+    before = _capi._gpu_pid
+    T = SuchTree("((A:1,B:2):0.5,C:3);")
+    assert T._dev_tree is None and _capi._gpu_pid == before

@@ -68,6 +68,14 @@ def test_fish_worm_sizes_and_laplacian_shape():
     assert (aj[41:, :41] > 0).sum() == 191
     ev = SLT.spectrum(on_gpu=False)
     assert ev.shape == (422,) and abs(ev[0]) < 1e-9
+    # the oracle's dense-block restatement of MuchTree.pyx:1750-1813 + 3081-3145 (no shared code)
+    from oracle.oracle import linked_adjacency, linked_laplacian
+    fa, fb = SLT.TreeA._flat, SLT.TreeB._flat
+    aj_o = linked_adjacency((fa.parent, fa.left, fa.right, fa.distance), (fb.parent, fb.left, fb.right, fb.distance),
+                            SLT.linklist, SLT.subset_a_root, SLT.subset_b_root,
+                            SLT.TreeA.polytomy_epsilon, SLT.TreeB.polytomy_epsilon)
+    assert np.array_equal(aj.view(np.int64), aj_o.view(np.int64))
+    assert np.array_equal(lp.view(np.int64), linked_laplacian(aj_o).view(np.int64))
 
 
 def test_subsetting():

@@ -5,6 +5,7 @@ against the structural facts the reference's tests assert
 (tests/test_SuchTree.py:35-44 children ids, :22-24 polytomy resolution).
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -218,3 +219,36 @@ class TestNativeNewick:
         t = flat_tree_from_newick(synth.to_newick(parent, dist))
         # epsilon edges print as 2.22e-16 and come back as the same float32
         assert np.array_equal(t.parent, parent) and np.array_equal(t.distance, dist)
+
+
+def test_reference_data_digests():
+    """Every tree file under the reference's data/ directory (327 Newick files) through both
+    parsers: same arrays from both, and the same arrays as when tests/golden/newick_digests.json
+    was written (scripts/newick_digests.py).  Runs where the reference checkout exists."""
+    import hashlib
+    import json
+    ref = "/root/reference/data"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present")
+    want = json.load(open(golden_path("newick_digests.json")))
+    assert len(want) == 327 and all(v.get("native") == "identical" for v in want.values())
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]   # noqa: E731
+    # the big trees, the one with a quote inside an unquoted label, and a spread of the rest
+    names = sorted(want)
+    sample = set(names[::9]) | {"bigtrees/ml.tree", "bigtrees/nj.tree", "plant-pollinators/rabr/plant.tree"}
+    for rel in sorted(sample):
+        text = open(os.path.join(ref, rel)).read()
+        for native in (False, True):
+            t = flat_tree_from_newick(text, native=native)
+            w = want[rel]
+            assert (t.size, t.num_leaves, t.root, t.depth) == (w["nodes"], w["leaves"], w["root"], w["depth"]), rel
+            assert sha(t.parent) == w["parent"] and sha(t.distance) == w["distance"], rel
+            assert hashlib.sha256("\n".join(t.leaves.keys()).encode()).hexdigest()[:24] == w["leaf_names"], rel
+
+
+def test_quote_inside_an_unquoted_label_is_an_ordinary_character():
+    """data/plant-pollinators/rabr/plant.tree carries the label Cuphea_o'donellii: a quote opens
+    a quoted label only at the start of a token (dendropy's tokenizer)."""
+    for native in (False, True):
+        t = flat_tree_from_newick("((A_o'b:1,C:2):1,'D e''f':3);", native=native)
+        assert list(t.leaves) == ["A_o'b", "C", "D e'f"]

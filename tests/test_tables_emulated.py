@@ -145,3 +145,26 @@ def test_general_trees_through_the_c_tables(emulator, n, max_children):
         assert_bits_equal(d, want_d, strategy)
         assert np.array_equal(m, want_m), strategy
     assert info.parity == 0
+
+
+def test_config4_complete_tree(emulator):
+    """BASELINE config 4's tree as SURVEY 8d words it: complete binary tree, last level partially
+    filled, 100,000 leaves, seed 44.  Shape checks, then both table families against the oracle."""
+    parent, dist = synth.complete_tree(100_000, seed=44)
+    n = len(parent)
+    assert n == 199_999 and int((parent < 0).sum()) == 1
+    depth = np.zeros(n, dtype=np.int64)
+    from suchtree_amd.newick import node_depths
+    depth = node_depths(parent)
+    leaf_depth = depth[0::2]                                   # leaves are the even ids
+    assert set(np.unique(leaf_depth).tolist()) == {16, 17}     # 2^16 < 100000 <= 2^17
+    assert np.all(np.diff(leaf_depth) <= 0)                    # the deep (last-level) leaves are the leftmost
+    assert int((leaf_depth == 17).sum()) == 2 * (100_000 - 65_536)
+    small_p, small_d = synth.complete_tree(11, seed=44)
+    from suchtree_amd.newick import flat_tree_from_newick
+    assert np.array_equal(flat_tree_from_newick(synth.to_newick(small_p, small_d)).parent, small_p)
+    rng = np.random.default_rng(44)
+    leaf_pairs = rng.integers(0, 100_000, (30_000, 2)) * 2
+    info = _check(emulator, parent, dist, leaf_pairs)
+    assert info.parity == 1 and info.n_leaves == 100_000
+    _check(emulator, parent, dist, rng.integers(0, n, (20_000, 2)))
