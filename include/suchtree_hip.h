@@ -226,6 +226,8 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
 /* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the canopy
  * kernel keeps in flight: 1 (default) or 2 (explicit pair arrays only); 0 = scalar, branchy
  * form (default for deep canopies).
+ * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
+ * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
  * "small_batch_path": 1 (default) = host batches of <= 2048 pairs go through a pinned,
  * device-mapped mailbox (one launch + one synchronisation), 0 = through the staged pipe. */
 int st_tree_set_option(st_tree *tree, const char *name, int64_t value);

@@ -155,6 +155,74 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
     return r;
 }
 
+// Ladder form of pair_canopy_split (deep canopies).  `lad` is the ladder table, `cdepth` the
+// canopy depths (both LDS on the device).  Phase 1 finds the meeting node with integer work
+// only: the deeper lineage is lifted to the other's depth, then both climb in lock step three
+// levels at a time while their third ancestors differ, one level at a time once they agree.
+// Phase 2 then knows how many edges each side climbs and adds them, three per entry, in
+// lineage order: a's canopy edges onto pbot_a, b's understory, b's canopy edges.
+template <int CAP, typename LadPtr, typename DepthPtr>
+ST_HD PairResult pair_ladder_split(LadPtr lad, DepthPtr cdepth, const int32_t *__restrict__ canopy_id,
+                                   uint32_t pa, float pbot_a, uint32_t pb,
+                                   const float *D_b, uint32_t nb_b)
+{
+    uint32_t u = pa, v = pb;
+    const uint32_t da = cdepth[pa], db = cdepth[pb];
+    uint32_t du = da, dv = db;
+    while (du > dv) {
+        const uint32_t l = lad[u].link;
+        if (du - dv >= 3) { u = l & 0xFFFFu; du -= 3; } else { u = l >> 16; du -= 1; }
+    }
+    while (dv > du) {
+        const uint32_t l = lad[v].link;
+        if (dv - du >= 3) { v = l & 0xFFFFu; dv -= 3; } else { v = l >> 16; dv -= 1; }
+    }
+    while (u != v) {
+        const uint32_t lu = lad[u].link, lv = lad[v].link;
+        if ((lu & 0xFFFFu) != (lv & 0xFFFFu)) { u = lu & 0xFFFFu; v = lv & 0xFFFFu; du -= 3; }
+        else { u = lu >> 16; v = lv >> 16; du -= 1; }
+    }
+    const uint32_t mc = u;
+    float s = pbot_a;
+    uint32_t k = da - du;
+    u = pa;
+    while (k >= 3) {
+        const LadderEntry e = lad[u];
+        s += e.d0; s += e.d1; s += e.d2;
+        u = e.link & 0xFFFFu;
+        k -= 3;
+    }
+    if (k) {
+        const LadderEntry e = lad[u];
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    if (CAP > 0) {
+#pragma unroll
+        for (int i = 0; i < CAP; i++)
+            if ((uint32_t)i < nb_b) s += D_b[i];
+    } else {
+        for (uint32_t i = 0; i < nb_b; i++) s += D_b[i];
+    }
+    k = db - du;
+    v = pb;
+    while (k >= 3) {
+        const LadderEntry e = lad[v];
+        s += e.d0; s += e.d1; s += e.d2;
+        v = e.link & 0xFFFFu;
+        k -= 3;
+    }
+    if (k) {
+        const LadderEntry e = lad[v];
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    PairResult r;
+    r.dist = s;
+    r.mrca = canopy_id[mc];
+    return r;
+}
+
 // Both lineages enter the canopy at the same node: the MRCA is that portal or
 // lies in the understory.  Align the two chains at the portal end.
 ST_HD PairResult pair_canopy_same_portal(const int32_t *__restrict__ canopy_id,

@@ -344,6 +344,8 @@ __global__ __launch_bounds__(256) void k_quartet_pick(const long long *__restric
 struct CanopyParams {
     const CanopyEntry *canopy;     // [canopy_nodes] global copy, staged to LDS
     const int32_t *canopy_id;      // [canopy_nodes]
+    const LadderEntry *ladder;     // [canopy_nodes] ladder form (deep canopies), staged to LDS instead of `canopy`
+    const uint16_t *cdepth;        // [canopy_nodes (padded to 8)] canopy depths, staged with the ladder
     const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
@@ -575,6 +577,163 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
     }
 }
 
+// Tile-sorted ladder form for deep canopies (the default there).  On trees like data/bigtrees/ml.tree
+// a pair's climb is anything from a few to several hundred LDS rounds, so in the kernels above
+// a wave is as slow as its longest lineage and keeps ~30 % of its lanes busy.  Here a workgroup
+// takes a tile of Q * 1024 pairs (Q = 2, or 1 when LDS is short), estimates each pair's work from the depths of its two portals
+// (one 4-byte read of each record), counting-sorts the tile by that key in LDS, and hands
+// every wave 64 pairs of similar length: waves, not lanes, differ in run time, and a wave's
+// instructions serve 64 active lanes.  With Q = 2 wave w processes sorted groups w and 31-w
+// (short with long), so the waves of a workgroup finish together.  Results go straight to the pair's own
+// slot of the output (scattered within the tile's window, a few KiB).  The canopy sits in LDS
+// in its ladder form (tree_prep.h: three edges per 16-byte entry), so a climb of k edges is k/3
+// LDS reads; the meeting node is found first with integer work only (pair_math.h:
+// pair_ladder_split).  Not one float addition changes: same operands, same order.
+constexpr int kSortBuckets = 256;
+// LDS scratch of a tile of Q * 1024 pairs: two uint32 slots and one uint16 per pair, the
+// bucket array and the scan carries
+__host__ __device__ constexpr size_t sort_scratch_bytes(int q)
+{
+    return (size_t)q * kCanopyBlock * (4 + 4 + 2) + (size_t)kSortBuckets * 4 + 64;
+}
+
+// LDS image of the ladder form: canopy_nodes 16-byte entries (the depths stay in global
+// memory: they are read twice per pair, from a table of a few KiB)
+__host__ __device__ inline size_t ladder_image_bytes(int canopy_nodes)
+{
+    return (size_t)canopy_nodes * 16;
+}
+
+template <int CAP, int Q, typename Src>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, Src src, long long n,
+                                                                DistSink out_d, int *__restrict__ out_m,
+                                                                Fault *fault, int key_shift)
+{
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const LadderEntry *lad = reinterpret_cast<const LadderEntry *>(lds_raw);
+    const uint16_t *cdep = P.cdepth;
+    constexpr int kSortTile = Q * kCanopyBlock;
+    {   // stage the ladder form of the canopy: one 16-byte entry per lane per step
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        const uint4 *src_e = reinterpret_cast<const uint4 *>(P.ladder);
+        for (int k = threadIdx.x; k < P.canopy_nodes; k += blockDim.x) dst[k] = src_e[k];
+        __syncthreads();
+    }
+    unsigned char *scratch = lds_raw + ladder_image_bytes(P.canopy_nodes);
+    uint32_t *SA = reinterpret_cast<uint32_t *>(scratch);            // [kSortTile] record slot of a
+    uint32_t *SB = SA + kSortTile;                                   // [kSortTile] record slot of b
+    uint32_t *HIST = SB + kSortTile;                                 // [kSortBuckets] counts, then exclusive starts
+    uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
+    uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
+
+    const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
+    const int half = rec_bytes / 2;
+    const bool parity = P.parity != 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * kSortTile; base < n; base += (long long)gridDim.x * kSortTile) {
+        if (threadIdx.x < kSortBuckets) HIST[threadIdx.x] = 0;
+        __syncthreads();
+        // keys: deeper portal of the pair, in units of 2^key_shift levels
+        uint32_t key[Q], rank[Q];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            const int j = (int)threadIdx.x + q * kCanopyBlock;
+            const long long i = base + j;
+            key[q] = 0xFFFFFFFFu;
+            rank[q] = 0;
+            if (i < n) {
+                long long a, b;
+                src.load(i, a, b);
+                if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
+                    (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+                    record_fault(fault, a, b, P.n_nodes);
+                    store_result(out_d, out_m, i, __builtin_nanf(""), -1);
+                } else {
+                    const long long sa = record_slot(a, parity, P.n_leaves);
+                    const long long sb = record_slot(b, parity, P.n_leaves);
+                    SA[j] = (uint32_t)sa;
+                    SB[j] = (uint32_t)sb;
+                    const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
+                    const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
+                    const uint32_t da = cdep[pa], db = cdep[pb];
+                    uint32_t k = (da > db ? da : db) >> key_shift;
+                    key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
+                    rank[q] = atomicAdd(&HIST[key[q]], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the 256 bucket counts (4 waves of 64)
+        uint32_t cnt = 0, incl = 0;
+        if (threadIdx.x < kSortBuckets) {
+            cnt = HIST[threadIdx.x];
+            incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) WSUM[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < kSortBuckets) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += WSUM[w];
+            HIST[threadIdx.x] = carry + incl - cnt;
+            if (threadIdx.x == kSortBuckets - 1) WSUM[4] = carry + incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            if (key[q] != 0xFFFFFFFFu) PERM[HIST[key[q]] + rank[q]] = (uint16_t)((int)threadIdx.x + q * kCanopyBlock);
+        __syncthreads();
+        const uint32_t total = WSUM[4];
+        // wave w: sorted groups w (short pairs) and, with two groups per wave, 31 - w (long pairs)
+#pragma unroll 1
+        for (int q = 0; q < Q; q++) {
+            const uint32_t pos = (uint32_t)((q == 0 ? wave : 31 - wave) * 64 + lane);
+            if (pos >= total) continue;
+            const int j = PERM[pos];
+            const long long sa = SA[j], sb = SB[j];
+            const uint8_t *rb = P.rec_b + sb * half;
+            const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+            const uint32_t wa = va.x;
+            const float pbot_a = __uint_as_float(va.y);
+            uint32_t wb;
+            float Db[CAP > 0 ? CAP : 1];
+            if (CAP == 1) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(rb);
+                wb = v.x;
+                Db[0] = __uint_as_float(v.y);
+            } else if (CAP > 1) {
+                uint32_t w[CAP + 1];
+#pragma unroll
+                for (int x = 0; x < (CAP + 1) / 4; x++) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(rb)[x];
+                    w[4 * x + 0] = v.x; w[4 * x + 1] = v.y; w[4 * x + 2] = v.z; w[4 * x + 3] = v.w;
+                }
+                wb = w[0];
+#pragma unroll
+                for (int x = 0; x < CAP; x++) Db[x] = __uint_as_float(w[x + 1]);
+            } else {
+                wb = *reinterpret_cast<const uint32_t *>(rb);
+                Db[0] = 0.0f;
+            }
+            const uint32_t pa = wa & 0xFFFFu, pb = wb & 0xFFFFu;
+            PairResult r;
+            if (pa != pb) {
+                const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
+                r = pair_ladder_split<CAP>(lad, cdep, P.canopy_id, pa, pbot_a, pb, dptr, wb >> 16);
+            } else {
+                const RecTables R{P.rec_a, P.rec_b, P.rec_i, half};
+                r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
+            }
+            store_result(out_d, out_m, base + j, r.dist, r.mrca);
+        }
+        __syncthreads();     // the next tile overwrites SA / SB / PERM
+    }
+}
+
 // ---- k nearest candidates per query row (nearest_neighbors, MuchTree.pyx:1032-1082) ----------
 // dist[row * n_c + c] are the float32 distances query(row) -> cands[c].  One workgroup per row
 // selects the k smallest in k rounds: round r finds the smallest key greater than the one
@@ -738,6 +897,9 @@ struct st_tree {
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
+    int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
+    LadderEntry *d_ladder = nullptr;
+    uint16_t *d_cdepth = nullptr;
     int canopy_depth = 0;     // deepest canopy node (edges)
     int small_batch_path = 1; // tuning: batches <= kMailboxPairs go through the pinned mailbox
     // staging of the host entry points: the device's shared pipe
@@ -786,10 +948,50 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     return hipGetLastError();
 }
 
+// pairs per lane of the tile-sorted kernel: 2 when the scratch fits next to the canopy image
+// (in half the LDS if possible: two workgroups per CU), else 1; 0 = does not fit at all
+static int sorted_q(const st_tree *t)
+{
+    const size_t image = ladder_image_bytes(t->canopy_nodes);
+    if (image + sort_scratch_bytes(2) <= 80 * 1024) return 2;
+    if (image + sort_scratch_bytes(1) <= 80 * 1024) return 1;
+    if (image + sort_scratch_bytes(2) <= 160 * 1024) return 2;
+    if (image + sort_scratch_bytes(1) <= 160 * 1024) return 1;
+    return 0;
+}
+
+template <int CAP, typename Src>
+static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
+                                       DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
+{
+    const int q = sorted_q(t);
+    const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q);
+    const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int64_t tile = (int64_t)q * kCanopyBlock;
+    int64_t blocks = (n + tile - 1) / tile;
+    blocks = std::max<int64_t>(std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu), 1);
+    int key_shift = 0;
+    while ((t->canopy_depth >> key_shift) >= kSortBuckets) key_shift++;
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
+                           (long long)n, out_d, out_m, fault, key_shift);
+        return hipGetLastError();
+    };
+    return q == 2 ? go(k_canopy_sorted<CAP, 2, Src>) : go(k_canopy_sorted<CAP, 1, Src>);
+}
+
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                   DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
 {
+    // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
+    if (t->tile_sort && sorted_q(t) > 0)
+        return launch_canopy_sorted<CAP>(t, P, src, n, out_d, out_m, fault, stream);
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     } else {
@@ -810,6 +1012,8 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     CanopyParams P;
     P.canopy = t->d_canopy;
     P.canopy_id = t->d_canopy_id;
+    P.ladder = t->d_ladder;
+    P.cdepth = t->d_cdepth;
     P.rec_a = t->d_rec_a;
     P.rec_b = t->d_rec_b;
     P.rec_i = t->d_rec_i;
@@ -818,6 +1022,11 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.canopy_nodes = t->canopy_nodes;
     P.rec_bytes = t->rec_bytes;
     P.parity = t->parity;
+    // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
+    // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
+    if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 &&
+        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t)) > 80 * 1024)
+        return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
     switch (t->rec_cap) {
         case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream);
         case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream);
@@ -1123,9 +1332,11 @@ static int build_tables(const int32_t *parent, const float *distance, int64_t n_
             for (const CanopyEntry &e : B.T.canopy) cdepth = std::max<int>(cdepth, (int)(e.link >> 16));
             if (cdepth > kDeepCanopyDepth) {
                 B.deep = true;
-                if (B.T.canopy_nodes > kDeepCanopyNodes) {
+                int deep_nodes = kDeepCanopyNodes;
+                if (const char *env = std::getenv("SUCHTREE_AMD_DEEP_NODES")) deep_nodes = std::atoi(env);   // tuning experiments
+                if (B.T.canopy_nodes > deep_nodes) {
                     TreeTables T2 = B.T;
-                    if (prepare_canopy(parent, distance, T2, kDeepCanopyNodes)) B.T = std::move(T2);
+                    if (prepare_canopy(parent, distance, T2, deep_nodes)) B.T = std::move(T2);
                 }
             }
         }
@@ -1154,7 +1365,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     t->n_nodes = T.n;
     t->n_leaves = T.n_leaves;
-    if (B.deep) t->pairs_per_lane = 0;
+    if (B.deep) { t->pairs_per_lane = 0; t->tile_sort = 1; }
     int64_t bytes = 0;
     int rc = upload(&t->d_nodes, T.nodes, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
@@ -1169,6 +1380,12 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
         if (image.size() & 1) image.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
         rc = upload(&t->d_canopy, image, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_ladder, T.ladder, &bytes);
+        if (rc == ST_OK) {
+            std::vector<uint16_t> cd = T.canopy_depth;
+            cd.resize((cd.size() + 7) / 8 * 8, 0);     // 16-byte staging granule
+            rc = upload(&t->d_cdepth, cd, &bytes);
+        }
         if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
@@ -1316,6 +1533,8 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_depth);
         (void)hipFree(t->d_canopy);
         (void)hipFree(t->d_canopy_id);
+        (void)hipFree(t->d_ladder);
+        (void)hipFree(t->d_cdepth);
         (void)hipFree(t->d_rec_a);
         (void)hipFree(t->d_rec_b);
         (void)hipFree(t->d_rec_i);
@@ -1366,6 +1585,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         if (value != 0 && value != 1 && value != 2)
             return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1 or 2");
         t->pairs_per_lane = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "tile_sort") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tile_sort must be 0 or 1");
+        t->tile_sort = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "small_batch_path") == 0) {
@@ -1758,37 +1982,49 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
     if (n <= 0 || n_edges < 0) return fail(ST_ERR_ARG, "bad sizes");
     if (n_edges > 0 && (!u || !v || !w)) return fail(ST_ERR_ARG, "edge arrays are NULL");
     if (!out_adjacency && !out_laplacian) return fail(ST_ERR_ARG, "both outputs are NULL");
-    if (n > 100000) return fail(ST_ERR_ARG, "dense n x n matrix too large");
     for (int64_t e = 0; e < n_edges; e++)
         if (u[e] < 0 || u[e] >= n || v[e] < 0 || v[e] >= n) return fail(ST_ERR_ARG, "edge endpoint out of range");
     ST_DEVICE(device);
+    // one workspace: A, L (only if asked for), column sums, edge list.  The dense matrices
+    // must fit the GPU's free memory with room to spare; beyond that the caller should not
+    // be building a dense Laplacian at all (the reference's numpy version would need the same
+    // bytes of host memory).
     const size_t mat = (size_t)n * (size_t)n * 8;
-    double *d_A = nullptr, *d_L = nullptr, *d_deg = nullptr, *d_w = nullptr;
-    int *d_u = nullptr, *d_v = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_A), mat);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_L), mat);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_deg), (size_t)n * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_u), (size_t)std::max<int64_t>(n_edges, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_v), (size_t)std::max<int64_t>(n_edges, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_w), (size_t)std::max<int64_t>(n_edges, 1) * 8);
-    if (e == hipSuccess) e = hipMemset(d_A, 0, mat);
-    if (e == hipSuccess && n_edges) e = hipMemcpy(d_u, u, (size_t)n_edges * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_edges) e = hipMemcpy(d_v, v, (size_t)n_edges * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_edges) e = hipMemcpy(d_w, w, (size_t)n_edges * 8, hipMemcpyHostToDevice);
+    const size_t edges_b = (size_t)std::max<int64_t>(n_edges, 1);
+    const size_t need = mat * (out_laplacian ? 2 : 1) + (size_t)n * 8 + edges_b * 16 + 4096;
+    size_t free_b = 0, total_b = 0;
+    ST_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (need > free_b / 10 * 9)
+        return fail(ST_ERR_NOMEM, "dense " + std::to_string(n) + " x " + std::to_string(n) + " graph matrices need " +
+                                      std::to_string(need >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) + " MiB free");
+    char *ws = nullptr;
+    ST_HIP(hipMalloc(reinterpret_cast<void **>(&ws), need));
+    double *d_A = reinterpret_cast<double *>(ws);
+    double *d_L = out_laplacian ? d_A + (size_t)n * n : nullptr;
+    double *d_deg = reinterpret_cast<double *>(ws + mat * (out_laplacian ? 2 : 1));
+    double *d_w = d_deg + n;
+    int *d_u = reinterpret_cast<int *>(d_w + edges_b), *d_v = d_u + edges_b;
+    hipError_t e = hipMemsetAsync(d_A, 0, mat, nullptr);
+    if (e == hipSuccess && n_edges) e = hipMemcpyAsync(d_u, u, (size_t)n_edges * 4, hipMemcpyHostToDevice, nullptr);
+    if (e == hipSuccess && n_edges) e = hipMemcpyAsync(d_v, v, (size_t)n_edges * 4, hipMemcpyHostToDevice, nullptr);
+    if (e == hipSuccess && n_edges) e = hipMemcpyAsync(d_w, w, (size_t)n_edges * 8, hipMemcpyHostToDevice, nullptr);
     if (e == hipSuccess) {
         if (n_edges)
             hipLaunchKernelGGL(k_graph_scatter, dim3((unsigned)std::min<int64_t>((n_edges + 255) / 256, 4096)),
                                dim3(256), 0, nullptr, d_A, (long long)n, (long long)n_edges, d_u, d_v, d_w);
-        hipLaunchKernelGGL(k_graph_degree, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0,
-                           nullptr, d_A, (long long)n, d_deg);
-        hipLaunchKernelGGL(k_graph_laplacian, dim3((unsigned)std::min<int64_t>((n * n + 255) / 256, 65536)),
-                           dim3(256), 0, nullptr, d_A, d_deg, (long long)n, d_L);
+        if (out_laplacian) {
+            // one lane per column, rows in increasing order (numpy's sum(axis=0) order); waves of
+            // 64 consecutive columns read each row coalesced, one wave per workgroup so that a
+            // few hundred columns already spread over the chip
+            hipLaunchKernelGGL(k_graph_degree, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, d_A, (long long)n, d_deg);
+            hipLaunchKernelGGL(k_graph_laplacian, dim3((unsigned)std::min<int64_t>((n * n + 255) / 256, 65536)),
+                               dim3(256), 0, nullptr, d_A, d_deg, (long long)n, d_L);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess && out_adjacency) e = hipMemcpy(out_adjacency, d_A, mat, hipMemcpyDeviceToHost);
     if (e == hipSuccess && out_laplacian) e = hipMemcpy(out_laplacian, d_L, mat, hipMemcpyDeviceToHost);
-    (void)hipFree(d_A); (void)hipFree(d_L); (void)hipFree(d_deg);
-    (void)hipFree(d_u); (void)hipFree(d_v); (void)hipFree(d_w);
+    (void)hipFree(ws);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("graph matrices: ") + hipGetErrorString(e));
     return ST_OK;
 }

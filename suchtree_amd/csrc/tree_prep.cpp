@@ -130,6 +130,20 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     T.canopy_nodes = (int32_t)T.canopy.size();
     if (T.canopy_nodes < 1 || T.canopy_nodes > kMaxCanopyNodes || T.canopy_nodes > 65535) return false;
     T.canopy[0].dist = 0.0f;   // root: never added
+    // ladder form: parents precede children in BFS order, so parent entries are complete
+    T.ladder.assign((size_t)T.canopy_nodes, LadderEntry{0.0f, 0.0f, 0.0f, 0u});
+    T.canopy_depth.assign((size_t)T.canopy_nodes, 0);
+    for (int32_t c = 0; c < T.canopy_nodes; c++) {
+        const uint32_t p1 = T.canopy[(size_t)c].link & kCanopyParentMask;          // root: 0 (itself)
+        const uint32_t p2 = T.canopy[(size_t)p1].link & kCanopyParentMask;
+        const uint32_t p3 = T.canopy[(size_t)p2].link & kCanopyParentMask;
+        LadderEntry &e = T.ladder[(size_t)c];
+        e.d0 = T.canopy[(size_t)c].dist;
+        e.d1 = T.canopy[(size_t)p1].dist;
+        e.d2 = T.canopy[(size_t)p2].dist;
+        e.link = p3 | (p1 << 16);
+        T.canopy_depth[(size_t)c] = (uint16_t)(T.canopy[(size_t)c].link >> 16);
+    }
     T.understory_max = H;
     T.record_bytes = rec_bytes;
     T.record_cap = cap;

@@ -41,6 +41,18 @@ struct CanopyEntry {
 constexpr uint32_t kCanopyParentMask = 0xFFFFu;
 static_assert(sizeof(CanopyEntry) == 8, "CanopyEntry must be 8 bytes");
 
+// Ladder form of the canopy, for deep trees (hundreds of levels): one 16-byte entry per canopy
+// node carries the branch lengths of THREE consecutive edges of its lineage -- its own, its
+// parent's and its grandparent's -- and the canopy indices of its parent and of its third
+// ancestor, so a climb of k edges costs k/3 LDS reads and k float adds (in lineage order,
+// exactly as before) instead of k reads.  Near the root the third ancestor is clamped to the
+// root (index 0) and the unused lengths are 0 (never added: climbs know their edge counts).
+struct LadderEntry {
+    float d0, d1, d2;   // dist[v], dist[parent(v)], dist[parent(parent(v))]
+    uint32_t link;      // bits 0..15: third ancestor (clamped to the root); bits 16..31: parent (root: itself)
+};
+static_assert(sizeof(LadderEntry) == 16, "LadderEntry must be 16 bytes");
+
 // Understory record of a node, cap = R/8 - 1 chain slots, kept in three tables so that
 // each side of a pair touches the fewest bytes (all indexed by record slot):
 //   rec_a  8 bytes  : word0 = portal (canopy index, bits 0..15) | chain length << 16,
@@ -73,6 +85,8 @@ struct TreeTables {
     int32_t record_cap = 0;             // chain slots per record
     std::vector<CanopyEntry> canopy;    // [canopy_nodes]
     std::vector<int32_t> canopy_id;     // [canopy_nodes] canopy index -> node id
+    std::vector<LadderEntry> ladder;    // [canopy_nodes] ladder form of the same canopy (see LadderEntry)
+    std::vector<uint16_t> canopy_depth; // [canopy_nodes] edges to the root
     std::vector<uint8_t> rec_a;         // [n * 8], slot order
     std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
     std::vector<uint8_t> rec_i;         // [n * record_bytes/2]

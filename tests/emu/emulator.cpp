@@ -68,9 +68,17 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                 g_err = "rec_a disagrees with rec_b / rec_i";
                 return 3;
             }
-            if (A.portal != B.portal)
+            if (A.portal != B.portal) {
                 r = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), wa & 0xFFFFu, pbot_a,
                                          B.portal, B.D, B.nb);
+                // the ladder form of the same canopy must agree bit for bit
+                const PairResult l = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(),
+                                                          wa & 0xFFFFu, pbot_a, B.portal, B.D, B.nb);
+                if (l.mrca != r.mrca || std::memcmp(&l.dist, &r.dist, 4) != 0) {
+                    g_err = "ladder climb disagrees with the plain canopy climb";
+                    return 4;
+                }
+            }
             else
                 r = pair_canopy_same_portal(T.canopy_id.data(), A, B);
         }

@@ -188,12 +188,10 @@ def test_config5_linked_distances(which):
     assert np.array_equal(SLT.adjacency(on_gpu=False).view(np.int64), aj_o.view(np.int64))
     assert np.allclose(lp_gpu.sum(axis=0), 0)
     # a subsetted graph (a clade of TreeB and the links into it)
-    sub_root = int(SLT.linklist[0, 0])
-    for _ in range(2):
-        up = int(SLT.TreeB.get_parent(sub_root))
-        if up == -1 or up == SLT.TreeB.root_node:
-            break
-        sub_root = up
+    B = SLT.TreeB          # a clade two levels above some linked leaf that is not the whole tree
+    sub_root = next(g for g in (int(B.get_parent(B.get_parent(int(x)))) for x in SLT.linklist[:, 0]
+                                if B.get_parent(int(x)) != B.root_node)
+                    if g not in (-1, B.root_node))
     SLT.subset_b(sub_root)
     aj_s = linked_adjacency((fa.parent, fa.left, fa.right, fa.distance), (fb.parent, fb.left, fb.right, fb.distance),
                             SLT.linklist, SLT.subset_a_root, SLT.subset_b_root,

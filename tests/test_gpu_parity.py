@@ -130,7 +130,7 @@ def test_config3_balanced_2_20_sample_and_full_size_properties():
     # full batch size of the bench step: size-independent properties
     big = synth.random_leaf_pairs(n_leaves, 20_000_000, seed=11)
     res = _both(dev, big)
-    (dw, mw), (dc, mc) = res["walk"], res["canopy/ppl2"]
+    (dw, mw), (dc, mc) = res["walk"], res["canopy"]
     for name, (d, m) in res.items():
         assert_bits_equal(d, dw, name + " vs walk at 2e7 pairs")
         assert np.array_equal(m, mw), name
