@@ -131,7 +131,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             tree.fault_check(stream.cuda_stream)
-            emit(fh, config=4, workload="full lower triangle, %d-leaf random binary tree, generated on device" % m,
+            emit(fh, config=4, workload="full lower triangle, complete %d-leaf binary tree (seed 44), generated on device" % m,
                  pairs=total, kernel_family=strategy, where="device (tile buffer overwritten)",
                  seconds=dt, pairs_per_s=total / dt, info=tree.info())
         tree.set_strategy("canopy")

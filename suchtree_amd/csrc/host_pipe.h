@@ -124,7 +124,8 @@ private:
 
 struct PipeSlot {
     void *h_in = nullptr, *h_d = nullptr, *h_m = nullptr;   // pinned host memory, read / written by the kernels
-    void *d_in = nullptr;                                   // device copy of h_in (quartet path only, see ensure_device_in)
+    void *d_in = nullptr;                                   // device copy of h_in  (quartets; tile-sorted kernels: ensure_device_stage)
+    void *d_d = nullptr, *d_m = nullptr;                    // device-side result staging (tile-sorted kernels only)
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     int64_t off = 0, m = 0;
@@ -176,6 +177,19 @@ struct HostPipe {
         return hipSuccess;
     }
 
+    // Device-side staging of a whole slot: kernels that read their pairs twice and store their
+    // results in sorted (scattered) order must not do that over PCIe; they work on these
+    // buffers and coalesced copy kernels move the slot between pinned and device memory.
+    hipError_t ensure_device_stage()
+    {
+        hipError_t e = ensure_device_in();
+        for (auto &s : slot) {
+            if (e == hipSuccess && !s.d_d) e = hipMalloc(&s.d_d, (size_t)cap * 4);
+            if (e == hipSuccess && !s.d_m) e = hipMalloc(&s.d_m, (size_t)cap * 4);
+        }
+        return e;
+    }
+
     hipError_t ensure_ids(int64_t n)
     {
         if (n <= ids_cap) return hipSuccess;
@@ -191,8 +205,8 @@ struct HostPipe {
     {
         for (auto &s : slot) {
             (void)hipHostFree(s.h_in); (void)hipHostFree(s.h_d); (void)hipHostFree(s.h_m);
-            (void)hipFree(s.d_in);
-            s.h_in = s.h_d = s.h_m = s.d_in = nullptr;
+            (void)hipFree(s.d_in); (void)hipFree(s.d_d); (void)hipFree(s.d_m);
+            s.h_in = s.h_d = s.h_m = s.d_in = s.d_d = s.d_m = nullptr;
             s.busy = false;
         }
         cap = 0;

@@ -368,16 +368,78 @@ __device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned cha
     __syncthreads();
 }
 
-// Scalar form (one pair per lane).  CAP = chain slots per record (rec_bytes = 8*(CAP+1));
-// CAP == 0 is the generic form for records longer than 128 bytes, which reads b's chain
-// through a pointer.
+// One pair, scalar: the record loads and the climb, for a valid pair with record slots sa / sb.
+// CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 is the generic form for records
+// longer than CAP allows in registers, which reads b's chain through a pointer.  LADDER: `image`
+// is the ladder form of the canopy (tree_prep.h), else the plain 8-byte entries.
+template <int CAP, bool LADDER>
+__device__ __forceinline__ PairResult canopy_pair_scalar(const CanopyParams &P, const unsigned char *image,
+                                                         long long sa, long long sb, int rec_bytes)
+{
+    const int half = rec_bytes / 2;
+    const uint8_t *rb = P.rec_b + sb * half;
+    // a: word0 and pbot (8 bytes of rec_a).  b: word0 + chain lengths (rec_b).
+    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+    const uint32_t wa = va.x;
+    const float pbot_a = __uint_as_float(va.y);
+    uint32_t wb;
+    float Db[CAP > 0 ? CAP : 1];
+    if (CAP == 1) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(rb);
+        wb = v.x;
+        Db[0] = __uint_as_float(v.y);
+    } else if (CAP > 1) {
+        uint32_t w[CAP + 1];
+#pragma unroll
+        for (int q = 0; q < (CAP + 1) / 4; q++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(rb)[q];
+            w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        wb = w[0];
+#pragma unroll
+        for (int q = 0; q < CAP; q++) Db[q] = __uint_as_float(w[q + 1]);
+    } else {
+        wb = *reinterpret_cast<const uint32_t *>(rb);
+        Db[0] = 0.0f;
+    }
+    const uint32_t pa = wa & 0xFFFFu, pb = wb & 0xFFFFu;
+    if (pa != pb) {
+        const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
+        if (LADDER)
+            return pair_ladder_split<CAP>(reinterpret_cast<const LadderEntry *>(image), P.cdepth, P.canopy_id,
+                                          pa, pbot_a, pb, dptr, wb >> 16);
+        return pair_canopy_split<CAP>(reinterpret_cast<const CanopyEntry *>(image), P.canopy_id, pa, pbot_a, pb,
+                                      dptr, wb >> 16);
+    }
+    const RecTables R{P.rec_a, P.rec_b, P.rec_i, half};
+    return pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
+}
+
+// LDS image of the ladder form: canopy_nodes 16-byte entries (the depths stay in global
+// memory: they are read twice per pair, from a table of a few KiB)
+__host__ __device__ inline size_t ladder_image_bytes(int canopy_nodes)
+{
+    return (size_t)canopy_nodes * 16;
+}
+
+__device__ __forceinline__ void stage_ladder(const CanopyParams &P, unsigned char *lds_raw)
+{
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+    const uint4 *src_e = reinterpret_cast<const uint4 *>(P.ladder);
+    for (int k = threadIdx.x; k < P.canopy_nodes; k += blockDim.x) dst[k] = src_e[k];
+    __syncthreads();
+}
+
+// Scalar, branchy kernel (one pair per lane, input order): records longer than 128 bytes and
+// the pairs_per_lane = 0 setting.  (Over the ladder image it measured no faster than the
+// predicated kernel on 2^17-leaf trees -- those are bound by record fetches too -- so the
+// ladder is only used by the tile-sorted kernel.)
 template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src, long long n,
                                                          DistSink out_d,
                                                          int *__restrict__ out_m, Fault *fault)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    CanopyEntry *can = reinterpret_cast<CanopyEntry *>(lds_raw);
     stage_canopy(P, lds_raw);
 
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
@@ -393,41 +455,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
         }
         const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
         const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
-        const uint8_t *rb = P.rec_b + sb * (rec_bytes / 2);
-
-        // a: word0 and pbot (8 bytes of rec_a).  b: word0 + chain lengths (rec_b).
-        const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-        const uint32_t wa = va.x;
-        const float pbot_a = __uint_as_float(va.y);
-        uint32_t wb;
-        float Db[CAP > 0 ? CAP : 1];
-        if (CAP == 1) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(rb);
-            wb = v.x;
-            Db[0] = __uint_as_float(v.y);
-        } else if (CAP > 1) {
-            uint32_t w[CAP + 1];
-#pragma unroll
-            for (int q = 0; q < (CAP + 1) / 4; q++) {
-                const uint4 v = reinterpret_cast<const uint4 *>(rb)[q];
-                w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-            }
-            wb = w[0];
-#pragma unroll
-            for (int q = 0; q < CAP; q++) Db[q] = __uint_as_float(w[q + 1]);
-        } else {
-            wb = *reinterpret_cast<const uint32_t *>(rb);
-            Db[0] = 0.0f;
-        }
-        const uint32_t pa = wa & 0xFFFFu, pb = wb & 0xFFFFu;
-        PairResult r;
-        if (pa != pb) {
-            const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
-            r = pair_canopy_split<CAP>(can, P.canopy_id, pa, pbot_a, pb, dptr, wb >> 16);
-        } else {
-            const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
-            r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
-        }
+        const PairResult r = canopy_pair_scalar<CAP, false>(P, lds_raw, sa, sb, rec_bytes);
         store_result(out_d, out_m, i, r.dist, r.mrca);
     }
 }
@@ -580,28 +608,21 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 // Tile-sorted ladder form for deep canopies (the default there).  On trees like data/bigtrees/ml.tree
 // a pair's climb is anything from a few to several hundred LDS rounds, so in the kernels above
 // a wave is as slow as its longest lineage and keeps ~30 % of its lanes busy.  Here a workgroup
-// takes a tile of Q * 1024 pairs (Q = 2, or 1 when LDS is short), estimates each pair's work from the depths of its two portals
+// takes a tile of Q * 1024 pairs (Q = 2 with two workgroups per CU, 4 with one), estimates each pair's work from the depths of its two portals
 // (one 4-byte read of each record), counting-sorts the tile by that key in LDS, and hands
 // every wave 64 pairs of similar length: waves, not lanes, differ in run time, and a wave's
-// instructions serve 64 active lanes.  With Q = 2 wave w processes sorted groups w and 31-w
-// (short with long), so the waves of a workgroup finish together.  Results go straight to the pair's own
+// instructions serve 64 active lanes.  Wave w processes sorted groups w, 31-w (, 32+w, 63-w):
+// short with long, so the waves of a workgroup finish together.  Results go straight to the pair's own
 // slot of the output (scattered within the tile's window, a few KiB).  The canopy sits in LDS
 // in its ladder form (tree_prep.h: three edges per 16-byte entry), so a climb of k edges is k/3
 // LDS reads; the meeting node is found first with integer work only (pair_math.h:
 // pair_ladder_split).  Not one float addition changes: same operands, same order.
 constexpr int kSortBuckets = 256;
-// LDS scratch of a tile of Q * 1024 pairs: two uint32 slots and one uint16 per pair, the
-// bucket array and the scan carries
+// LDS scratch of a tile of Q * 1024 pairs: one uint16 per pair (the sorted order), the bucket
+// array and the scan carries
 __host__ __device__ constexpr size_t sort_scratch_bytes(int q)
 {
-    return (size_t)q * kCanopyBlock * (4 + 4 + 2) + (size_t)kSortBuckets * 4 + 64;
-}
-
-// LDS image of the ladder form: canopy_nodes 16-byte entries (the depths stay in global
-// memory: they are read twice per pair, from a table of a few KiB)
-__host__ __device__ inline size_t ladder_image_bytes(int canopy_nodes)
-{
-    return (size_t)canopy_nodes * 16;
+    return (size_t)q * kCanopyBlock * 2 + (size_t)kSortBuckets * 4 + 64;
 }
 
 template <int CAP, int Q, typename Src>
@@ -610,19 +631,11 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                                                                 Fault *fault, int key_shift)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const LadderEntry *lad = reinterpret_cast<const LadderEntry *>(lds_raw);
     const uint16_t *cdep = P.cdepth;
     constexpr int kSortTile = Q * kCanopyBlock;
-    {   // stage the ladder form of the canopy: one 16-byte entry per lane per step
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-        const uint4 *src_e = reinterpret_cast<const uint4 *>(P.ladder);
-        for (int k = threadIdx.x; k < P.canopy_nodes; k += blockDim.x) dst[k] = src_e[k];
-        __syncthreads();
-    }
+    stage_ladder(P, lds_raw);
     unsigned char *scratch = lds_raw + ladder_image_bytes(P.canopy_nodes);
-    uint32_t *SA = reinterpret_cast<uint32_t *>(scratch);            // [kSortTile] record slot of a
-    uint32_t *SB = SA + kSortTile;                                   // [kSortTile] record slot of b
-    uint32_t *HIST = SB + kSortTile;                                 // [kSortBuckets] counts, then exclusive starts
+    uint32_t *HIST = reinterpret_cast<uint32_t *>(scratch);          // [kSortBuckets] counts, then exclusive starts
     uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
     uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
 
@@ -651,8 +664,6 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 } else {
                     const long long sa = record_slot(a, parity, P.n_leaves);
                     const long long sb = record_slot(b, parity, P.n_leaves);
-                    SA[j] = (uint32_t)sa;
-                    SB[j] = (uint32_t)sb;
                     const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
                     const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
                     const uint32_t da = cdep[pa], db = cdep[pb];
@@ -688,49 +699,19 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
             if (key[q] != 0xFFFFFFFFu) PERM[HIST[key[q]] + rank[q]] = (uint16_t)((int)threadIdx.x + q * kCanopyBlock);
         __syncthreads();
         const uint32_t total = WSUM[4];
-        // wave w: sorted groups w (short pairs) and, with two groups per wave, 31 - w (long pairs)
+        // wave w: sorted groups w, 31 - w, 32 + w, 63 - w (short pairs with long pairs)
 #pragma unroll 1
         for (int q = 0; q < Q; q++) {
-            const uint32_t pos = (uint32_t)((q == 0 ? wave : 31 - wave) * 64 + lane);
+            const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
             if (pos >= total) continue;
             const int j = PERM[pos];
-            const long long sa = SA[j], sb = SB[j];
-            const uint8_t *rb = P.rec_b + sb * half;
-            const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-            const uint32_t wa = va.x;
-            const float pbot_a = __uint_as_float(va.y);
-            uint32_t wb;
-            float Db[CAP > 0 ? CAP : 1];
-            if (CAP == 1) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(rb);
-                wb = v.x;
-                Db[0] = __uint_as_float(v.y);
-            } else if (CAP > 1) {
-                uint32_t w[CAP + 1];
-#pragma unroll
-                for (int x = 0; x < (CAP + 1) / 4; x++) {
-                    const uint4 v = reinterpret_cast<const uint4 *>(rb)[x];
-                    w[4 * x + 0] = v.x; w[4 * x + 1] = v.y; w[4 * x + 2] = v.z; w[4 * x + 3] = v.w;
-                }
-                wb = w[0];
-#pragma unroll
-                for (int x = 0; x < CAP; x++) Db[x] = __uint_as_float(w[x + 1]);
-            } else {
-                wb = *reinterpret_cast<const uint32_t *>(rb);
-                Db[0] = 0.0f;
-            }
-            const uint32_t pa = wa & 0xFFFFu, pb = wb & 0xFFFFu;
-            PairResult r;
-            if (pa != pb) {
-                const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
-                r = pair_ladder_split<CAP>(lad, cdep, P.canopy_id, pa, pbot_a, pb, dptr, wb >> 16);
-            } else {
-                const RecTables R{P.rec_a, P.rec_b, P.rec_i, half};
-                r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
-            }
+            long long a, b;
+            src.load(base + j, a, b);     // (the tile was read a moment ago: an L2 hit; validated then)
+            const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+            const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes);
             store_result(out_d, out_m, base + j, r.dist, r.mrca);
         }
-        __syncthreads();     // the next tile overwrites SA / SB / PERM
+        __syncthreads();     // the next tile overwrites PERM
     }
 }
 
@@ -928,9 +909,9 @@ static size_t canopy_lds_bytes(const st_tree *t)
 template <typename Kern, typename Src>
 static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
                                   const Src &src, int64_t n, DistSink out_d, int32_t *out_m,
-                                  Fault *fault, hipStream_t stream)
+                                  Fault *fault, hipStream_t stream, size_t lds = 0)
 {
-    const size_t lds = canopy_lds_bytes(t);
+    if (lds == 0) lds = canopy_lds_bytes(t);
     if (lds > 64 * 1024) {
         // dynamic LDS above 64 KiB has to be granted per kernel (cheap host-side call)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -948,16 +929,21 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     return hipGetLastError();
 }
 
-// pairs per lane of the tile-sorted kernel: 2 when the scratch fits next to the canopy image
-// (in half the LDS if possible: two workgroups per CU), else 1; 0 = does not fit at all
+// pairs per lane of the tile-sorted kernel: 2 when image + scratch fit half the LDS (two
+// workgroups per CU), else 4 with one workgroup per CU; 0 = the ladder image does not fit
 static int sorted_q(const st_tree *t)
 {
     const size_t image = ladder_image_bytes(t->canopy_nodes);
+    static const int forced = std::getenv("SUCHTREE_AMD_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_SORT_Q")) : 0;   // tuning experiments
+    if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced) <= 160 * 1024) return forced;
     if (image + sort_scratch_bytes(2) <= 80 * 1024) return 2;
-    if (image + sort_scratch_bytes(1) <= 80 * 1024) return 1;
-    if (image + sort_scratch_bytes(2) <= 160 * 1024) return 2;
-    if (image + sort_scratch_bytes(1) <= 160 * 1024) return 1;
+    if (image + sort_scratch_bytes(4) <= 160 * 1024) return 4;
     return 0;
+}
+
+static bool wants_device_stage(const st_tree *t, int64_t m)
+{
+    return t->strategy == ST_STRATEGY_CANOPY && t->tile_sort && m >= 4096 && sorted_q(t) > 0;
 }
 
 template <int CAP, typename Src>
@@ -982,7 +968,7 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
                            (long long)n, out_d, out_m, fault, key_shift);
         return hipGetLastError();
     };
-    return q == 2 ? go(k_canopy_sorted<CAP, 2, Src>) : go(k_canopy_sorted<CAP, 1, Src>);
+    return q == 2 ? go(k_canopy_sorted<CAP, 2, Src>) : go(k_canopy_sorted<CAP, 4, Src>);
 }
 
 template <int CAP, typename Src>
@@ -1127,8 +1113,10 @@ constexpr int64_t kMailboxPairs = 2048;   // largest batch served through the ma
 // several devices the chunk shrinks (down to kHostChunkMin) so that every device gets work.
 static int64_t host_chunk_pairs(int64_t n, int n_dev)
 {
-    if (n_dev <= 1) return std::max<int64_t>(std::min<int64_t>(n, kHostChunk), 1);
-    int64_t chunk = (n + 2 * (int64_t)n_dev - 1) / (2 * (int64_t)n_dev);   // two rounds per device
+    if (n <= kHostChunkMin) return std::max<int64_t>(n, 1);
+    // at least eight chunks per device, so that packing, the link and unpacking overlap even
+    // on batches of a few million pairs; never below kHostChunkMin, never above kHostChunk
+    int64_t chunk = (n + 8 * (int64_t)n_dev - 1) / (8 * (int64_t)n_dev);
     chunk = std::min(std::max(chunk, kHostChunkMin), kHostChunk);
     return (chunk + 1023) / 1024 * 1024;
 }
@@ -1187,6 +1175,51 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
     ST_HIP(hipStreamSynchronize(t->mb_stream));
     if (out_dist) std::memcpy(out_dist, h_dist, (size_t)n * 8);
     if (out_mrca) std::memcpy(out_mrca, h_mrca, (size_t)n * 4);
+    return ST_OK;
+}
+
+// Coalesced word copy between pinned host memory and device memory (either direction).
+__global__ __launch_bounds__(1024) void k_words_copy(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, long long n_words)
+{
+    const long long n4 = n_words >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) dst[i] = src[i];
+}
+
+static hipError_t enqueue_words_copy(const void *src, void *dst, int64_t n_words, hipStream_t stream)
+{
+    if (n_words <= 0) return hipSuccess;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n_words / 4 + 1023) / 1024, 512));
+    hipLaunchKernelGGL(k_words_copy, dim3((unsigned)blocks), dim3(1024), 0, stream, static_cast<const uint32_t *>(src),
+                       static_cast<uint32_t *>(dst), (long long)n_words);
+    return hipGetLastError();
+}
+
+// The tile-sorted kernel reads every pair twice and stores results in sorted order: fine in
+// HBM, ruinous over PCIe (scattered 4-byte writes).  For trees that use it the host path keeps
+// the slot in device memory and moves it with the copy kernel above.
+static bool wants_device_stage(const st_tree *t, int64_t m);
+
+// One chunk of a host-path call on slot s: `make_src(in)` builds the pair source from the
+// chunk's input pointer (NULL for generated sources), results go to the slot's pinned arrays.
+template <typename MakeSrc>
+static int launch_chunk(st_tree *r, PipeSlot &s, int64_t m, int in_words_per_pair, bool want_d, bool want_m,
+                        MakeSrc make_src)
+{
+    if (!wants_device_stage(r, m))
+        return enqueue_src(r, make_src(s.h_in), m, DistSink{nullptr, want_d ? static_cast<float *>(s.h_d) : nullptr},
+                           want_m ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+    hipError_t e = r->dp->pipe.ensure_device_stage();
+    if (e == hipSuccess && in_words_per_pair) e = enqueue_words_copy(s.h_in, s.d_in, m * in_words_per_pair, s.stream);
+    if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
+    const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, want_d ? static_cast<float *>(s.d_d) : nullptr},
+                               want_m ? static_cast<int32_t *>(s.d_m) : nullptr, r->d_fault_host, s.stream);
+    if (rc != ST_OK) return rc;
+    if (want_d) e = enqueue_words_copy(s.d_d, s.h_d, m, s.stream);
+    if (e == hipSuccess && want_m) e = enqueue_words_copy(s.d_m, s.h_m, m, s.stream);
+    if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     return ST_OK;
 }
 
@@ -1701,9 +1734,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
             });
         };
         auto launch = [&](PipeSlot &s, int64_t, int64_t m) {
-            return enqueue_src(r, SrcContig32{static_cast<const int *>(s.h_in)}, m,
-                               DistSink{nullptr, out_dist ? static_cast<float *>(s.h_d) : nullptr},
-                               out_mrca ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+            return launch_chunk(r, s, m, 2, out_dist != nullptr, out_mrca != nullptr,
+                                [](const void *in) { return SrcContig32{static_cast<const int *>(in)}; });
         };
         {   // (the pipe may not exist yet: ensure() inside run_pipe creates the streams)
             const hipError_t e = r->dp->pipe.ensure(std::max<int64_t>(seq.chunk, 1024));
@@ -1794,8 +1826,7 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
         auto pack = [](PipeSlot &, int64_t, int64_t) {};
         auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
             const SrcTriangle src{static_cast<const long long *>(P.d_ids), 1, (long long)(k_begin + off)};
-            return enqueue_src(r, src, c, DistSink{nullptr, out_dist ? static_cast<float *>(s.h_d) : nullptr},
-                               out_mrca ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+            return launch_chunk(r, s, c, 0, out_dist != nullptr, out_mrca != nullptr, [&](const void *) { return src; });
         };
         const int rc2 = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
         if (rc2 != ST_OK) return rc2;
@@ -1843,8 +1874,7 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
         auto pack = [](PipeSlot &, int64_t, int64_t) {};
         auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
             const SrcGrid src{d_rows, d_cols, (long long)n_cols, (long long)(e_begin + off), symmetric};
-            return enqueue_src(r, src, c, DistSink{nullptr, out_dist ? static_cast<float *>(s.h_d) : nullptr},
-                               out_mrca ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+            return launch_chunk(r, s, c, 0, out_dist != nullptr, out_mrca != nullptr, [&](const void *) { return src; });
         };
         const int rc2 = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
         if (rc2 != ST_OK) return rc2;
