@@ -256,6 +256,18 @@ int st_newick_fill(const st_newick *h, int32_t *parent, int32_t *left, int32_t *
                    int64_t *name_offsets);
 void st_newick_close(st_newick *h);
 
+/*
+ * Pinned, GPU-addressable host memory for result arrays.  The "_host" entry points recognise
+ * result arrays that live in such memory (these blocks, hipHostRegister-ed memory, pinned torch
+ * tensors) and let the kernels write the float64 distances / int32 MRCA ids straight into them:
+ * no staging slot, no unpack pass on the CPU, no page faults on first touch and no page
+ * teardown when the array is released.  suchtree_amd hands its numpy results out of a
+ * recycled pool of these blocks (the reference allocates a fresh numpy array per call,
+ * SuchTree/MuchTree.pyx:906-907).
+ */
+int st_host_alloc(int64_t bytes, void **out);
+int st_host_free(void *ptr);
+
 /* Thin device-memory helpers so callers without torch can stage buffers. */
 int st_device_malloc(int device, int64_t bytes, void **out);
 int st_device_free(int device, void *ptr);

@@ -38,6 +38,24 @@ def main():
         best = min(best, time.perf_counter() - t0)
         del r
     out["fresh_dist_only_pairs_per_s"] = n / best
+    pooled = _capi.DeviceTree(parent, dist, pinned_results=True)
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        r = pooled.distances_host(pairs, True, True)       # result arrays from the pinned pool, written directly
+        best = min(best, time.perf_counter() - t0)
+        del r
+    out["pinned_pool_pairs_per_s"] = n / best
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r = tree.distances_host(pairs, True, True)
+        del r                                              # the caller's side of a fresh array: freeing it
+    out["fresh_incl_free_pairs_per_s"] = 3 * n / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r = pooled.distances_host(pairs, True, True)
+        del r
+    out["pinned_pool_incl_free_pairs_per_s"] = 3 * n / (time.perf_counter() - t0)
     p32 = pairs.astype(np.int32)
     t0 = time.perf_counter()
     tree.distances_host(p32, True, True, out_dist=h_d, out_mrca=h_m)

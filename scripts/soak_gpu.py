@@ -53,12 +53,35 @@ def main():
                 if rng.random() < 0.3:
                     dev.set_option("pairs_per_lane", int(rng.choice([0, 1, 2])))
                     dev.set_option("small_batch_path", int(rng.integers(0, 2)))
+                    if k == 0:
+                        dev.set_option("tile_sort", int(rng.integers(0, 2)))
+                if rng.random() < 0.2:
+                    view = np.ascontiguousarray(view).astype(np.int32)      # the int32 entry point
                 d, m = dev.distances_host(view, want_d, want_m)
-                s = min(n, 20000)
-                if want_d and not np.array_equal(d[:s].view(np.int64), O.distances(pairs[:s]).view(np.int64)):
-                    errors.append("dist mismatch tree %d n %d layout %d" % (k, n, layout))
-                if want_m and not np.array_equal(m[:s], O.mrca_bulk(pairs[:s])):
-                    errors.append("mrca mismatch tree %d n %d layout %d" % (k, n, layout))
+                # the head, the tail and a random window of the batch
+                for lo in {0, max(0, n - 20000), int(rng.integers(0, max(1, n - 20000)))}:
+                    hi = min(n, lo + 20000)
+                    if want_d and not np.array_equal(d[lo:hi].view(np.int64), O.distances(pairs[lo:hi]).view(np.int64)):
+                        errors.append("dist mismatch tree %d n %d layout %d at %d" % (k, n, layout, lo))
+                    if want_m and not np.array_equal(m[lo:hi], O.mrca_bulk(pairs[lo:hi])):
+                        errors.append("mrca mismatch tree %d n %d layout %d at %d" % (k, n, layout, lo))
+                if rng.random() < 0.15:
+                    # the generated sources: a slice of the triangle and of a symmetric grid
+                    ids = rng.choice(n_nodes, size=int(rng.integers(2, 900)), replace=False).astype(np.int64)
+                    mm = len(ids)
+                    total = mm * (mm - 1) // 2
+                    k0 = int(rng.integers(0, total))
+                    cnt = int(rng.integers(1, total - k0 + 1))
+                    td, _ = dev.triangle_host(ids, k_begin=k0, k_count=cnt)
+                    ii, jj = np.tril_indices(mm, -1)
+                    tp = np.stack([ids[jj[k0:k0 + cnt]], ids[ii[k0:k0 + cnt]]], 1)
+                    if not np.array_equal(td.view(np.int64), O.distances(tp).view(np.int64)):
+                        errors.append("triangle mismatch tree %d m %d k0 %d cnt %d" % (k, mm, k0, cnt))
+                    gd, _ = dev.grid_host(ids, ids, symmetric=True)
+                    r, c = np.divmod(np.arange(mm * mm), mm)
+                    gp = np.stack([ids[np.minimum(r, c)], ids[np.maximum(r, c)]], 1)
+                    if not np.array_equal(gd.view(np.int64), O.distances(gp).view(np.int64)):
+                        errors.append("grid mismatch tree %d m %d" % (k, mm))
                 if n > 10 and rng.random() < 0.1:
                     bad = pairs.copy()
                     bad[int(rng.integers(0, n)), int(rng.integers(0, 2))] = n_nodes + 3

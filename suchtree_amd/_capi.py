@@ -25,7 +25,7 @@ SYMBOLS = (
     "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
-    "st_host_depths", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
+    "st_host_depths", "st_host_alloc", "st_host_free", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
 
@@ -167,6 +167,8 @@ def load():
         L.st_newick_close.argtypes = [vp]
         L.st_newick_close.restype = None
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
+        L.st_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
+        L.st_host_free.argtypes = [vp]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
         L.st_device_free.argtypes = [i32, vp]
         L.st_memcpy_h2d.argtypes = [i32, vp, vp, i64]
@@ -263,6 +265,99 @@ def host_chunk_map(n, n_devices):
     return out
 
 
+class _Lent:
+    """A pinned block on loan to one numpy array (its ``base``); goes back to the pool when the
+    array and every view of it are gone."""
+
+    def __init__(self, pool, ptr, capacity, n, dtype):
+        self._pool, self._ptr, self._capacity = pool, ptr, capacity
+        self.__array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": np.dtype(dtype).str, "version": 3}
+
+    def __del__(self):
+        try:
+            self._pool._give_back(self._ptr, self._capacity)
+        except Exception:     # interpreter shutdown
+            pass
+
+
+class ResultPool:
+    """Recycled pinned, GPU-addressable blocks (``st_host_alloc``) for result arrays.
+
+    A result array that lives in such a block is written by the kernels directly over PCIe:
+    no staging slot, no unpack pass on the CPU, no page faults on first touch and no page
+    teardown when it is released -- for batches of 1e6-1e8 pairs those cost as much as the
+    computation (``scripts/thp_probe.py``).  OPT-IN (``SuchTree(..., pinned_results=True)`` or
+    ``SUCHTREE_AMD_PINNED_RESULTS=1``) because of one behavioural difference: pinned memory is
+    not inherited by ``fork()`` children (the driver marks it DONTFORK), so a result array
+    handed to a fork-pool worker is unreadable there; ordinary numpy arrays are.
+    ``budget_bytes`` caps what the pool keeps pinned; beyond it callers get ordinary arrays.
+    """
+
+    MIN_BYTES = 1 << 20
+
+    def __init__(self, budget_bytes=None):
+        if budget_bytes is None:
+            budget_bytes = int(os.environ.get("SUCHTREE_AMD_RESULT_POOL_MB", "4096")) << 20
+        self.budget = int(budget_bytes)
+        self.total = 0
+        self._free = {}
+        self._lock = threading.Lock()
+        self._pid = os.getpid()
+
+    @staticmethod
+    def _size_class(nbytes):
+        cap = 1 << 21
+        while cap < nbytes and cap < (1 << 26):
+            cap <<= 1
+        if cap < nbytes:                                   # beyond 64 MiB: multiples of 64 MiB
+            cap = (nbytes + (1 << 26) - 1) >> 26 << 26
+        return cap
+
+    def array(self, n, dtype):
+        """A 1-D array of ``n`` items in a pinned block, or None (too small, over budget, no GPU)."""
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        if nbytes < self.MIN_BYTES or self._pid != os.getpid():
+            return None
+        cap = self._size_class(nbytes)
+        with self._lock:
+            stack = self._free.get(cap)
+            ptr = stack.pop() if stack else None
+            if ptr is None:
+                if self.total + cap > self.budget:
+                    return None
+                p = ctypes.c_void_p()
+                if load().st_host_alloc(cap, ctypes.byref(p)) != ST_OK or not p.value:
+                    return None
+                ptr = p.value
+                self.total += cap
+        return np.asarray(_Lent(self, ptr, cap, int(n), dtype))
+
+    def _give_back(self, ptr, cap):
+        if self._pid != os.getpid():       # a forked child must not touch the parent's HIP state
+            return
+        with self._lock:
+            self._free.setdefault(cap, []).append(ptr)
+
+    def trim(self):
+        """Unpin every block that is not on loan."""
+        with self._lock:
+            free, self._free = self._free, {}
+        for cap, ptrs in free.items():
+            for ptr in ptrs:
+                load().st_host_free(ctypes.c_void_p(ptr))
+                self.total -= cap
+
+
+_result_pool = None
+
+
+def result_pool():
+    global _result_pool
+    if _result_pool is None or _result_pool._pid != os.getpid():
+        _result_pool = ResultPool()
+    return _result_pool
+
+
 def device_count():
     c = ctypes.c_int(0)
     rc = load().st_device_count(ctypes.byref(c))
@@ -280,8 +375,11 @@ class DeviceTree:
     ``devices=[...]`` -- replicated on several GPUs of the node (``st_tree_create_multi``),
     the host-buffer entry points then dealing their chunks over all of them."""
 
-    def __init__(self, parent, distance, device=0, strategy="auto", devices=None):
+    def __init__(self, parent, distance, device=0, strategy="auto", devices=None, pinned_results=None):
         global _gpu_pid
+        if pinned_results is None:
+            pinned_results = os.environ.get("SUCHTREE_AMD_PINNED_RESULTS", "0") == "1"
+        self.pinned_results = bool(pinned_results)
         _check_fork()
         L = load()
         self._lib = L
@@ -343,11 +441,14 @@ class DeviceTree:
     def set_option(self, name, value):
         check(self._lib.st_tree_set_option(self.handle, name.encode(), int(value)))
 
-    @staticmethod
-    def _out(buf, n, dtype, want):
+    def _out(self, buf, n, dtype, want):
         if not want:
             return None
         if buf is None:
+            if self.pinned_results:
+                arr = result_pool().array(n, dtype)
+                if arr is not None:
+                    return arr
             return np.empty(n, dtype=dtype)
         if buf.dtype != dtype or buf.shape != (n,) or not buf.flags.c_contiguous:
             raise ValueError("output buffer must be a contiguous %s array of shape (%d,)" % (np.dtype(dtype).name, n))

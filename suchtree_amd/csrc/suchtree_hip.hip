@@ -1197,6 +1197,48 @@ static hipError_t enqueue_words_copy(const void *src, void *dst, int64_t n_words
     return hipGetLastError();
 }
 
+// float32 (device) -> float64 (pinned host), coalesced: the staged form of a direct result write
+__global__ __launch_bounds__(1024) void k_widen_copy(const float *__restrict__ src, double *__restrict__ dst, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (double)src[i];
+}
+
+// Is [p, p + bytes) pinned host memory the GPU can address (hipHostMalloc / hipHostRegister)?
+// Result arrays like that -- st_host_alloc blocks, pinned torch tensors -- are written by the
+// kernels directly: no staging slot, no unpack pass, no page faults.
+static bool device_visible_host(const void *p, int64_t bytes)
+{
+    if (!p || bytes <= 0) return false;
+    for (const char *q : {static_cast<const char *>(p), static_cast<const char *>(p) + bytes - 1}) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (attr.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+// Where the results of a host-path call go: the caller's arrays, and whether the kernels can
+// write each of them directly.
+struct HostOut {
+    double *dist = nullptr;
+    int32_t *mrca = nullptr;
+    bool direct_d = false, direct_m = false;
+};
+
+static HostOut make_host_out(double *out_dist, int32_t *out_mrca, int64_t n)
+{
+    HostOut o;
+    o.dist = out_dist;
+    o.mrca = out_mrca;
+    o.direct_d = device_visible_host(out_dist, n * 8);
+    o.direct_m = device_visible_host(out_mrca, n * 4);
+    return o;
+}
+
 // The tile-sorted kernel reads every pair twice and stores results in sorted order: fine in
 // HBM, ruinous over PCIe (scattered 4-byte writes).  For trees that use it the host path keeps
 // the slot in device memory and moves it with the copy kernel above.
@@ -1205,20 +1247,32 @@ static bool wants_device_stage(const st_tree *t, int64_t m);
 // One chunk of a host-path call on slot s: `make_src(in)` builds the pair source from the
 // chunk's input pointer (NULL for generated sources), results go to the slot's pinned arrays.
 template <typename MakeSrc>
-static int launch_chunk(st_tree *r, PipeSlot &s, int64_t m, int in_words_per_pair, bool want_d, bool want_m,
+static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_words_per_pair, const HostOut &out,
                         MakeSrc make_src)
 {
-    if (!wants_device_stage(r, m))
-        return enqueue_src(r, make_src(s.h_in), m, DistSink{nullptr, want_d ? static_cast<float *>(s.h_d) : nullptr},
-                           want_m ? static_cast<int32_t *>(s.h_m) : nullptr, r->d_fault_host, s.stream);
+    if (!wants_device_stage(r, m)) {
+        DistSink sink{nullptr, nullptr};
+        if (out.dist) {
+            if (out.direct_d) sink.d64 = out.dist + off;
+            else sink.f32 = static_cast<float *>(s.h_d);
+        }
+        int32_t *mrca = !out.mrca ? nullptr : out.direct_m ? out.mrca + off : static_cast<int32_t *>(s.h_m);
+        return enqueue_src(r, make_src(s.h_in), m, sink, mrca, r->d_fault_host, s.stream);
+    }
     hipError_t e = r->dp->pipe.ensure_device_stage();
     if (e == hipSuccess && in_words_per_pair) e = enqueue_words_copy(s.h_in, s.d_in, m * in_words_per_pair, s.stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
-    const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, want_d ? static_cast<float *>(s.d_d) : nullptr},
-                               want_m ? static_cast<int32_t *>(s.d_m) : nullptr, r->d_fault_host, s.stream);
+    const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, out.dist ? static_cast<float *>(s.d_d) : nullptr},
+                               out.mrca ? static_cast<int32_t *>(s.d_m) : nullptr, r->d_fault_host, s.stream);
     if (rc != ST_OK) return rc;
-    if (want_d) e = enqueue_words_copy(s.d_d, s.h_d, m, s.stream);
-    if (e == hipSuccess && want_m) e = enqueue_words_copy(s.d_m, s.h_m, m, s.stream);
+    if (out.dist && out.direct_d) {
+        hipLaunchKernelGGL(k_widen_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, 512))),
+                           dim3(1024), 0, s.stream, static_cast<const float *>(s.d_d), out.dist + off, (long long)m);
+        e = hipGetLastError();
+    } else if (out.dist) {
+        e = enqueue_words_copy(s.d_d, s.h_d, m, s.stream);
+    }
+    if (e == hipSuccess && out.mrca) e = enqueue_words_copy(s.d_m, out.direct_m ? static_cast<void *>(out.mrca + off) : s.h_m, m, s.stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     return ST_OK;
 }
@@ -1226,12 +1280,15 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t m, int in_words_per_pai
 // Push this device's chunks of a batch through the two-slot pipe (host_pipe.h).
 // pack(slot, off, m) fills slot.h_in for chunk [off, off+m); launch(slot, off, m) enqueues
 // the kernel on slot.stream, reading slot.h_in and writing slot.h_d / slot.h_m -- pinned
-// host memory, accessed by the kernel over PCIe (see host_pipe.h).  Caller holds the device
-// pipe's mutex.
+// host memory, accessed by the kernel over PCIe (see host_pipe.h) -- or, where the caller's
+// own result array is pinned (HostOut::direct_*), that array itself.  Caller holds the
+// device pipe's mutex.
 template <typename Pack, typename Launch>
-static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch,
-                    double *out_dist, int32_t *out_mrca)
+static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, const HostOut &out)
 {
+    // results the kernels write directly need neither unpacking nor pre-faulting
+    double *const out_dist = out.direct_d ? nullptr : out.dist;
+    int32_t *const out_mrca = out.direct_m ? nullptr : out.mrca;
     HostPipe &P = t->dp->pipe;
     {
         const hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
@@ -1691,9 +1748,10 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
         ST_DEVICE(t->device);
         return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
     }
+    const HostOut out = make_host_out(out_dist, out_mrca, n);
     // fresh result arrays: ask for huge pages before the first touch (a no-op on resident memory)
-    if (out_dist) advise_huge(out_dist, n * 8);
-    if (out_mrca) advise_huge(out_mrca, n * 4);
+    if (out_dist && !out.direct_d) advise_huge(out_dist, n * 8);
+    if (out_mrca && !out.direct_m) advise_huge(out_mrca, n * 4);
 
     // Ids cross PCIe as int32 (half the H2D bytes).  Values that do not fit are clamped to
     // INT32_MAX / INT32_MIN -- still out of range for the kernel -- and their exact extremes
@@ -1733,8 +1791,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
                 }
             });
         };
-        auto launch = [&](PipeSlot &s, int64_t, int64_t m) {
-            return launch_chunk(r, s, m, 2, out_dist != nullptr, out_mrca != nullptr,
+        auto launch = [&](PipeSlot &s, int64_t off, int64_t m) {
+            return launch_chunk(r, s, off, m, 2, out,
                                 [](const void *in) { return SrcContig32{static_cast<const int *>(in)}; });
         };
         {   // (the pipe may not exist yet: ensure() inside run_pipe creates the streams)
@@ -1745,7 +1803,7 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
         // a fresh word for this call (an earlier call that failed half-way may have left it set)
         ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
         ST_HIP(hipStreamSynchronize(s0));
-        int rc = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
+        int rc = run_pipe(r, seq, pack, launch, out);
         if (rc != ST_OK) return rc;
         rc = fetch_fault(r->d_fault_host, s0, fault);
         if (rc != ST_OK) return rc;
@@ -1804,8 +1862,9 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
-    if (out_dist) advise_huge(out_dist, k_count * 8);
-    if (out_mrca) advise_huge(out_mrca, k_count * 4);
+    const HostOut out = make_host_out(out_dist, out_mrca, k_count);
+    if (out_dist && !out.direct_d) advise_huge(out_dist, k_count * 8);
+    if (out_mrca && !out.direct_m) advise_huge(out_mrca, k_count * 4);
     // the id list goes up once per device (packed); results stream back through the pipe
     std::vector<int64_t> packed;
     const int64_t *src_ids = ids;
@@ -1826,9 +1885,9 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
         auto pack = [](PipeSlot &, int64_t, int64_t) {};
         auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
             const SrcTriangle src{static_cast<const long long *>(P.d_ids), 1, (long long)(k_begin + off)};
-            return launch_chunk(r, s, c, 0, out_dist != nullptr, out_mrca != nullptr, [&](const void *) { return src; });
+            return launch_chunk(r, s, off, c, 0, out, [&](const void *) { return src; });
         };
-        const int rc2 = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
+        const int rc2 = run_pipe(r, seq, pack, launch, out);
         if (rc2 != ST_OK) return rc2;
         return fetch_fault(r->d_fault_host, s0, fault);
     };
@@ -1858,8 +1917,9 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
     if (rc != ST_OK) return rc;
     if (symmetric && (n_rows != n_cols)) return fail(ST_ERR_ARG, "symmetric grid needs n_rows == n_cols");
     if (e_count == 0) return ST_OK;
-    if (out_dist) advise_huge(out_dist, e_count * 8);
-    if (out_mrca) advise_huge(out_mrca, e_count * 4);
+    const HostOut out = make_host_out(out_dist, out_mrca, e_count);
+    if (out_dist && !out.direct_d) advise_huge(out_dist, e_count * 8);
+    if (out_mrca && !out.direct_m) advise_huge(out_mrca, e_count * 4);
     auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
         HostPipe &P = r->dp->pipe;
         hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
@@ -1874,9 +1934,9 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
         auto pack = [](PipeSlot &, int64_t, int64_t) {};
         auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
             const SrcGrid src{d_rows, d_cols, (long long)n_cols, (long long)(e_begin + off), symmetric};
-            return launch_chunk(r, s, c, 0, out_dist != nullptr, out_mrca != nullptr, [&](const void *) { return src; });
+            return launch_chunk(r, s, off, c, 0, out, [&](const void *) { return src; });
         };
-        const int rc2 = run_pipe(r, seq, pack, launch, out_dist, out_mrca);
+        const int rc2 = run_pipe(r, seq, pack, launch, out);
         if (rc2 != ST_OK) return rc2;
         return fetch_fault(r->d_fault_host, s0, fault);
     };
@@ -2056,6 +2116,21 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
     if (e == hipSuccess && out_laplacian) e = hipMemcpy(out_laplacian, d_L, mat, hipMemcpyDeviceToHost);
     (void)hipFree(ws);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("graph matrices: ") + hipGetErrorString(e));
+    return ST_OK;
+}
+
+int st_host_alloc(int64_t bytes, void **out)
+{
+    if (!out || bytes < 0) return fail(ST_ERR_ARG, "bad arguments");
+    *out = nullptr;
+    // portable: addressable by every GPU of the process (multi-device handles write into it too)
+    ST_HIP(hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocPortable));
+    return ST_OK;
+}
+
+int st_host_free(void *ptr)
+{
+    if (ptr) ST_HIP(hipHostFree(ptr));
     return ST_OK;
 }
 

@@ -45,9 +45,13 @@ class SuchTree:
     the bulk methods taking host arrays (``distances_bulk``, ``pairwise_distances``, ...) deal
     their work over every listed GPU from this one process.
     ``strategy``: ``'auto'`` | ``'canopy'`` | ``'walk'`` kernel family.
+    ``pinned_results``: hand bulk results out of a recycled pool of pinned, GPU-addressable
+    memory that the kernels write directly (no unpack pass, no page faults, no page teardown;
+    see ``_capi.ResultPool``).  Off by default: such arrays cannot be read by ``fork()`` children.
     """
 
-    def __init__(self, tree_input, device: int = 0, strategy: str = "auto", devices=None):
+    def __init__(self, tree_input, device: int = 0, strategy: str = "auto", devices=None,
+                 pinned_results=None):
         self._epsilon = EPSILON
         if isinstance(tree_input, FlatTree):
             flat = tree_input
@@ -77,6 +81,7 @@ class SuchTree:
         if strategy not in _capi.STRATEGY:
             raise ValueError("strategy must be one of %s" % sorted(_capi.STRATEGY))
         self._strategy = strategy
+        self._pinned_results = pinned_results
         self._dev_tree = None
 
     # ------------------------------------------------------------------ device
@@ -90,7 +95,7 @@ class SuchTree:
         if self._dev_tree is None:
             self._dev_tree = _capi.DeviceTree(self._flat.parent, self._flat.distance,
                                               device=self._device, strategy=self._strategy,
-                                              devices=self._devices)
+                                              devices=self._devices, pinned_results=self._pinned_results)
         return self._dev_tree
 
     def to_device(self) -> "SuchTree":

@@ -16,6 +16,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
+def ml_arrays():
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ml_tree.npz"))
+    return z["parent"], z["distance"]
+
+
+@pytest.fixture(scope="module")
 def tree17():
     parent, dist = synth.balanced_tree(17)
     return parent, dist, OracleTree(parent, dist)
@@ -138,3 +144,69 @@ def test_two_trees_share_one_staging_pipe(tree17):
     assert_bits_equal(db[:100_000], OracleTree(p2, d2).distances(pb[:100_000]))
     A.close()
     assert_bits_equal(B.distances_bulk(pb), db)        # the pipe outlives the first tree
+
+
+def test_pinned_result_arrays_are_written_directly_and_recycled(tree17, ml_arrays):
+    """Opt-in result pool: numpy results in pinned, GPU-addressable blocks that the kernels write
+    directly (float64 + int32, no unpack pass); blocks are recycled once the arrays are gone."""
+    import gc
+    parent, dist, O = tree17
+    rng = np.random.default_rng(15)
+    pool = _capi.result_pool()
+    for (p, d, oracle) in ((parent, dist, O), (ml_arrays[0], ml_arrays[1], OracleTree(ml_arrays[0], ml_arrays[1]))):
+        T = SuchTree((p, d), pinned_results=True)          # ml.tree: the device-staged (tile-sorted) form
+        pairs = rng.integers(0, len(p), (3_000_001, 2))
+        d1, m1 = T.distances_and_ancestors_bulk(pairs)
+        assert type(d1.base).__name__ == "_Lent" and type(m1.base).__name__ == "_Lent"
+        k = 300_000
+        assert_bits_equal(d1[:k], oracle.distances(pairs[:k]))
+        assert_bits_equal(d1[-k:], oracle.distances(pairs[-k:]))
+        assert np.array_equal(m1[-k:], oracle.mrca_bulk(pairs[-k:]))
+        d2 = T.distances_bulk(pairs[::-1])                 # a second block while the first is alive
+        assert d2.ctypes.data != d1.ctypes.data
+        assert_bits_equal(d2[:k], oracle.distances(pairs[::-1][:k]))
+        assert_bits_equal(d1[:k], oracle.distances(pairs[:k]))           # untouched by the second call
+        d1[0] = 42.0                                        # an ordinary writable array
+        ptr = d1.ctypes.data
+        view = d1[5:50]
+        del d1
+        gc.collect()
+        d3 = T.distances_bulk(pairs[:2_999_000])
+        assert d3.ctypes.data != ptr                        # the view still holds the block
+        del view, d3
+        gc.collect()
+        d4 = T.distances_bulk(pairs)
+        assert d4.ctypes.data in (ptr, d2.ctypes.data) or pool.total > 0
+        assert_bits_equal(d4[:k], oracle.distances(pairs[:k]))
+        small = T.distances_bulk(pairs[:1000])              # below the pool's minimum: ordinary array
+        assert type(small.base).__name__ != "_Lent"
+        tri, _ = T._device_tree().triangle_host(np.arange(0, 6000, 2, dtype=np.int64))
+        i, j = np.tril_indices(3000, -1)
+        sel = rng.integers(0, len(i), 200_000)
+        ids = np.arange(0, 6000, 2)
+        assert_bits_equal(tri[sel], oracle.distances(np.stack([ids[j[sel]], ids[i[sel]]], 1)))
+        T.close()
+    del d2, d4, m1, tri
+    gc.collect()
+    pool.trim()
+    assert pool.total == 0 or pool.total < (1 << 30)
+
+
+def test_caller_supplied_pinned_outputs_take_the_direct_path(tree17):
+    import torch
+    parent, dist, O = tree17
+    dev = SuchTree((parent, dist)).to_device()._device_tree()
+    pairs = np.random.default_rng(16).integers(0, len(parent), (2_500_000, 2))
+    out_d = torch.empty(len(pairs) + 3, dtype=torch.float64).pin_memory()
+    out_m = torch.empty(len(pairs), dtype=torch.int32)                 # pageable: mixed modes in one call
+    out_d.fill_(-1.0)
+    dev.distances_host(pairs, True, True, out_dist=out_d.numpy()[3:], out_mrca=out_m.numpy())
+    assert out_d[:3].tolist() == [-1.0, -1.0, -1.0]
+    assert_bits_equal(out_d.numpy()[3:][:400_000], O.distances(pairs[:400_000]))
+    assert_bits_equal(out_d.numpy()[3:][-400_000:], O.distances(pairs[-400_000:]))
+    assert np.array_equal(out_m.numpy()[-400_000:], O.mrca_bulk(pairs[-400_000:]))
+    bad = pairs.copy()
+    bad[77, 0] = -5
+    with pytest.raises(InvalidNodeError) as e:
+        dev.distances_host(bad, True, False, out_dist=out_d.numpy()[3:])
+    assert e.value.node_id == -5

@@ -388,6 +388,32 @@ def test_general_trees_through_the_c_abi():
         dev.close()
 
 
+def test_batch_sizes_around_kernel_tile_boundaries(ml_arrays):
+    """Batch lengths at and around every granule the launch code knows: the walk/canopy switch
+    (4096 pairs), the 1024-pair workgroup tile, the 2048 / 4096-pair tiles of the tile-sorted
+    kernel, a few workgroups more or less -- shallow and deep tree, device-resident pairs."""
+    import torch
+    rng = np.random.default_rng(77)
+    sizes = [1, 63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 6145,
+             8191, 8192, 8193, 2048 * 512 - 1, 2048 * 512 + 1, 4096 * 256 + 4095]
+    for parent, dist in (synth.balanced_tree(15), (ml_arrays[0], ml_arrays[1])):
+        O = OracleTree(parent, dist)
+        dev = _capi.DeviceTree(parent, dist)
+        big = rng.integers(0, len(parent), (max(sizes), 2))
+        big[::97, 1] = big[::97, 0]                                  # some pairs (x, x)
+        want_d, want_m = O.distances(big), O.mrca_bulk(big)
+        t = torch.from_numpy(big).cuda()
+        for n in sizes:
+            out_d = torch.full((n + 8,), -1.0, dtype=torch.float64, device="cuda")
+            out_m = torch.full((n + 8,), -7, dtype=torch.int32, device="cuda")
+            dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d[:n].cpu().numpy(), want_d[:n], "n=%d" % n)
+            assert np.array_equal(out_m[:n].cpu().numpy(), want_m[:n]), n
+            assert out_d[n:].eq(-1.0).all() and out_m[n:].eq(-7).all(), "wrote past n=%d" % n
+        dev.close()
+
+
 def test_non_default_canopy_variants(ml_arrays):
     """The selectable forms of the canopy kernel -- scalar (pairs_per_lane 0), one and two
     pairs per lane -- on a shallow and a deep tree, explicit pairs and the generated triangle."""
