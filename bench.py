@@ -7,9 +7,10 @@ on BASELINE's 1M-leaf tree.
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "Config 3"): synthetic
 perfectly balanced binary tree with 2^20 leaves (2,097,151 nodes, in-order ids),
 ONE batch of 1e8 uniform random leaf pairs, int64 (n,2), resident in HBM on every
-rank when the timed region starts.  One step = the whole batch: rank g computes the
-contiguous slice [g*n/G, (g+1)*n/G) on its own GPU (tree replicated, no data-path
-collective) and the result -- float64 distances + int32 MRCA ids for all n pairs --
+rank when the timed region starts.  One step = the whole batch: every rank computes one
+contiguous slice on its own GPU (tree replicated, no data-path collective; rank 0's slice is
+larger than the peers' so that its kernels end when their transfers do, --root-share) and
+the result -- float64 distances + int32 MRCA ids for all n pairs --
 is assembled on rank 0 by point-to-point RCCL transfers over xGMI, INSIDE the timed
 region (suchtree_amd/sharding.py::run_sharded: float32 + int32 on the wire, sent in
 pieces that overlap the next piece's kernel).  "scaling": "strong"; value = n pairs /
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--levels", type=int, default=20, help="balanced tree with 2**levels leaves")
     ap.add_argument("--strategy", default="auto", choices=["auto", "canopy", "walk"])
     ap.add_argument("--chunks", type=int, default=4, help="pieces per rank slice (transfer/compute overlap, N > 1)")
+    ap.add_argument("--root-share", default="auto",
+                    help="N > 1: fraction of the batch rank 0 computes itself: 'auto' (balance its kernels against the "
+                         "peers' transfers, from rates measured before the timed region), 'even' (1/N) or a number")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank its own batch, no gather")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,6 +145,45 @@ def hardware_ceilings(device_index, footprint_bytes):
     return out
 
 
+def calibrate_root_share(tree, pairs, n, world, rank, device, stream, dist_, sharding):
+    """Untimed, before the benchmark: this GPU's kernel rate on a prefix of the batch and the rate
+    at which rank 0 receives from all peers at once (the gather's pattern), then the root's share
+    of the batch for which its kernels and the peers' transfers end together
+    (sharding.balanced_root_share).  Rank 0 decides; everyone gets its number."""
+    import torch
+    m = min(n, 20_000_000)
+    d = torch.empty(m, dtype=torch.float32, device=device)
+    mm = torch.empty(m, dtype=torch.int32, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for k in range(2):
+        e0.record(stream)
+        tree.distances_device(pairs.data_ptr(), m, d.data_ptr(), mm.data_ptr(), stream=stream.cuda_stream, f32=True)
+        e1.record(stream)
+    torch.cuda.synchronize(device)
+    kernel_rate = m / (e0.elapsed_time(e1) * 1e-3)
+    nbytes = 64 << 20
+    buf = torch.empty(nbytes // 4 * (world if rank == 0 else 1), dtype=torch.float32, device=device)
+    link = 0.0
+    for k in range(2):
+        torch.cuda.synchronize(device)
+        dist_.barrier()
+        t0 = time.perf_counter()
+        if rank == 0:
+            ops = [dist_.P2POp(dist_.irecv, buf[g * (nbytes // 4):(g + 1) * (nbytes // 4)], g) for g in range(1, world)]
+        else:
+            ops = [dist_.P2POp(dist_.isend, buf, 0)]
+        for w in dist_.batch_isend_irecv(ops):
+            w.wait()
+        torch.cuda.synchronize(device)
+        link = nbytes / (time.perf_counter() - t0)          # per link, all links busy at once
+    share = sharding.balanced_root_share(world, kernel_rate, link) if rank == 0 else 0.0
+    share = min(0.95, max(1.0 / world, share))
+    t = torch.tensor([share, kernel_rate, link], dtype=torch.float64, device=device)
+    dist_.broadcast(t, src=0)
+    del d, mm, buf
+    return float(t[0].item()), {"kernel_pairs_per_s": float(t[1].item()), "link_GBps_into_root_per_peer": float(t[2].item()) / 1e9}
+
+
 def main():
     args = parse()
     # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when a
@@ -187,8 +230,14 @@ def main():
     pairs = torch.randint(0, n_leaves, (n, 2), generator=gen, device=device, dtype=torch.int64) * 2
     stream = torch.cuda.current_stream(device)
     strong = not args.weak
+    root_share, calib = None, None
+    if strong and world > 1 and args.root_share != "even":
+        if args.root_share == "auto":
+            root_share, calib = calibrate_root_share(tree, pairs, n, world, rank, device, stream, dist_, sharding)
+        else:
+            root_share = float(args.root_share)
     plan = sharding.ShardPlan(n, world if strong else 1, rank if strong else 0,
-                              chunks=args.chunks if (strong and world > 1) else 1)
+                              chunks=args.chunks if (strong and world > 1) else 1, root_share=root_share)
     out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=device)
     piece_events = []
 
@@ -281,8 +330,10 @@ def main():
                        "pairs_per_step": n_job, "pairs_per_gpu": pairs_this_rank if strong else n,
                        "tree_levels": args.levels, "kernel_family": info["strategy"],
                        "canopy_nodes": info["canopy_nodes"], "record_bytes": info["record_bytes"],
-                       "sharding": ("contiguous pair slices, tree replicated, no data-path collective; results to rank 0 "
-                                    "by RCCL send/recv over xGMI (float32 + int32 on the wire, %d pieces per slice)" % plan.chunks)
+                       "sharding": ("contiguous pair slices (rank 0: %.0f %% of the batch, the peers share the rest: its kernels "
+                                    "end when their transfers do), tree replicated, no data-path collective; results to rank 0 "
+                                    "by RCCL send/recv over xGMI (float32 + int32 on the wire, %d pieces per slice)"
+                                    % (100.0 * pairs_this_rank / n, plan.chunks))
                        if (strong and world > 1) else "none" if world == 1 else
                        "weak: every rank its own batch, tree replicated, nothing gathered"},
             "roofline": roof,
@@ -294,6 +345,9 @@ def main():
             # what the gather costs on top of the slowest rank's kernels (exposed, after overlap)
             line["gather_ms"] = max(0.0, ms_per_step - kernel_ms_max)
             line["gather_bytes_into_root"] = 8 * (n - pairs_this_rank)
+            line["root_share"] = pairs_this_rank / n
+            if calib:
+                line["root_share_calibration"] = calib
             line["parity"] = sample_parity(parent, dist, pairs, out_d, out_m, plan)
         if not args.no_microbench:
             # footprint the record gathers fall on: rec_a (8 B) + rec_b (record_bytes / 2) per leaf

@@ -41,20 +41,48 @@ def triangle_row_of(k):
 class ShardPlan:
     """Who computes what, and in which pieces the results travel.
 
-    ``n`` pairs are cut into ``world`` contiguous slices (``shard_bounds``); every
-    slice is cut again into ``chunks`` contiguous pieces so that the transfer of
-    piece c to the root overlaps the kernel of piece c+1 (the all-at-once gather
-    of an 8-GPU run costs ~4x the kernel time it follows).
+    ``n`` pairs are cut into ``world`` contiguous slices, one per rank in rank order; every
+    slice is cut again into ``chunks`` contiguous pieces so that the transfer of piece c to the
+    root overlaps the kernel of piece c+1.
+
+    ``root_share`` (default: 1/world, i.e. equal slices as in ``shard_bounds``): fraction of the
+    pairs the root computes itself.  Results are assembled on the root over point-to-point
+    links, and a result costs several times more to ship (8 B over one xGMI link) than to
+    compute, so the fastest split gives the root MORE than 1/world: with kernel time t_k per
+    pair and wire time t_w per pair and link, root and peers finish together at
+    ``root_share = t_w / (t_w + (world - 1) * t_k)`` (``balanced_root_share``).
     """
 
-    def __init__(self, n: int, world: int, rank: int, chunks: int = 4, root: int = 0):
+    def __init__(self, n: int, world: int, rank: int, chunks: int = 4, root: int = 0,
+                 root_share: Optional[float] = None):
         if n < 0 or chunks < 1 or not (0 <= root < world):
             raise ValueError("bad plan")
         self.n, self.world, self.rank, self.chunks, self.root = int(n), int(world), int(rank), int(chunks), int(root)
         shard_bounds(n, world, rank)   # validates world / rank
+        if root_share is None or world == 1:
+            self.root_pairs = None
+        else:
+            if not (0.0 < root_share <= 1.0):
+                raise ValueError("root_share must be in (0, 1]")
+            self.root_pairs = min(self.n, max(0, int(round(root_share * self.n))))
+        self.root_share = root_share
 
     def bounds(self, g: int) -> Tuple[int, int]:
-        return shard_bounds(self.n, self.world, g)
+        if self.root_pairs is None:
+            return shard_bounds(self.n, self.world, g)
+        if not (0 <= g < self.world):
+            raise ValueError("bad rank")
+        rest = self.n - self.root_pairs                 # split evenly over the world - 1 peers
+
+        def size(r):
+            if r == self.root:
+                return self.root_pairs
+            k = r if r < self.root else r - 1           # index among the peers
+            lo, hi = shard_bounds(rest, self.world - 1, k)
+            return hi - lo
+
+        lo = sum(size(r) for r in range(g))
+        return lo, lo + size(g)
 
     def piece(self, g: int, c: int) -> Tuple[int, int]:
         """Global pair range of piece ``c`` of rank ``g``'s slice (may be empty)."""
@@ -64,6 +92,18 @@ class ShardPlan:
 
     def pieces(self, g: int):
         return [self.piece(g, c) for c in range(self.chunks)]
+
+
+def balanced_root_share(world: int, kernel_pairs_per_s: float, link_bytes_per_s: float,
+                        wire_bytes_per_pair: float = 8.0) -> float:
+    """Root's fraction of the batch for which its own kernels and every peer's transfers end
+    together: the root computes s*n pairs in s*n*t_k; each peer ships (1-s)*n/(world-1) results
+    over its own link in (1-s)*n/(world-1)*t_w (its kernels hide under the transfers)."""
+    if world <= 1:
+        return 1.0
+    t_k = 1.0 / kernel_pairs_per_s
+    t_w = wire_bytes_per_pair / link_bytes_per_s
+    return t_w / (t_w + (world - 1) * t_k)
 
 
 def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=None, wire_m=None,

@@ -64,7 +64,7 @@ def _worker(rank, world, port, n_pairs, q):
         dist.destroy_process_group()
 
 
-def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q):
+def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=None):
     """bench.py's step, verbatim (sharding.run_sharded), on gloo/CPU tensors with the oracle
     injected as the compute step: slices, pieces, float32 wire format, assembly on the root."""
     import torch
@@ -78,7 +78,7 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q):
         parent, dist_ = synth.balanced_tree(9)
         O = OracleTree(parent, dist_)
         pairs = np.random.default_rng(5).integers(0, len(parent), (n_pairs, 2))
-        plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, root=root)
+        plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, root=root, root_share=root_share)
         out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan)
         calls = []
 
@@ -101,13 +101,15 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs,chunks,root", [(1001, 3, 0), (4, 4, 0), (777, 1, 1)])
-def test_run_sharded_world_size_2_gloo(n_pairs, chunks, root):
+@pytest.mark.parametrize("n_pairs,chunks,root,root_share", [(1001, 3, 0, None), (4, 4, 0, None), (777, 1, 1, None),
+                                                            (1001, 4, 0, 0.8), (1001, 2, 1, 0.37), (50, 3, 0, 1.0)])
+def test_run_sharded_world_size_2_gloo(n_pairs, chunks, root, root_share):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_run_sharded, args=(r, 2, port, n_pairs, chunks, root, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_run_sharded, args=(r, 2, port, n_pairs, chunks, root, q, root_share))
+             for r in range(2)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in procs)
     [p.join(timeout=60) for p in procs]
@@ -115,13 +117,27 @@ def test_run_sharded_world_size_2_gloo(n_pairs, chunks, root):
     assert all(p.exitcode == 0 for p in procs)
 
 
+def test_balanced_root_share():
+    # wire 8 B/pair at 60 GB/s = 133 ps, kernel 33.7 ps/pair: the root keeps 80 % at 2 GPUs, 36 % at 8
+    s2 = sharding.balanced_root_share(2, 1 / 33.7e-12, 60e9)
+    s8 = sharding.balanced_root_share(8, 1 / 33.7e-12, 60e9)
+    assert abs(s2 - 0.798) < 0.005 and abs(s8 - 0.361) < 0.005 and sharding.balanced_root_share(1, 1e9, 1e9) == 1.0
+    plan = sharding.ShardPlan(100_000_000, 8, 3, root=0, root_share=s8)
+    sizes = [plan.bounds(g)[1] - plan.bounds(g)[0] for g in range(8)]
+    assert sum(sizes) == 100_000_000 and sizes[0] == round(s8 * 1e8) and max(sizes[1:]) - min(sizes[1:]) <= 1
+    # root and peers finish together under the model
+    t_root = sizes[0] * 33.7e-12
+    t_peer = sizes[1] * 8 / 60e9
+    assert abs(t_root - t_peer) / t_root < 0.01
+
+
 def test_shard_plan_pieces_tile_the_batch():
     for n in (0, 5, 1000, 12345):
         for world in (1, 2, 8):
-            for chunks in (1, 3, 4):
+            for chunks, share, root in ((1, None, 0), (3, None, 0), (4, None, 0), (4, 0.45, 0), (3, 0.9, world - 1), (2, 1.0, 0)):
                 seen = []
                 for g in range(world):
-                    plan = sharding.ShardPlan(n, world, g, chunks=chunks)
+                    plan = sharding.ShardPlan(n, world, g, chunks=chunks, root=root, root_share=share)
                     assert plan.pieces(g)[0][0] == plan.bounds(g)[0] and plan.pieces(g)[-1][1] == plan.bounds(g)[1]
                     seen += plan.pieces(g)
                 assert seen[0][0] == 0 and seen[-1][1] == n
