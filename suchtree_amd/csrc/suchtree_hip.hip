@@ -1181,7 +1181,10 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
 // Coalesced word copy between pinned host memory and device memory (either direction).
 __global__ __launch_bounds__(1024) void k_words_copy(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, long long n_words)
 {
-    const long long n4 = n_words >> 2;
+    // 16 bytes per lane when both ends are 16-byte aligned (staging slots always are; a caller's
+    // pinned result array need not be), else word by word
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const long long n4 = vec ? n_words >> 2 : 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
         reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];

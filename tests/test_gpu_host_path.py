@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal
+from conftest import assert_bits_equal, golden_path
 from oracle.oracle import OracleTree
 from suchtree_amd import SuchTree, _capi, synth
 from suchtree_amd.exceptions import HipBackendError, InvalidNodeError
@@ -199,12 +199,21 @@ def test_caller_supplied_pinned_outputs_take_the_direct_path(tree17):
     pairs = np.random.default_rng(16).integers(0, len(parent), (2_500_000, 2))
     out_d = torch.empty(len(pairs) + 3, dtype=torch.float64).pin_memory()
     out_m = torch.empty(len(pairs), dtype=torch.int32)                 # pageable: mixed modes in one call
+    pin_m = torch.empty(len(pairs) + 1, dtype=torch.int32).pin_memory()   # pinned, 4-byte-aligned view below
     out_d.fill_(-1.0)
     dev.distances_host(pairs, True, True, out_dist=out_d.numpy()[3:], out_mrca=out_m.numpy())
     assert out_d[:3].tolist() == [-1.0, -1.0, -1.0]
     assert_bits_equal(out_d.numpy()[3:][:400_000], O.distances(pairs[:400_000]))
     assert_bits_equal(out_d.numpy()[3:][-400_000:], O.distances(pairs[-400_000:]))
     assert np.array_equal(out_m.numpy()[-400_000:], O.mrca_bulk(pairs[-400_000:]))
+    z = np.load(golden_path("ml_tree.npz"))                              # tile-sorted tree: staged copies into pinned outputs
+    deep = SuchTree((z["parent"], z["distance"])).to_device()._device_tree()
+    dp = np.random.default_rng(17).integers(0, len(z["parent"]), (len(pairs), 2))
+    deep.distances_host(dp, True, True, out_dist=out_d.numpy()[3:], out_mrca=pin_m.numpy()[1:])
+    OD = OracleTree(z["parent"], z["distance"])
+    assert_bits_equal(out_d.numpy()[3:][-300_000:], OD.distances(dp[-300_000:]))
+    assert np.array_equal(pin_m.numpy()[1:][-300_000:], OD.mrca_bulk(dp[-300_000:]))
+    assert np.array_equal(pin_m.numpy()[1:][:300_000], OD.mrca_bulk(dp[:300_000]))
     bad = pairs.copy()
     bad[77, 0] = -5
     with pytest.raises(InvalidNodeError) as e:
