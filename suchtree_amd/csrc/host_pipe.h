@@ -20,7 +20,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <emmintrin.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -32,7 +36,12 @@
 
 namespace st {
 
-// A fixed pool of threads that split [0, n) into contiguous ranges.
+// A fixed pool of threads that split [0, n) into contiguous ranges.  A host-path call runs
+// three or four short parallel phases per chunk (pack, pre-fault, unpack), a few hundred
+// microseconds apart, so waking sleeping threads through a condition variable for each of
+// them (~50 us a time) would cost as much as the phases themselves on batches of a million
+// pairs: workers spin on the generation counter for kSpinMicros after finishing a phase and
+// only then go to sleep; the caller spins for the phase's completion.
 class CopyPool {
 public:
     CopyPool() = default;
@@ -44,20 +53,19 @@ public:
     {
         if (!workers_.empty()) return;
         n_ = std::max(1, n_threads);
-        for (int i = 0; i < n_ - 1; i++) workers_.emplace_back([this, i] { loop(i + 1); });
+        quit_.store(false);
+        const uint64_t born = generation_.load();     // (a restarted pool does not start from zero)
+        for (int i = 0; i < n_ - 1; i++) workers_.emplace_back([this, i, born] { loop(i + 1, born); });
     }
 
     void stop()
     {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            quit_ = true;
-            ++generation_;
-        }
+        quit_.store(true);
+        generation_.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> g(m_); }
         cv_.notify_all();
         for (auto &w : workers_) w.join();
         workers_.clear();
-        quit_ = false;
     }
 
     // fn(begin, end) over a partition of [0, n); returns when every part is done.
@@ -65,17 +73,17 @@ public:
     {
         if (n <= 0) return;
         if (workers_.empty() || n < (int64_t)1 << 14) { fn(0, n); return; }
-        {
-            std::lock_guard<std::mutex> g(m_);
-            fn_ = &fn;
-            total_ = n;
-            pending_ = n_ - 1;
-            ++generation_;
-        }
+        fn_ = &fn;
+        total_ = n;
+        pending_.store(n_ - 1, std::memory_order_relaxed);
+        generation_.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> g(m_); }     // a worker about to sleep has either seen the new generation or is waiting
         cv_.notify_all();
         run_part(0);
-        std::unique_lock<std::mutex> g(m_);
-        done_cv_.wait(g, [this] { return pending_ == 0; });
+        for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
+            if ((spins & 1023) == 1023) std::this_thread::yield();
+            else _mm_pause();
+        }
         fn_ = nullptr;
     }
 
@@ -87,39 +95,44 @@ public:
     }
 
 private:
+    static constexpr int kSpinMicros = 200;
+
     void run_part(int part)
     {
         const int64_t b = total_ * part / n_, e = total_ * (part + 1) / n_;
         if (e > b) (*fn_)(b, e);
     }
 
-    void loop(int part)
+    void loop(int part, uint64_t seen)
     {
-        uint64_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return generation_ != seen; });
-                seen = generation_;
-                if (quit_) return;
+            // spin a little: the next phase of the same call is usually moments away
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; generation_.load(std::memory_order_acquire) == seen; spins++) {
+                _mm_pause();
+                if ((spins & 255) == 255 &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinMicros)) {
+                    std::unique_lock<std::mutex> g(m_);
+                    cv_.wait(g, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                    break;
+                }
             }
+            seen = generation_.load(std::memory_order_acquire);
+            if (quit_.load()) return;
             run_part(part);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                --pending_;
-            }
-            done_cv_.notify_one();
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
 
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
     const std::function<void(int64_t, int64_t)> *fn_ = nullptr;
     int64_t total_ = 0;
-    int n_ = 1, pending_ = 0;
-    uint64_t generation_ = 0;
-    bool quit_ = false;
+    int n_ = 1;
+    std::atomic<int> pending_{0};
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<bool> quit_{false};
 };
 
 struct PipeSlot {

@@ -1305,22 +1305,23 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         s.busy = false;
         const hipError_t e = hipEventSynchronize(s.done);
         if (e != hipSuccess) return e;
-        if (out_dist) {
-            // distances crossed PCIe as float32; widen into the caller's float64 array
-            const float *src = static_cast<const float *>(s.h_d);
-            double *dst = out_dist + s.off;
-            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) { widen_f32_to_f64(dst + b, src + b, e - b); });
-        }
-        if (out_mrca) {
-            const int32_t *src = static_cast<const int32_t *>(s.h_m);
-            int32_t *dst = out_mrca + s.off;
-            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) { copy_stream(dst + b, src + b, (e - b) * 4); });
-        }
+        // distances crossed PCIe as float32 and are widened into the caller's float64 array;
+        // MRCA ids are copied; one pass of the pool over the chunk does both
+        const float *src_d = static_cast<const float *>(s.h_d);
+        const int32_t *src_m = static_cast<const int32_t *>(s.h_m);
+        double *dst_d = out_dist ? out_dist + s.off : nullptr;
+        int32_t *dst_m = out_mrca ? out_mrca + s.off : nullptr;
+        if (dst_d || dst_m)
+            P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) {
+                if (dst_d) widen_f32_to_f64(dst_d + b, src_d + b, e - b);
+                if (dst_m) copy_stream(dst_m + b, src_m + b, (e - b) * 4);
+            });
         return hipSuccess;
     };
     // pages of a freshly allocated result array are populated here, by the pool, while the
     // chunk is on the GPU -- not one fault at a time inside the unpack loops
     auto prefault = [&](int64_t off, int64_t m) {
+        if (!out_dist && !out_mrca) return;
         P.pool.parallel_for(m, [=](int64_t b, int64_t e) {
             if (out_dist) populate_for_write(out_dist + off + b, (e - b) * 8);
             if (out_mrca) populate_for_write(out_mrca + off + b, (e - b) * 4);
