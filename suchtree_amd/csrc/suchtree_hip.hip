@@ -874,6 +874,7 @@ struct st_tree {
     // device pipe's mutex) and is never confused by a caller who skipped st_fault_check
     Fault *d_fault = nullptr;        // st_distances_device / st_triangle_device / st_fault_check
     Fault *d_fault_host = nullptr;   // st_*_host
+    bool host_fault_dirty = false;   // a host call ended before reading its fault word back: re-arm it first
     // canopy geometry
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
@@ -1075,6 +1076,26 @@ static int fetch_fault(Fault *d_word, hipStream_t stream, Fault &f)
     return ST_OK;
 }
 
+// The host path's fault word is clean between calls (fetch_fault re-arms it when it fired), so
+// a call does not pay a reset + synchronisation up front -- unless the previous call on this
+// tree ended early.  begin_host_faults marks the word as in use, end_host_faults reads it back.
+static int begin_host_faults(st_tree *t, hipStream_t stream)
+{
+    if (t->host_fault_dirty) {
+        ST_HIP(hipMemcpyAsync(t->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream));
+        ST_HIP(hipStreamSynchronize(stream));
+    }
+    t->host_fault_dirty = true;
+    return ST_OK;
+}
+
+static int end_host_faults(st_tree *t, hipStream_t stream, Fault &f)
+{
+    const int rc = fetch_fault(t->d_fault_host, stream, f);
+    if (rc == ST_OK) t->host_fault_dirty = false;
+    return rc;
+}
+
 static void merge_fault(Fault &into, const Fault &f)
 {
     into.max_bad = std::max(into.max_bad, f.max_bad);
@@ -1106,7 +1127,7 @@ constexpr int64_t kHostChunk = (int64_t)1 << 22;      // most pairs per pipeline
 constexpr int64_t kHostChunkMin = (int64_t)1 << 18;   // fewest, when a batch is dealt over several GPUs
 constexpr int kDeepCanopyDepth = 100;     // canopies deeper than this (edges) are "deep"
 constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
-constexpr int64_t kMailboxPairs = 2048;   // largest batch served through the mailbox
+constexpr int64_t kMailboxPairs = 8192;   // largest batch served through the mailbox (beyond it the staged pipe's fixed ~60 us pay off)
 
 // How a host batch of n pairs is cut into pipeline chunks and dealt over n_dev devices:
 // chunk c covers [c*chunk, min(n, (c+1)*chunk)) and belongs to device index c % n_dev.  With
@@ -1748,7 +1769,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
     if (n > 0 && !pairs) return fail(ST_ERR_ARG, "pairs is NULL");
     if (!out_dist && !out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
     if (n == 0) return ST_OK;
-    if (n <= kMailboxPairs && t->small_batch_path) {
+    // (deep canopies: beyond the walk/canopy switch the tile-sorted kernel beats the mailbox's walk)
+    if (n <= (t->tile_sort ? kCanopyMinPairs - 1 : kMailboxPairs) && t->small_batch_path) {
         ST_DEVICE(t->device);
         return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
     }
@@ -1804,12 +1826,10 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
             if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
             s0 = r->dp->pipe.slot[0].stream;
         }
-        // a fresh word for this call (an earlier call that failed half-way may have left it set)
-        ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
-        ST_HIP(hipStreamSynchronize(s0));
-        int rc = run_pipe(r, seq, pack, launch, out);
+        int rc = begin_host_faults(r, s0);
+        if (rc == ST_OK) rc = run_pipe(r, seq, pack, launch, out);
         if (rc != ST_OK) return rc;
-        rc = fetch_fault(r->d_fault_host, s0, fault);
+        rc = end_host_faults(r, s0, fault);
         if (rc != ST_OK) return rc;
         // a clamped id always trips the device check as well; its exact value replaces the clamp
         if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) merge_fault(fault, wide);
@@ -1883,8 +1903,7 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
         if (e == hipSuccess) e = P.ensure_ids(m);
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
         hipStream_t s0 = P.slot[0].stream;
-        ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
-        ST_HIP(hipStreamSynchronize(s0));
+        if (begin_host_faults(r, s0) != ST_OK) return ST_ERR_HIP;
         ST_HIP(hipMemcpy(P.d_ids, src_ids, (size_t)m * 8, hipMemcpyHostToDevice));
         auto pack = [](PipeSlot &, int64_t, int64_t) {};
         auto launch = [&](PipeSlot &s, int64_t off, int64_t c) {
@@ -1893,7 +1912,7 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
         };
         const int rc2 = run_pipe(r, seq, pack, launch, out);
         if (rc2 != ST_OK) return rc2;
-        return fetch_fault(r->d_fault_host, s0, fault);
+        return end_host_faults(r, s0, fault);
     };
     Fault fault;
     rc = for_each_replica(t, k_count, fault, work);
@@ -1930,8 +1949,7 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
         if (e == hipSuccess) e = P.ensure_ids(n_rows + n_cols);
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
         hipStream_t s0 = P.slot[0].stream;
-        ST_HIP(hipMemcpyAsync(r->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
-        ST_HIP(hipStreamSynchronize(s0));
+        if (begin_host_faults(r, s0) != ST_OK) return ST_ERR_HIP;
         long long *d_rows = static_cast<long long *>(P.d_ids), *d_cols = d_rows + n_rows;
         ST_HIP(hipMemcpy(d_rows, row_ids, (size_t)n_rows * 8, hipMemcpyHostToDevice));
         ST_HIP(hipMemcpy(d_cols, col_ids, (size_t)n_cols * 8, hipMemcpyHostToDevice));
@@ -1942,7 +1960,7 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
         };
         const int rc2 = run_pipe(r, seq, pack, launch, out);
         if (rc2 != ST_OK) return rc2;
-        return fetch_fault(r->d_fault_host, s0, fault);
+        return end_host_faults(r, s0, fault);
     };
     Fault fault;
     rc = for_each_replica(t, e_count, fault, work);
@@ -1984,8 +2002,8 @@ int st_knn_host(st_tree *t, const int64_t *queries, int64_t n_queries, const int
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_od), (size_t)n_queries * k * 8);
     if (e == hipSuccess) e = hipMemcpyAsync(d_q, queries, (size_t)n_queries * 8, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_c, cands, (size_t)n_cands * 8, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(t->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) { cleanup(); return fail(ST_ERR_HIP, std::string("knn setup: ") + hipGetErrorString(e)); }
+    if (begin_host_faults(t, stream) != ST_OK) { cleanup(); return ST_ERR_HIP; }
     for (int64_t r0 = 0; r0 < n_queries; r0 += rows_per_block) {
         const int64_t rows = std::min(rows_per_block, n_queries - r0);
         const SrcGrid src{d_q + r0, d_c, (long long)n_cands, 0, 0};
@@ -1999,7 +2017,7 @@ int st_knn_host(st_tree *t, const int64_t *queries, int64_t n_queries, const int
     e = hipMemcpyAsync(out_index, d_oi, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_dist, d_od, (size_t)n_queries * k * 8, hipMemcpyDeviceToHost, stream);
     Fault f = kFaultInit;
-    int rc = e == hipSuccess ? fetch_fault(t->d_fault_host, stream, f) : fail(ST_ERR_HIP, std::string("knn D2H: ") + hipGetErrorString(e));
+    int rc = e == hipSuccess ? end_host_faults(t, stream, f) : fail(ST_ERR_HIP, std::string("knn D2H: ") + hipGetErrorString(e));
     cleanup();
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
@@ -2024,7 +2042,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
     }
     PipeSlot &in = pipe.slot[0], &out = pipe.slot[1];
-    ST_HIP(hipMemcpyAsync(t->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, in.stream));
+    if (begin_host_faults(t, in.stream) != ST_OK) return ST_ERR_HIP;
     WalkParams P;
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
@@ -2065,7 +2083,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         pipe.pool.copy(out_topologies + off * 4, out.h_in, m * 32);
     }
     Fault f;
-    const int rc = fetch_fault(t->d_fault_host, in.stream, f);
+    const int rc = end_host_faults(t, in.stream, f);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
 }

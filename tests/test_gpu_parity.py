@@ -76,7 +76,7 @@ def test_config1_gopher_1000_random_leaf_pairs(gopher_flat):
     O = OracleTree(gopher_flat.parent, gopher_flat.distance)
     dev = _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance)
     big = np.random.default_rng(2).choice(leaf_ids, size=(5000, 2)).astype(np.int64)
-    for n in (1, 2, 63, 64, 65, 1000, 2047, 2048, 2049, 5000):
+    for n in (1, 2, 63, 64, 65, 1000, 2047, 2048, 2049, 5000, 8191, 8192, 8193):
         for mailbox in (1, 0):
             dev.set_option("small_batch_path", mailbox)
             for view in (big[:n], np.asfortranarray(big[:n]), big[:n][:, ::-1]):
