@@ -161,27 +161,9 @@ def calibrate_root_share(tree, pairs, n, world, rank, device, stream, dist_, sha
         e1.record(stream)
     torch.cuda.synchronize(device)
     kernel_rate = m / (e0.elapsed_time(e1) * 1e-3)
-    nbytes = 64 << 20
-    buf = torch.empty(nbytes // 4 * (world if rank == 0 else 1), dtype=torch.float32, device=device)
-    link = 0.0
-    for k in range(2):
-        torch.cuda.synchronize(device)
-        dist_.barrier()
-        t0 = time.perf_counter()
-        if rank == 0:
-            ops = [dist_.P2POp(dist_.irecv, buf[g * (nbytes // 4):(g + 1) * (nbytes // 4)], g) for g in range(1, world)]
-        else:
-            ops = [dist_.P2POp(dist_.isend, buf, 0)]
-        for w in dist_.batch_isend_irecv(ops):
-            w.wait()
-        torch.cuda.synchronize(device)
-        link = nbytes / (time.perf_counter() - t0)          # per link, all links busy at once
-    share = sharding.balanced_root_share(world, kernel_rate, link) if rank == 0 else 0.0
-    share = min(0.95, max(1.0 / world, share))
-    t = torch.tensor([share, kernel_rate, link], dtype=torch.float64, device=device)
-    dist_.broadcast(t, src=0)
-    del d, mm, buf
-    return float(t[0].item()), {"kernel_pairs_per_s": float(t[1].item()), "link_GBps_into_root_per_peer": float(t[2].item()) / 1e9}
+    share, link, k_rate = sharding.measure_root_share(world, rank, kernel_rate, device=device)
+    del d, mm
+    return share, {"kernel_pairs_per_s": k_rate, "link_GBps_into_root_per_peer": link / 1e9}
 
 
 def main():

@@ -177,6 +177,45 @@ def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=N
     return pending
 
 
+def measure_root_share(world: int, rank: int, kernel_pairs_per_s: float, device=None, group=None,
+                       nbytes: int = 64 << 20, root: int = 0, wire_bytes_per_pair: float = 8.0):
+    """The rate at which ``root`` receives from ALL peers at once (the gather's pattern: every
+    peer ships ``nbytes`` over its own link), measured on the root, then the balanced root share
+    for ``kernel_pairs_per_s`` (the root's own value is used).  Collective: every rank of the
+    group calls it.  Returns ``(root_share, link_bytes_per_s, kernel_pairs_per_s_of_root)``,
+    identical on all ranks (broadcast by the root).  Works on RCCL (device tensors; the caller's
+    current device) and gloo (CPU tensors)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    def sync():
+        if device is not None and torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+
+    words = max(1, nbytes // 4)
+    buf = torch.zeros(words * (world if rank == root else 1), dtype=torch.float32, device=device)
+    link = 0.0
+    for _ in range(2):                              # the first round also builds the point-to-point channels
+        sync()
+        dist.barrier(group)
+        t0 = time.perf_counter()
+        if rank == root:
+            ops = [dist.P2POp(dist.irecv, buf[g * words:(g + 1) * words], g, group) for g in range(world) if g != root]
+        else:
+            ops = [dist.P2POp(dist.isend, buf, root, group)]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        sync()
+        link = 4.0 * words / max(time.perf_counter() - t0, 1e-9)      # per link, all links busy at once
+    share = balanced_root_share(world, kernel_pairs_per_s, link, wire_bytes_per_pair) if rank == root else 0.0
+    share = min(0.95, max(1.0 / world, share))
+    t = torch.tensor([share, link, kernel_pairs_per_s], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=root, group=group)
+    return float(t[0].item()), float(t[1].item()), float(t[2].item())
+
+
 def sharded_buffers(plan: ShardPlan, device=None):
     """(result_d, result_m, wire_d, wire_m) torch tensors of the sizes ``run_sharded`` needs on
     this rank: results only on the root, wire buffers only where something travels."""

@@ -117,6 +117,35 @@ def test_run_sharded_world_size_2_gloo(n_pairs, chunks, root, root_share):
     assert all(p.exitcode == 0 for p in procs)
 
 
+def _worker_measure(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # each rank passes a different kernel rate: the root's must win, and everyone must agree
+        share, link, k = sharding.measure_root_share(world, rank, 1e9 * (rank + 1), nbytes=1 << 20)
+        q.put((rank, share, link, k))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_measure_root_share_world_size_2_gloo():
+    """bench.py's calibration step (batched point-to-point transfers into the root + broadcast)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_measure, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, s0, l0, k0), (r1, s1, l1, k1) = res
+    assert (s0, l0, k0) == (s1, l1, k1) and k0 == 1e9 and l0 > 0 and 0.5 <= s0 <= 0.95
+    assert s0 == min(0.95, max(0.5, sharding.balanced_root_share(2, 1e9, l0)))
+
+
 def test_balanced_root_share():
     # wire 8 B/pair at 60 GB/s = 133 ps, kernel 33.7 ps/pair: the root keeps 80 % at 2 GPUs, 36 % at 8
     s2 = sharding.balanced_root_share(2, 1 / 33.7e-12, 60e9)
