@@ -1,7 +1,10 @@
-mkdir -p gpurun_out/r2k
-timeout 1700 python -m pytest tests -m gpu -x -q > gpurun_out/r2k/pytest.log 2>&1; grep -E "passed|failed|^E |^FAILED" gpurun_out/r2k/pytest.log | tail -5
-python scripts/bench_configs.py --configs 1,2,4,5,3-host,f4 --out gpurun_out/r2k/configs.jsonl > gpurun_out/r2k/configs.log 2>&1; cut -c1-330 gpurun_out/r2k/configs.jsonl
-bash scripts/profile_counters.sh r02_headline --levels 20 --pairs 100000000 --rounds 2 > gpurun_out/r2k/sq_headline.txt 2>&1
-bash scripts/profile_counters.sh r02_ml --tree ml --pairs 20000000 --rounds 2 > gpurun_out/r2k/sq_ml.txt 2>&1
-tail -25 gpurun_out/r2k/sq_headline.txt; tail -25 gpurun_out/r2k/sq_ml.txt
-python bench.py > gpurun_out/r2k/bench.json 2> gpurun_out/r2k/bench.err; cut -c1-600 gpurun_out/r2k/bench.json
+# Final measurement suite of round 2 (GPU box): tests, configs, profiles, counters, bench.
+mkdir -p gpurun_out/r2z
+timeout 1700 python -m pytest tests -m gpu -x -q > gpurun_out/r2z/pytest.log 2>&1; grep -E "passed|failed|^E |^FAILED" gpurun_out/r2z/pytest.log | tail -5
+python scripts/bench_configs.py --configs 1,2,4,5,3-host,f4 --out gpurun_out/r2z/configs.jsonl > gpurun_out/r2z/configs.log 2>&1; cut -c1-260 gpurun_out/r2z/configs.jsonl
+python scripts/latency_curve.py > gpurun_out/r2z/latency.log 2>&1
+python scripts/host_path_probe.py > gpurun_out/r2z/host_probe.log 2>&1
+python scripts/host_path_sweep.py > gpurun_out/r2z/host_sweep.jsonl 2>/dev/null
+python scripts/bench_by_name.py > gpurun_out/r2z/by_name.json 2>/dev/null; cat gpurun_out/r2z/by_name.json
+bash scripts/profile_gpu.sh r02b > gpurun_out/r2z/profile.log 2>&1; cp profiles/*r02b* gpurun_out/r2z/
+python bench.py > gpurun_out/r2z/bench.json 2> gpurun_out/r2z/bench.err; cut -c1-400 gpurun_out/r2z/bench.json

@@ -9,7 +9,9 @@ TAG=${1:-r02}; shift || true
 ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-microbench"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+mkdir -p $OUT $REPO/scripts/micro/bin
+# the calibration program (known traffic) is built on demand; binaries are not kept in git
+[ -x $REPO/scripts/micro/bin/calib_requests ] || hipcc --offload-arch=gfx950 -O3 -o $REPO/scripts/micro/bin/calib_requests $REPO/scripts/micro/calib_requests.hip
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"

@@ -219,3 +219,28 @@ def test_caller_supplied_pinned_outputs_take_the_direct_path(tree17):
     with pytest.raises(InvalidNodeError) as e:
         dev.distances_host(bad, True, False, out_dist=out_d.numpy()[3:])
     assert e.value.node_id == -5
+
+
+def test_create_destroy_cycles_do_not_leak_device_or_pinned_memory(tree17):
+    """Trees come and go (the per-device staging pipe is reference counted): HBM returns to its
+    level and the pipe is rebuilt on demand."""
+    import torch
+    parent, dist, O = tree17
+    pairs = np.random.default_rng(18).integers(0, len(parent), (400_000, 2))
+    want = O.distances(pairs[:50_000])
+
+    def cycle():
+        T = SuchTree((parent, dist))
+        d = T.distances_bulk(pairs)
+        assert_bits_equal(d[:50_000], want)
+        T.close()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 25 create/close cycles" % ((free0 - free1) >> 20)
