@@ -6,20 +6,23 @@
 //
 //   walk    pointer chase over the 8-byte {parent,dist} table with a depth
 //           cut; works for any rooted tree.
-//   canopy  the top of the tree lives in LDS (BFS-numbered, 8 B per node);
-//           everything below it is folded into one fixed-stride understory
-//           record per node (split into an 8-byte a-side table and a b-side table), so
-//           a pair costs two record reads plus an LDS climb instead of ~h dependent
-//           global gathers.
-//           k_canopy      scalar, branchy (default for deep canopies)
-//           k_canopy_ilp  1-2 pairs per lane, predicated (default otherwise)
+//   canopy  the top of the tree lives in LDS (BFS-numbered); everything below it is
+//           folded into one fixed-stride understory record per node (split into an
+//           8-byte a-side table and a b-side table), so a pair costs two record reads
+//           plus an LDS climb instead of ~h dependent global gathers.
+//           k_canopy_ilp     1-2 pairs per lane, predicated (the default)
+//           k_canopy_sorted  deep canopies: ladder form of the canopy (three edges per
+//                            16-byte LDS entry), pairs sorted by climb length within a
+//                            workgroup tile
+//           k_canopy         scalar, branchy (records longer than 128 bytes)
 //
 // Every kernel is templated on a pair source (SrcContig / SrcContig32 / SrcStrided /
-// SrcTriangle / SrcQuartet): an explicit (n,2) array in HBM, or pairs derived from their
-// index (all-pairs triangle, the six pairs of a quartet).
+// SrcTriangle / SrcGrid / SrcQuartet): an explicit (n,2) array, or pairs derived from their
+// index (all-pairs triangle, rows x columns grid, the six pairs of a quartet).
 //
-// Host side of the C ABI: tree upload (tree_prep.cpp builds the tables), the staged
-// host path (host_pipe.h), the small-batch mailbox, fault read-back.
+// Host side of the C ABI: tree upload to one or several GPUs (tree_prep.cpp builds the
+// tables), the zero-copy host path (host_pipe.h, host_copy.h: kernels read and write pinned
+// host memory), the small-batch mailbox, fault read-back, k-nearest selection, graph matrices.
 //
 // Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <hip/hip_runtime.h>
