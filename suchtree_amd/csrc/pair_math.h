@@ -22,62 +22,60 @@ struct PairResult {
 };
 
 // ---- walk family -----------------------------------------------------------
-// Depth cut: lift the deeper endpoint to the other's depth, then climb in
-// lock step until the lineages meet.  The a-side sum is accumulated during
-// the climb (it starts from 0, so climbing order == summation order); the
-// b-side continues the same accumulator and therefore needs a second pass
-// over b's lineage once the a-side total is known.
-ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
-                           int32_t a, int32_t b)
+// Works on any rooted tree, no tables but the tree itself.  The meeting node is found first,
+// with integer work only: the deeper endpoint is lifted to the other's depth, then both climb
+// in lock step -- three levels per gather (Stride3::p3) while their third ancestors differ, one
+// level (Node8::parent) once they agree.  Both sums then know their edge counts and add three
+// edges per 16-byte gather, in lineage order: a's edges from 0, then b's onto the same
+// accumulator, exactly the reference's two loops (MuchTree.pyx:934-942).
+ST_HD int32_t pair_walk_mrca(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
+                             const Stride3 *__restrict__ stride, int32_t a, int32_t b, int32_t *depth_of_mrca = nullptr)
 {
     int32_t x = a, y = b;
     int32_t dx = depth[x], dy = depth[y];
-    float s = 0.0f;
     while (dx > dy) {
-        Node8 e = nodes[x];
-        s += e.dist;
-        x = e.parent;
-        dx--;
+        if (dx - dy >= 3) { x = stride[x].p3; dx -= 3; } else { x = nodes[x].parent; dx -= 1; }
     }
     while (dy > dx) {
-        y = nodes[y].parent;
-        dy--;
+        if (dy - dx >= 3) { y = stride[y].p3; dy -= 3; } else { y = nodes[y].parent; dy -= 1; }
     }
     while (x != y) {
-        Node8 ex = nodes[x];
-        int32_t py = nodes[y].parent;
-        s += ex.dist;
-        x = ex.parent;
-        y = py;
+        const int32_t px = stride[x].p3, py = stride[y].p3;
+        if (px != py) { x = px; y = py; dx -= 3; }
+        else { x = nodes[x].parent; y = nodes[y].parent; dx -= 1; }
     }
-    const int32_t m = x;
-    y = b;
-    while (y != m) {
-        Node8 e = nodes[y];
-        s += e.dist;
-        y = e.parent;
+    if (depth_of_mrca) *depth_of_mrca = dx;
+    return x;
+}
+
+ST_HD float walk_sum(const Stride3 *__restrict__ stride, float s, int32_t u, int32_t k)
+{
+    while (k >= 3) {
+        const Stride3 e = stride[u];
+        s += e.d0; s += e.d1; s += e.d2;
+        u = e.p3;
+        k -= 3;
     }
+    if (k) {
+        const Stride3 e = stride[u];
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    return s;
+}
+
+ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
+                           const Stride3 *__restrict__ stride, int32_t a, int32_t b)
+{
+    int32_t dm;
+    const int32_t da = depth[a], db = depth[b];
+    const int32_t m = pair_walk_mrca(nodes, depth, stride, a, b, &dm);
+    float s = walk_sum(stride, 0.0f, a, da - dm);
+    s = walk_sum(stride, s, b, db - dm);
     PairResult r;
     r.dist = s;
     r.mrca = m;
     return r;
-}
-
-// MRCA only (no branch-length loads).
-ST_HD int32_t pair_walk_mrca(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
-                             int32_t a, int32_t b)
-{
-    int32_t x = a, y = b;
-    int32_t dx = depth[x], dy = depth[y];
-    while (dx > dy) { x = nodes[x].parent; dx--; }
-    while (dy > dx) { y = nodes[y].parent; dy--; }
-    while (x != y) {
-        int32_t px = nodes[x].parent;
-        int32_t py = nodes[y].parent;
-        x = px;
-        y = py;
-    }
-    return x;
 }
 
 // ---- canopy family ---------------------------------------------------------

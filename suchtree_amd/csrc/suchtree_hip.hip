@@ -225,6 +225,7 @@ __device__ __forceinline__ void store_result(const DistSink &out_d, int *__restr
 struct WalkParams {
     const Node8 *nodes;
     const int32_t *depth;
+    const Stride3 *stride;
     long long n_nodes;
 };
 
@@ -244,10 +245,10 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
             continue;
         }
         if (out_d.any()) {
-            const PairResult r = pair_walk(P.nodes, P.depth, (int32_t)a, (int32_t)b);
+            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b);
             store_result(out_d, out_m, i, r.dist, r.mrca);
         } else {
-            out_m[i] = pair_walk_mrca(P.nodes, P.depth, (int32_t)a, (int32_t)b);
+            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b);
         }
     }
 }
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void k_quartets(WalkParams P, const long long 
         int M[6];
 #pragma unroll
         for (int j = 0; j < 6; j++)
-            M[j] = pair_walk_mrca(P.nodes, P.depth, (int32_t)id[pa[j]], (int32_t)id[pb[j]]);
+            M[j] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)id[pa[j]], (int32_t)id[pb[j]]);
         int pick = 5;
 #pragma unroll
         for (int j = 5; j >= 0; j--) {
@@ -869,6 +870,7 @@ struct st_tree {
     // device tables
     Node8 *d_nodes = nullptr;
     int32_t *d_depth = nullptr;
+    Stride3 *d_stride = nullptr;
     CanopyEntry *d_canopy = nullptr;
     int32_t *d_canopy_id = nullptr;
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
@@ -1033,6 +1035,7 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
     WalkParams P;
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
+    P.stride = t->d_stride;
     P.n_nodes = t->n_nodes;
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
@@ -1188,6 +1191,7 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
     WalkParams P;
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
+    P.stride = t->d_stride;
     P.n_nodes = t->n_nodes;
     const SrcContig src{reinterpret_cast<const long long *>(d_base)};
     double *d_dist = reinterpret_cast<double *>(d_base + (size_t)kMailboxPairs * 16);
@@ -1487,6 +1491,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     int64_t bytes = 0;
     int rc = upload(&t->d_nodes, T.nodes, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
+    if (rc == ST_OK) rc = upload(&t->d_stride, T.stride, &bytes);
     if (rc == ST_OK && B.canopy_ok) {
         t->has_canopy = true;
         t->canopy_nodes = T.canopy_nodes;
@@ -1649,6 +1654,7 @@ void st_tree_destroy(st_tree *t)
         DeviceScope scope(t->device);
         (void)hipFree(t->d_nodes);
         (void)hipFree(t->d_depth);
+        (void)hipFree(t->d_stride);
         (void)hipFree(t->d_canopy);
         (void)hipFree(t->d_canopy_id);
         (void)hipFree(t->d_ladder);
@@ -2049,6 +2055,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     WalkParams P;
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
+    P.stride = t->d_stride;
     P.n_nodes = t->n_nodes;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);

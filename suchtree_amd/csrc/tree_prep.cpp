@@ -75,6 +75,18 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
         T.nodes[(size_t)i].parent = parent[i];
         T.nodes[(size_t)i].dist = distance[i];
     }
+    // stride-3 image: the root's own "length" (-1 in the reference's table) is never an edge
+    T.stride.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t p1 = parent[i] >= 0 ? parent[i] : (int32_t)i;
+        const int32_t p2 = parent[p1] >= 0 ? parent[p1] : p1;
+        const int32_t p3 = parent[p2] >= 0 ? parent[p2] : p2;
+        Stride3 &e = T.stride[(size_t)i];
+        e.d0 = parent[i] >= 0 ? distance[i] : 0.0f;
+        e.d1 = (p1 != (int32_t)i && parent[p1] >= 0) ? distance[p1] : 0.0f;
+        e.d2 = (p2 != p1 && parent[p2] >= 0) ? distance[p2] : 0.0f;
+        e.p3 = p3;
+    }
     return true;
 }
 

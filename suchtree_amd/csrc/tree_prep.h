@@ -4,8 +4,9 @@
 // /root/reference/SuchTree/MuchTree.pyx:55-60,182-216).  Output is everything
 // the gfx950 kernels read:
 //
-//   nodes    {parent,dist} 8-byte table ........ walk kernel
+//   nodes    {parent,dist} 8-byte table ........ walk kernel (single steps)
 //   depth    edges to root per node ............ walk kernel (depth cut)
+//   stride   three edges + third ancestor ...... walk kernel (three levels per gather)
 //   canopy   the top of the tree, BFS-numbered so that parent index < child
 //            index; staged into LDS by every workgroup .... canopy kernel
 //   records  one fixed-stride "understory" record per node: which canopy
@@ -33,6 +34,17 @@ struct Node8 {
     float dist;
 };
 static_assert(sizeof(Node8) == 8, "Node8 must be 8 bytes");
+
+// Stride-3 image of the whole tree for the walk family: the branch lengths of three
+// consecutive edges of a node's lineage and its third ancestor, so that a walk of k edges is
+// k/3 dependent 16-byte gathers instead of k (single steps use Node8::parent).  Beyond the
+// root the ancestor is clamped to the root and the lengths are 0 (never added: walks know
+// their edge counts).
+struct Stride3 {
+    float d0, d1, d2;   // dist[x], dist[parent(x)], dist[parent(parent(x))]
+    int32_t p3;         // third ancestor (clamped to the root)
+};
+static_assert(sizeof(Stride3) == 16, "Stride3 must be 16 bytes");
 
 struct CanopyEntry {
     float dist;        // branch length above this canopy node
@@ -75,6 +87,7 @@ struct TreeTables {
     bool parity_layout = false;         // leaves are exactly the even ids
     std::vector<Node8> nodes;           // [n]
     std::vector<int32_t> depth;         // [n] edges to root
+    std::vector<Stride3> stride;        // [n] stride-3 image (walk family)
     std::vector<int32_t> bfs_order;     // [n] scratch: parents before children
     std::vector<int32_t> height;        // [n] scratch: nodes down to the deepest leaf (leaf = 1)
     // canopy family (empty when the tree does not admit it)

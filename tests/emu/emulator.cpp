@@ -51,8 +51,8 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
         const int64_t a = pairs[2 * i], b = pairs[2 * i + 1];
         PairResult r;
         if (!canopy) {
-            r = pair_walk(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
-            if (out_m && !out_d) r.mrca = pair_walk_mrca(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
+            r = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b);
+            if (out_m && !out_d) r.mrca = pair_walk_mrca(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b);
         } else {
             const int64_t sa = record_slot(a, T.parity_layout, T.n_leaves);
             const int64_t sb = record_slot(b, T.parity_layout, T.n_leaves);

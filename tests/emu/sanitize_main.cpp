@@ -58,8 +58,8 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
     std::uniform_int_distribution<int64_t> pick(0, n - 1);
     for (int k = 0; k < 20000; k++) {
         const int64_t a = pick(rng), b = k % 3 == 0 ? std::min<int64_t>(n - 1, a + k % 17) : pick(rng);
-        const PairResult w = pair_walk(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b);
-        if (pair_walk_mrca(T.nodes.data(), T.depth.data(), (int32_t)a, (int32_t)b) != w.mrca) return 2;
+        const PairResult w = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b);
+        if (pair_walk_mrca(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b) != w.mrca) return 2;
         if (!canopy) continue;
         const RecTables R{T.rec_a.data(), T.rec_b.data(), T.rec_i.data(), T.record_bytes / 2};
         const RecView A = rec_view(R, record_slot(a, T.parity_layout, T.n_leaves));
