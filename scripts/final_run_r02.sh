@@ -1,7 +1,7 @@
 # Final measurement suite of round 2 (GPU box): tests, configs, profiles, counters, bench.
 mkdir -p gpurun_out/r2z
 timeout 1700 python -m pytest tests -m gpu -x -q > gpurun_out/r2z/pytest.log 2>&1; grep -E "passed|failed|^E |^FAILED" gpurun_out/r2z/pytest.log | tail -5
-python scripts/bench_configs.py --configs 1,2,4,5,3-host,f4 --out gpurun_out/r2z/configs.jsonl > gpurun_out/r2z/configs.log 2>&1; cut -c1-260 gpurun_out/r2z/configs.jsonl
+python scripts/bench_configs.py --configs 1,2,4,5,host,quartets --out gpurun_out/r2z/configs.jsonl > gpurun_out/r2z/configs.log 2>&1; cut -c1-260 gpurun_out/r2z/configs.jsonl
 python scripts/latency_curve.py > gpurun_out/r2z/latency.log 2>&1
 python scripts/host_path_probe.py > gpurun_out/r2z/host_probe.log 2>&1
 python scripts/host_path_sweep.py > gpurun_out/r2z/host_sweep.jsonl 2>/dev/null

@@ -2119,8 +2119,27 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
     if (need > free_b / 10 * 9)
         return fail(ST_ERR_NOMEM, "dense " + std::to_string(n) + " x " + std::to_string(n) + " graph matrices need " +
                                       std::to_string(need >> 20) + " MiB of device memory, " + std::to_string(free_b >> 20) + " MiB free");
-    char *ws = nullptr;
-    ST_HIP(hipMalloc(reinterpret_cast<void **>(&ws), need));
+    // one grow-only workspace per device, kept between calls (a 422 x 422 Laplacian is all
+    // allocation time otherwise); calls on one device take turns
+    struct Workspace { std::mutex m; char *p = nullptr; size_t cap = 0; };
+    static std::mutex ws_map_mutex;
+    static std::map<int, Workspace *> ws_map;
+    Workspace *W;
+    {
+        std::lock_guard<std::mutex> g(ws_map_mutex);
+        Workspace *&slot = ws_map[device];
+        if (!slot) slot = new Workspace();
+        W = slot;
+    }
+    std::lock_guard<std::mutex> ws_lock(W->m);
+    if (W->cap < need) {
+        (void)hipFree(W->p);
+        W->p = nullptr;
+        W->cap = 0;
+        ST_HIP(hipMalloc(reinterpret_cast<void **>(&W->p), need));
+        W->cap = need;
+    }
+    char *ws = W->p;
     double *d_A = reinterpret_cast<double *>(ws);
     double *d_L = out_laplacian ? d_A + (size_t)n * n : nullptr;
     double *d_deg = reinterpret_cast<double *>(ws + mat * (out_laplacian ? 2 : 1));
@@ -2146,7 +2165,11 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
     }
     if (e == hipSuccess && out_adjacency) e = hipMemcpy(out_adjacency, d_A, mat, hipMemcpyDeviceToHost);
     if (e == hipSuccess && out_laplacian) e = hipMemcpy(out_laplacian, d_L, mat, hipMemcpyDeviceToHost);
-    (void)hipFree(ws);
+    if (W->cap > ((size_t)256 << 20)) {     // do not sit on a multi-GB workspace
+        (void)hipFree(W->p);
+        W->p = nullptr;
+        W->cap = 0;
+    }
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("graph matrices: ") + hipGetErrorString(e));
     return ST_OK;
 }
