@@ -153,7 +153,74 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
     return r;
 }
 
-// Ladder form of pair_canopy_split (deep canopies).  `lad` is the ladder table, `cdepth` the
+// Meeting node of two canopy nodes from the sparse table (tree_prep.h): two 2-byte rank reads
+// and two 4-byte table reads, no climbing.  Returns depth << 16 | canopy index.
+ST_HD uint32_t canopy_meet(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ rmq, int32_t n_canopy,
+                           uint32_t pa, uint32_t pb)
+{
+    const uint32_t ra = pos[pa], rb = pos[pb];
+    const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
+    const uint32_t len = r - l + 1;
+    uint32_t k = 0;
+    while ((2u << k) <= len) k++;                       // floor(log2(len)); len <= 16384
+    const uint32_t e1 = rmq[(size_t)k * (size_t)n_canopy + l];
+    const uint32_t e2 = rmq[(size_t)k * (size_t)n_canopy + (r + 1 - (1u << k))];
+    return (e2 >> 16) < (e1 >> 16) ? e2 : e1;
+}
+
+// Ladder form of pair_canopy_split (deep canopies).  `lad` is the ladder table (LDS on the
+// device).  The meeting node `meet` (depth << 16 | canopy index, from canopy_meet) and the
+// depths of the two portals are known, so both sums know how many edges they climb and add
+// them three per 16-byte entry, in lineage order: a's canopy edges onto pbot_a, b's
+// understory, b's canopy edges.
+template <int CAP, typename LadPtr>
+ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy_id, uint32_t meet,
+                                  uint32_t pa, uint32_t da, float pbot_a, uint32_t pb, uint32_t db,
+                                  const float *D_b, uint32_t nb_b)
+{
+    const uint32_t dm = meet >> 16;
+    float s = pbot_a;
+    uint32_t k = da - dm;
+    uint32_t u = pa;
+    while (k >= 3) {
+        const LadderEntry e = lad[u];
+        s += e.d0; s += e.d1; s += e.d2;
+        u = e.link & 0xFFFFu;
+        k -= 3;
+    }
+    if (k) {
+        const LadderEntry e = lad[u];
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    if (CAP > 0) {
+#pragma unroll
+        for (int i = 0; i < CAP; i++)
+            if ((uint32_t)i < nb_b) s += D_b[i];
+    } else {
+        for (uint32_t i = 0; i < nb_b; i++) s += D_b[i];
+    }
+    k = db - dm;
+    uint32_t v = pb;
+    while (k >= 3) {
+        const LadderEntry e = lad[v];
+        s += e.d0; s += e.d1; s += e.d2;
+        v = e.link & 0xFFFFu;
+        k -= 3;
+    }
+    if (k) {
+        const LadderEntry e = lad[v];
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    PairResult r;
+    r.dist = s;
+    r.mrca = canopy_id[meet & 0xFFFFu];
+    return r;
+}
+
+// Ladder form of pair_canopy_split for trees whose ids are NOT an in-order numbering (no
+// sparse table): lock-step search for the meeting node.  `lad` is the ladder table, `cdepth` the
 // canopy depths (both LDS on the device).  Phase 1 finds the meeting node with integer work
 // only: the deeper lineage is lifted to the other's depth, then both climb in lock step three
 // levels at a time while their third ancestors differ, one level at a time once they agree.

@@ -349,7 +349,9 @@ struct CanopyParams {
     const CanopyEntry *canopy;     // [canopy_nodes] global copy, staged to LDS
     const int32_t *canopy_id;      // [canopy_nodes]
     const LadderEntry *ladder;     // [canopy_nodes] ladder form (deep canopies), staged to LDS instead of `canopy`
-    const uint16_t *cdepth;        // [canopy_nodes (padded to 8)] canopy depths, staged with the ladder
+    const uint16_t *cdepth;        // [canopy_nodes (padded to 8)] canopy depths
+    const uint16_t *cpos;          // [canopy_nodes] rank by node id; NULL unless ids are in-order positions
+    const uint32_t *rmq;           // [levels * canopy_nodes] sparse table of shallowest nodes (tree_prep.h)
     const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
@@ -376,47 +378,75 @@ __device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned cha
 // CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 is the generic form for records
 // longer than CAP allows in registers, which reads b's chain through a pointer.  LADDER: `image`
 // is the ladder form of the canopy (tree_prep.h), else the plain 8-byte entries.
-template <int CAP, bool LADDER>
-__device__ __forceinline__ PairResult canopy_pair_scalar(const CanopyParams &P, const unsigned char *image,
-                                                         long long sa, long long sb, int rec_bytes)
-{
-    const int half = rec_bytes / 2;
-    const uint8_t *rb = P.rec_b + sb * half;
-    // a: word0 and pbot (8 bytes of rec_a).  b: word0 + chain lengths (rec_b).
-    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-    const uint32_t wa = va.x;
-    const float pbot_a = __uint_as_float(va.y);
-    uint32_t wb;
+// The record reads of one pair: word0 + pbot of a (8 bytes of rec_a), word0 + chain of b (rec_b).
+template <int CAP>
+struct PairRecs {
+    uint32_t wa, wb;
+    float pbot_a;
     float Db[CAP > 0 ? CAP : 1];
+    const uint8_t *rb;
+    __device__ __forceinline__ const float *chain() const { return CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4); }
+};
+
+template <int CAP>
+__device__ __forceinline__ void load_pair_recs(const CanopyParams &P, long long sa, long long sb, int rec_bytes, PairRecs<CAP> &L)
+{
+    L.rb = P.rec_b + sb * (rec_bytes / 2);
+    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+    L.wa = va.x;
+    L.pbot_a = __uint_as_float(va.y);
     if (CAP == 1) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(rb);
-        wb = v.x;
-        Db[0] = __uint_as_float(v.y);
+        const uint2 v = *reinterpret_cast<const uint2 *>(L.rb);
+        L.wb = v.x;
+        L.Db[0] = __uint_as_float(v.y);
     } else if (CAP > 1) {
         uint32_t w[CAP + 1];
 #pragma unroll
         for (int q = 0; q < (CAP + 1) / 4; q++) {
-            const uint4 v = reinterpret_cast<const uint4 *>(rb)[q];
+            const uint4 v = reinterpret_cast<const uint4 *>(L.rb)[q];
             w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
-        wb = w[0];
+        L.wb = w[0];
 #pragma unroll
-        for (int q = 0; q < CAP; q++) Db[q] = __uint_as_float(w[q + 1]);
+        for (int q = 0; q < CAP; q++) L.Db[q] = __uint_as_float(w[q + 1]);
     } else {
-        wb = *reinterpret_cast<const uint32_t *>(rb);
-        Db[0] = 0.0f;
+        L.wb = *reinterpret_cast<const uint32_t *>(L.rb);
+        L.Db[0] = 0.0f;
     }
-    const uint32_t pa = wa & 0xFFFFu, pb = wb & 0xFFFFu;
+}
+
+// One pair, scalar, after its record reads: the climb, for a valid pair with record slots sa / sb.
+// CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 is the generic form for records
+// longer than CAP allows in registers, which reads b's chain through a pointer.  LADDER: `image`
+// is the ladder form of the canopy (tree_prep.h), else the plain 8-byte entries.
+template <int CAP, bool LADDER>
+__device__ __forceinline__ PairResult canopy_pair_finish(const CanopyParams &P, const unsigned char *image,
+                                                         const PairRecs<CAP> &L, long long sa, long long sb,
+                                                         int rec_bytes, uint32_t meet)
+{
+    const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
     if (pa != pb) {
-        const float *dptr = CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4);
-        if (LADDER)
-            return pair_ladder_split<CAP>(reinterpret_cast<const LadderEntry *>(image), P.cdepth, P.canopy_id,
-                                          pa, pbot_a, pb, dptr, wb >> 16);
-        return pair_canopy_split<CAP>(reinterpret_cast<const CanopyEntry *>(image), P.canopy_id, pa, pbot_a, pb,
-                                      dptr, wb >> 16);
+        if (LADDER) {
+            const LadderEntry *lad = reinterpret_cast<const LadderEntry *>(image);
+            if (meet != 0xFFFFFFFFu)      // meeting node known from the sparse table: only the sums remain
+                return pair_ladder_sums<CAP>(lad, P.canopy_id, meet, pa, P.cdepth[pa], L.pbot_a, pb, P.cdepth[pb], L.chain(), L.wb >> 16);
+            return pair_ladder_split<CAP>(lad, P.cdepth, P.canopy_id, pa, L.pbot_a, pb, L.chain(), L.wb >> 16);
+        }
+        return pair_canopy_split<CAP>(reinterpret_cast<const CanopyEntry *>(image), P.canopy_id, pa, L.pbot_a, pb,
+                                      L.chain(), L.wb >> 16);
     }
-    const RecTables R{P.rec_a, P.rec_b, P.rec_i, half};
+    const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
     return pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
+}
+
+template <int CAP, bool LADDER>
+__device__ __forceinline__ PairResult canopy_pair_scalar(const CanopyParams &P, const unsigned char *image,
+                                                         long long sa, long long sb, int rec_bytes,
+                                                         uint32_t meet = 0xFFFFFFFFu)
+{
+    PairRecs<CAP> L;
+    load_pair_recs<CAP>(P, sa, sb, rec_bytes, L);
+    return canopy_pair_finish<CAP, LADDER>(P, image, L, sa, sb, rec_bytes, meet);
 }
 
 // LDS image of the ladder form: canopy_nodes 16-byte entries (the depths stay in global
@@ -622,11 +652,12 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 // LDS reads; the meeting node is found first with integer work only (pair_math.h:
 // pair_ladder_split).  Not one float addition changes: same operands, same order.
 constexpr int kSortBuckets = 256;
-// LDS scratch of a tile of Q * 1024 pairs: one uint16 per pair (the sorted order), the bucket
-// array and the scan carries
-__host__ __device__ constexpr size_t sort_scratch_bytes(int q)
+// LDS scratch of a tile of Q * 1024 pairs: per pair one uint16 (the sorted order) and -- when
+// the meeting nodes come from the sparse table -- one uint32 (the pair's meeting node), then
+// the bucket array and the scan carries
+__host__ __device__ constexpr size_t sort_scratch_bytes(int q, bool rmq)
 {
-    return (size_t)q * kCanopyBlock * 2 + (size_t)kSortBuckets * 4 + 64;
+    return (size_t)q * kCanopyBlock * (2 + (rmq ? 4 : 0)) + (size_t)kSortBuckets * 4 + 64;
 }
 
 template <int CAP, int Q, typename Src>
@@ -639,9 +670,11 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
     constexpr int kSortTile = Q * kCanopyBlock;
     stage_ladder(P, lds_raw);
     unsigned char *scratch = lds_raw + ladder_image_bytes(P.canopy_nodes);
+    const bool have_rmq = P.rmq != nullptr;
     uint32_t *HIST = reinterpret_cast<uint32_t *>(scratch);          // [kSortBuckets] counts, then exclusive starts
     uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
     uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
+    uint32_t *MEET = reinterpret_cast<uint32_t *>(PERM + kSortTile); // [kSortTile] meeting node (depth << 16 | index), sparse-table mode
 
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const int half = rec_bytes / 2;
@@ -650,7 +683,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
     for (long long base = (long long)blockIdx.x * kSortTile; base < n; base += (long long)gridDim.x * kSortTile) {
         if (threadIdx.x < kSortBuckets) HIST[threadIdx.x] = 0;
         __syncthreads();
-        // keys: deeper portal of the pair, in units of 2^key_shift levels
+        // keys, in units of 2^key_shift levels: the canopy edges the pair will climb (its meeting
+        // node comes out of the sparse table right here), or -- ids not in order, no table -- the
+        // depth of its deeper portal
         uint32_t key[Q], rank[Q];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
@@ -671,7 +706,14 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                     const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
                     const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
                     const uint32_t da = cdep[pa], db = cdep[pb];
-                    uint32_t k = (da > db ? da : db) >> key_shift;
+                    uint32_t k;
+                    if (have_rmq) {
+                        const uint32_t meet = canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb);
+                        MEET[j] = meet;
+                        k = (da + db - 2 * (meet >> 16)) >> key_shift;
+                    } else {
+                        k = (2 * (da > db ? da : db)) >> key_shift;
+                    }
                     key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
                     rank[q] = atomicAdd(&HIST[key[q]], 1u);
                 }
@@ -712,10 +754,10 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
             long long a, b;
             src.load(base + j, a, b);     // (the tile was read a moment ago: an L2 hit; validated then)
             const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-            const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes);
+            const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes, have_rmq ? MEET[j] : 0xFFFFFFFFu);
             store_result(out_d, out_m, base + j, r.dist, r.mrca);
         }
-        __syncthreads();     // the next tile overwrites PERM
+        __syncthreads();     // the next tile overwrites PERM and MEET
     }
 }
 
@@ -887,6 +929,8 @@ struct st_tree {
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
     LadderEntry *d_ladder = nullptr;
     uint16_t *d_cdepth = nullptr;
+    uint16_t *d_cpos = nullptr;     // sparse table for the meeting node (in-order ids only)
+    uint32_t *d_rmq = nullptr;
     int canopy_depth = 0;     // deepest canopy node (edges)
     int small_batch_path = 1; // tuning: batches <= kMailboxPairs go through the pinned mailbox
     // staging of the host entry points: the device's shared pipe
@@ -935,17 +979,31 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     return hipGetLastError();
 }
 
-// pairs per lane of the tile-sorted kernel: 2 when image + scratch fit half the LDS (two
-// workgroups per CU), else 4 with one workgroup per CU; 0 = the ladder image does not fit
-static int sorted_q(const st_tree *t)
+// Shape of the tile-sorted launch: pairs per lane (2 when image + scratch fit half the LDS, i.e.
+// two workgroups per CU; else 4 with one workgroup per CU) and whether the meeting nodes come
+// from the sparse table (in-order ids, and the extra 4 bytes per pair of scratch still leave
+// room for the same tile) or from the lock-step search.  q = 0: the ladder image does not fit.
+struct SortedShape {
+    int q;
+    bool rmq;
+};
+
+static SortedShape sorted_shape(const st_tree *t)
 {
     const size_t image = ladder_image_bytes(t->canopy_nodes);
     static const int forced = std::getenv("SUCHTREE_AMD_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_SORT_Q")) : 0;   // tuning experiments
-    if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced) <= 160 * 1024) return forced;
-    if (image + sort_scratch_bytes(2) <= 80 * 1024) return 2;
-    if (image + sort_scratch_bytes(4) <= 160 * 1024) return 4;
-    return 0;
+    const bool table = t->d_rmq != nullptr;
+    for (const bool rmq : {table, false}) {
+        if (rmq != table && !table) break;
+        if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, rmq) <= 160 * 1024) return {forced, rmq};
+        if (image + sort_scratch_bytes(2, rmq) <= 80 * 1024) return {2, rmq};
+        if (image + sort_scratch_bytes(4, rmq) <= 160 * 1024) return {4, rmq};
+    }
+    if (image + sort_scratch_bytes(2, false) <= 160 * 1024) return {2, false};
+    return {0, false};
 }
+
+static int sorted_q(const st_tree *t) { return sorted_shape(t).q; }
 
 static bool wants_device_stage(const st_tree *t, int64_t m)
 {
@@ -956,21 +1014,24 @@ template <int CAP, typename Src>
 static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                        DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
 {
-    const int q = sorted_q(t);
-    const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q);
+    const SortedShape shape = sorted_shape(t);
+    const int q = shape.q;
+    const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q, shape.rmq);
+    CanopyParams Pk = P;
+    if (!shape.rmq) { Pk.cpos = nullptr; Pk.rmq = nullptr; }
     const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t tile = (int64_t)q * kCanopyBlock;
     int64_t blocks = (n + tile - 1) / tile;
     blocks = std::max<int64_t>(std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu), 1);
-    int key_shift = 0;
-    while ((t->canopy_depth >> key_shift) >= kSortBuckets) key_shift++;
+    int key_shift = 0;     // keys are edge counts of up to twice the canopy's depth
+    while (((2 * t->canopy_depth) >> key_shift) >= kSortBuckets) key_shift++;
     auto go = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, Pk, src,
                            (long long)n, out_d, out_m, fault, key_shift);
         return hipGetLastError();
     };
@@ -1006,6 +1067,8 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.canopy_id = t->d_canopy_id;
     P.ladder = t->d_ladder;
     P.cdepth = t->d_cdepth;
+    P.cpos = t->d_cpos;
+    P.rmq = t->d_rmq;
     P.rec_a = t->d_rec_a;
     P.rec_b = t->d_rec_b;
     P.rec_i = t->d_rec_i;
@@ -1017,7 +1080,7 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
     // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
     if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 &&
-        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t)) > 80 * 1024)
+        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq) > 80 * 1024)
         return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
     switch (t->rec_cap) {
         case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream);
@@ -1509,6 +1572,10 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
             cd.resize((cd.size() + 7) / 8 * 8, 0);     // 16-byte staging granule
             rc = upload(&t->d_cdepth, cd, &bytes);
         }
+        if (rc == ST_OK && B.deep && T.inorder_ids && !T.canopy_rmq.empty()) {
+            rc = upload(&t->d_cpos, T.canopy_pos, &bytes);
+            if (rc == ST_OK) rc = upload(&t->d_rmq, T.canopy_rmq, &bytes);
+        }
         if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
@@ -1659,6 +1726,8 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_canopy_id);
         (void)hipFree(t->d_ladder);
         (void)hipFree(t->d_cdepth);
+        (void)hipFree(t->d_cpos);
+        (void)hipFree(t->d_rmq);
         (void)hipFree(t->d_rec_a);
         (void)hipFree(t->d_rec_b);
         (void)hipFree(t->d_rec_i);

@@ -68,6 +68,22 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
         if (p >= 0) T.height[(size_t)p] = std::max(T.height[(size_t)p], T.height[(size_t)x] + 1);
     }
     T.parity_layout = parity && (T.n_leaves == (n + 1) / 2);
+    {   // in-order numbering: every internal node x has exactly two children whose subtrees
+        // occupy the id ranges [lo, x-1] and [x+1, hi]
+        std::vector<int32_t> lo((size_t)n), hi((size_t)n);
+        bool ok = true;
+        for (int64_t k = n - 1; k >= 0 && ok; k--) {
+            const int32_t x = T.bfs_order[(size_t)k];
+            const int64_t c0 = off[(size_t)x], c1 = off[(size_t)x + 1];
+            if (c1 == c0) { lo[(size_t)x] = hi[(size_t)x] = x; continue; }
+            if (c1 - c0 != 2) { ok = false; break; }
+            const int32_t l = child[(size_t)c0], r = child[(size_t)c0 + 1];     // increasing id
+            if (hi[(size_t)l] != x - 1 || lo[(size_t)r] != x + 1) { ok = false; break; }
+            lo[(size_t)x] = lo[(size_t)l];
+            hi[(size_t)x] = hi[(size_t)r];
+        }
+        T.inorder_ids = ok;
+    }
     T.tree_depth = max_leaf_depth + 1;   // MuchTree.pyx:218-225 counts nodes
 
     T.nodes.resize((size_t)n);
@@ -141,6 +157,34 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     }
     T.canopy_nodes = (int32_t)T.canopy.size();
     if (T.canopy_nodes < 1 || T.canopy_nodes > kMaxCanopyNodes || T.canopy_nodes > 65535) return false;
+    T.canopy_pos.clear();
+    T.canopy_rmq.clear();
+    T.rmq_levels = 0;
+    if (T.inorder_ids) {   // sparse table for the meeting node (see tree_prep.h)
+        const int32_t C = T.canopy_nodes;
+        std::vector<int32_t> by_id((size_t)C);
+        for (int32_t c = 0; c < C; c++) by_id[(size_t)c] = c;
+        std::sort(by_id.begin(), by_id.end(), [&](int32_t a, int32_t b) { return T.canopy_id[(size_t)a] < T.canopy_id[(size_t)b]; });
+        T.canopy_pos.assign((size_t)C, 0);
+        for (int32_t r = 0; r < C; r++) T.canopy_pos[(size_t)by_id[(size_t)r]] = (uint16_t)r;
+        int32_t levels = 1;
+        while ((1 << levels) <= C) levels++;
+        T.rmq_levels = levels;
+        T.canopy_rmq.assign((size_t)levels * (size_t)C, 0u);
+        for (int32_t r = 0; r < C; r++) {
+            const int32_t c = by_id[(size_t)r];
+            T.canopy_rmq[(size_t)r] = ((T.canopy[(size_t)c].link >> 16) << 16) | (uint32_t)c;
+        }
+        for (int32_t k = 1; k < levels; k++) {
+            const uint32_t *lo = T.canopy_rmq.data() + (size_t)(k - 1) * (size_t)C;
+            uint32_t *cur = T.canopy_rmq.data() + (size_t)k * (size_t)C;
+            const int32_t half = 1 << (k - 1);
+            for (int32_t i = 0; i < C; i++) {
+                const uint32_t a = lo[i], b = i + half < C ? lo[i + half] : a;
+                cur[i] = (b >> 16) < (a >> 16) ? b : a;
+            }
+        }
+    }
     T.canopy[0].dist = 0.0f;   // root: never added
     // ladder form: parents precede children in BFS order, so parent entries are complete
     T.ladder.assign((size_t)T.canopy_nodes, LadderEntry{0.0f, 0.0f, 0.0f, 0u});

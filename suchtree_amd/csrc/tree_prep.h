@@ -85,6 +85,7 @@ struct TreeTables {
     int32_t root = -1;
     int32_t tree_depth = 0;             // nodes on the longest leaf->root path
     bool parity_layout = false;         // leaves are exactly the even ids
+    bool inorder_ids = false;           // strictly binary and ids = in-order positions (every tree of the reference)
     std::vector<Node8> nodes;           // [n]
     std::vector<int32_t> depth;         // [n] edges to root
     std::vector<Stride3> stride;        // [n] stride-3 image (walk family)
@@ -100,6 +101,15 @@ struct TreeTables {
     std::vector<int32_t> canopy_id;     // [canopy_nodes] canopy index -> node id
     std::vector<LadderEntry> ladder;    // [canopy_nodes] ladder form of the same canopy (see LadderEntry)
     std::vector<uint16_t> canopy_depth; // [canopy_nodes] edges to the root
+    // Meeting node of two canopy nodes in O(1): node ids are in-order positions of a strictly
+    // binary tree, so the MRCA of u and v is THE minimum-depth node among those whose id lies
+    // between theirs -- and it is a canopy node (the canopy is closed under "parent of").
+    // canopy_pos[c] = rank of canopy node c when the canopy is sorted by node id;
+    // canopy_rmq[k * canopy_nodes + i] = (depth << 16 | canopy index) of the shallowest node
+    // among ranks [i, i + 2^k): a sparse table, one 4-byte read per half of a query.
+    std::vector<uint16_t> canopy_pos;   // [canopy_nodes]
+    std::vector<uint32_t> canopy_rmq;   // [rmq_levels * canopy_nodes]
+    int32_t rmq_levels = 0;
     std::vector<uint8_t> rec_a;         // [n * 8], slot order
     std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
     std::vector<uint8_t> rec_i;         // [n * record_bytes/2]

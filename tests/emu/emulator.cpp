@@ -72,10 +72,25 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                 r = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), wa & 0xFFFFu, pbot_a,
                                          B.portal, B.D, B.nb);
                 // the ladder form of the same canopy must agree bit for bit
-                const PairResult l = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(),
-                                                          wa & 0xFFFFu, pbot_a, B.portal, B.D, B.nb);
+                // in-order trees: meeting node from the sparse table, then the two sums with known
+                // edge counts; other trees: lock-step search on the ladder
+                const uint32_t pa = wa & 0xFFFFu, pb = B.portal;
+                PairResult l;
+                if (T.inorder_ids) {
+                    const uint32_t meet = canopy_meet(T.canopy_pos.data(), T.canopy_rmq.data(), T.canopy_nodes, pa, pb);
+                    l = pair_ladder_sums<0>(T.ladder.data(), T.canopy_id.data(), meet, pa, T.canopy_depth[pa],
+                                            pbot_a, pb, T.canopy_depth[pb], B.D, B.nb);
+                    const PairResult l2 = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(),
+                                                               pa, pbot_a, pb, B.D, B.nb);
+                    if (l2.mrca != l.mrca || std::memcmp(&l2.dist, &l.dist, 4) != 0) {
+                        g_err = "sparse-table form disagrees with the lock-step ladder form";
+                        return 5;
+                    }
+                } else {
+                    l = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(), pa, pbot_a, pb, B.D, B.nb);
+                }
                 if (l.mrca != r.mrca || std::memcmp(&l.dist, &r.dist, 4) != 0) {
-                    g_err = "ladder climb disagrees with the plain canopy climb";
+                    g_err = "sparse-table / ladder form disagrees with the plain canopy climb";
                     return 4;
                 }
             }
