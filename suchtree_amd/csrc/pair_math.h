@@ -28,9 +28,23 @@ struct PairResult {
 // level (Node8::parent) once they agree.  Both sums then know their edge counts and add three
 // edges per 16-byte gather, in lineage order: a's edges from 0, then b's onto the same
 // accumulator, exactly the reference's two loops (MuchTree.pyx:934-942).
+// `rmq` (optional): the whole-tree sparse table of tree_prep.h -- the meeting node and its
+// depth from two 8-byte reads, no climbing.
 ST_HD int32_t pair_walk_mrca(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
-                             const Stride3 *__restrict__ stride, int32_t a, int32_t b, int32_t *depth_of_mrca = nullptr)
+                             const Stride3 *__restrict__ stride, int32_t a, int32_t b, int32_t *depth_of_mrca = nullptr,
+                             const uint64_t *__restrict__ rmq = nullptr, int64_t n_nodes = 0)
 {
+    if (rmq) {
+        const uint32_t l = (uint32_t)(a < b ? a : b), r = (uint32_t)(a < b ? b : a);
+        const uint32_t len = r - l + 1;
+        uint32_t k = 0;
+        while ((2ull << k) <= len) k++;
+        const uint64_t e1 = rmq[(size_t)k * (size_t)n_nodes + l];
+        const uint64_t e2 = rmq[(size_t)k * (size_t)n_nodes + (r + 1 - (1u << k))];
+        const uint64_t e = e2 < e1 ? e2 : e1;
+        if (depth_of_mrca) *depth_of_mrca = (int32_t)(e >> 32);
+        return (int32_t)(uint32_t)e;
+    }
     int32_t x = a, y = b;
     int32_t dx = depth[x], dy = depth[y];
     while (dx > dy) {
@@ -65,11 +79,12 @@ ST_HD float walk_sum(const Stride3 *__restrict__ stride, float s, int32_t u, int
 }
 
 ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
-                           const Stride3 *__restrict__ stride, int32_t a, int32_t b)
+                           const Stride3 *__restrict__ stride, int32_t a, int32_t b,
+                           const uint64_t *__restrict__ rmq = nullptr, int64_t n_nodes = 0)
 {
     int32_t dm;
     const int32_t da = depth[a], db = depth[b];
-    const int32_t m = pair_walk_mrca(nodes, depth, stride, a, b, &dm);
+    const int32_t m = pair_walk_mrca(nodes, depth, stride, a, b, &dm, rmq, n_nodes);
     float s = walk_sum(stride, 0.0f, a, da - dm);
     s = walk_sum(stride, s, b, db - dm);
     PairResult r;

@@ -226,6 +226,7 @@ struct WalkParams {
     const Node8 *nodes;
     const int32_t *depth;
     const Stride3 *stride;
+    const uint64_t *rmq;     // whole-tree sparse table for the meeting node, or NULL
     long long n_nodes;
 };
 
@@ -245,10 +246,10 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
             continue;
         }
         if (out_d.any()) {
-            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b);
+            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, P.rmq, P.n_nodes);
             store_result(out_d, out_m, i, r.dist, r.mrca);
         } else {
-            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b);
+            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, nullptr, P.rmq, P.n_nodes);
         }
     }
 }
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void k_quartets(WalkParams P, const long long 
         int M[6];
 #pragma unroll
         for (int j = 0; j < 6; j++)
-            M[j] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)id[pa[j]], (int32_t)id[pb[j]]);
+            M[j] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)id[pa[j]], (int32_t)id[pb[j]], nullptr, P.rmq, P.n_nodes);
         int pick = 5;
 #pragma unroll
         for (int j = 5; j >= 0; j--) {
@@ -913,6 +914,7 @@ struct st_tree {
     Node8 *d_nodes = nullptr;
     int32_t *d_depth = nullptr;
     Stride3 *d_stride = nullptr;
+    uint64_t *d_tree_rmq = nullptr;   // whole-tree sparse table (in-order ids, small trees), else NULL
     CanopyEntry *d_canopy = nullptr;
     int32_t *d_canopy_id = nullptr;
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
@@ -1099,6 +1101,7 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
     P.stride = t->d_stride;
+    P.rmq = t->d_tree_rmq;
     P.n_nodes = t->n_nodes;
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
@@ -1255,6 +1258,7 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
     P.stride = t->d_stride;
+    P.rmq = t->d_tree_rmq;
     P.n_nodes = t->n_nodes;
     const SrcContig src{reinterpret_cast<const long long *>(d_base)};
     double *d_dist = reinterpret_cast<double *>(d_base + (size_t)kMailboxPairs * 16);
@@ -1555,6 +1559,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     int rc = upload(&t->d_nodes, T.nodes, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_stride, T.stride, &bytes);
+    if (rc == ST_OK && !T.tree_rmq.empty()) rc = upload(&t->d_tree_rmq, T.tree_rmq, &bytes);
     if (rc == ST_OK && B.canopy_ok) {
         t->has_canopy = true;
         t->canopy_nodes = T.canopy_nodes;
@@ -1722,6 +1727,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_nodes);
         (void)hipFree(t->d_depth);
         (void)hipFree(t->d_stride);
+        (void)hipFree(t->d_tree_rmq);
         (void)hipFree(t->d_canopy);
         (void)hipFree(t->d_canopy_id);
         (void)hipFree(t->d_ladder);
@@ -2125,6 +2131,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
     P.stride = t->d_stride;
+    P.rmq = t->d_tree_rmq;
     P.n_nodes = t->n_nodes;
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);

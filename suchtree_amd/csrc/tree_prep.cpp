@@ -84,6 +84,26 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
         }
         T.inorder_ids = ok;
     }
+    T.tree_rmq.clear();
+    T.tree_rmq_levels = 0;
+    if (T.inorder_ids) {
+        int32_t levels = 1;
+        while (((int64_t)1 << levels) <= n) levels++;
+        if ((int64_t)levels * n * 8 <= kMaxTreeRmqBytes) {
+            T.tree_rmq_levels = levels;
+            T.tree_rmq.resize((size_t)levels * (size_t)n);
+            for (int64_t i = 0; i < n; i++) T.tree_rmq[(size_t)i] = ((uint64_t)(uint32_t)T.depth[(size_t)i] << 32) | (uint64_t)(uint32_t)i;
+            for (int32_t k = 1; k < levels; k++) {
+                const uint64_t *lo = T.tree_rmq.data() + (size_t)(k - 1) * (size_t)n;
+                uint64_t *cur = T.tree_rmq.data() + (size_t)k * (size_t)n;
+                const int64_t half = (int64_t)1 << (k - 1);
+                for (int64_t i = 0; i < n; i++) {
+                    const uint64_t a = lo[i], b = i + half < n ? lo[i + half] : a;
+                    cur[i] = b < a ? b : a;        // depth in the high word: the shallower entry is the smaller
+                }
+            }
+        }
+    }
     T.tree_depth = max_leaf_depth + 1;   // MuchTree.pyx:218-225 counts nodes
 
     T.nodes.resize((size_t)n);

@@ -77,6 +77,7 @@ static_assert(sizeof(LadderEntry) == 16, "LadderEntry must be 16 bytes");
 constexpr int kMaxCanopyNodes = 16384;   // 16384 * 8 B = 128 KiB of the 160 KiB LDS
 constexpr int kMaxRecordBytes = 512;
 constexpr int kMinRecordBytes = 16;
+constexpr int64_t kMaxTreeRmqBytes = (int64_t)64 << 20;   // whole-tree sparse table: trees of up to ~450k nodes
 inline int record_cap_for(int rec_bytes) { return rec_bytes / 8 - 1; }
 
 struct TreeTables {
@@ -89,6 +90,12 @@ struct TreeTables {
     std::vector<Node8> nodes;           // [n]
     std::vector<int32_t> depth;         // [n] edges to root
     std::vector<Stride3> stride;        // [n] stride-3 image (walk family)
+    // Whole-tree sparse table for the walk family's meeting node (in-order ids only, and only
+    // while it stays small: kMaxTreeRmqBytes): tree_rmq[k * n + i] = depth << 32 | id of the
+    // shallowest node among ids [i, i + 2^k).  The MRCA of a and b is the shallowest node
+    // whose id lies between theirs: two 8-byte reads instead of a climb.
+    std::vector<uint64_t> tree_rmq;     // [tree_rmq_levels * n] or empty
+    int32_t tree_rmq_levels = 0;
     std::vector<int32_t> bfs_order;     // [n] scratch: parents before children
     std::vector<int32_t> height;        // [n] scratch: nodes down to the deepest leaf (leaf = 1)
     // canopy family (empty when the tree does not admit it)

@@ -52,6 +52,14 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
         PairResult r;
         if (!canopy) {
             r = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b);
+            if (!T.tree_rmq.empty()) {     // the sparse-table form of the meeting node must agree
+                const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
+                                               T.tree_rmq.data(), T.n);
+                if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
+                    g_err = "walk: sparse-table meeting node disagrees with the lock-step search";
+                    return 7;
+                }
+            }
             if (out_m && !out_d) r.mrca = pair_walk_mrca(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b);
         } else {
             const int64_t sa = record_slot(a, T.parity_layout, T.n_leaves);
