@@ -1692,9 +1692,13 @@ int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n
     int rc = check_create_args(parent, distance, n_nodes, strategy, out);
     if (rc != ST_OK) return rc;
     if (!devices || n_devices < 1) return fail(ST_ERR_ARG, "devices is NULL or n_devices < 1");
-    for (int i = 0; i < n_devices; i++)
-        for (int j = 0; j < i; j++)
-            if (devices[i] == devices[j]) return fail(ST_ERR_ARG, "device " + std::to_string(devices[i]) + " listed twice");
+    // (SUCHTREE_AMD_ALLOW_DUPLICATE_DEVICES=1: testing aid -- several replicas on one GPU, so that
+    // the dealing of chunks over replicas can run on a single-GPU box; they take turns on its pipe)
+    const char *dup = std::getenv("SUCHTREE_AMD_ALLOW_DUPLICATE_DEVICES");
+    if (!dup || dup[0] != '1')
+        for (int i = 0; i < n_devices; i++)
+            for (int j = 0; j < i; j++)
+                if (devices[i] == devices[j]) return fail(ST_ERR_ARG, "device " + std::to_string(devices[i]) + " listed twice");
     BuiltTables B;
     rc = build_tables(parent, distance, n_nodes, strategy, B);
     if (rc != ST_OK) return rc;

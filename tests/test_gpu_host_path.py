@@ -244,3 +244,33 @@ def test_create_destroy_cycles_do_not_leak_device_or_pinned_memory(tree17):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 25 create/close cycles" % ((free0 - free1) >> 20)
+
+
+def test_chunks_dealt_over_several_replicas(tree17, monkeypatch):
+    """The multi-device code path on a one-GPU box: three replicas of the tree on device 0 (a
+    testing aid, SUCHTREE_AMD_ALLOW_DUPLICATE_DEVICES), one host thread each, chunks dealt
+    round-robin, fault words merged -- the results must not depend on who computed what."""
+    monkeypatch.setenv("SUCHTREE_AMD_ALLOW_DUPLICATE_DEVICES", "1")
+    parent, dist, O = tree17
+    T = SuchTree((parent, dist), devices=[0, 0, 0])
+    assert T.device_info()["n_devices"] == 3
+    rng = np.random.default_rng(19)
+    n = 3_300_001                                   # 13 chunks of 2^18 pairs over three replicas
+    assert len(_capi.host_chunk_map(n, 3)) >= 9
+    pairs = rng.integers(0, len(parent), (n, 2))
+    d, m = T.distances_and_ancestors_bulk(pairs)
+    for lo in (0, 1_000_000, n - 300_000):
+        assert_bits_equal(d[lo:lo + 300_000], O.distances(pairs[lo:lo + 300_000]))
+        assert np.array_equal(m[lo:lo + 300_000], O.mrca_bulk(pairs[lo:lo + 300_000]))
+    ids = np.asarray(T.leaf_node_ids[:2600], dtype=np.int64)
+    tri, _ = T._device_tree().triangle_host(ids)                     # 3.4e6 generated pairs, dealt too
+    i, j = np.tril_indices(len(ids), -1)
+    sel = rng.integers(0, len(i), 300_000)
+    assert_bits_equal(tri[sel], O.distances(np.stack([ids[j[sel]], ids[i[sel]]], 1)))
+    bad = pairs.copy()
+    bad[2_900_000, 0] = len(parent) + 11            # lands in one replica's chunk ...
+    bad[100, 1] = -3                                # ... and this one in another's
+    with pytest.raises(InvalidNodeError) as e:
+        T.distances_bulk(bad)
+    assert e.value.node_id == len(parent) + 11      # max id too large wins over the negative one, as in the reference
+    T.close()
