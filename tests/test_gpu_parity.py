@@ -385,6 +385,13 @@ def test_general_trees_through_the_c_abi():
         for name, (d, m) in _both(dev, pairs).items():
             assert_bits_equal(d, want_d, name)
             assert np.array_equal(m, want_m), name
+        # the tile-sorted ladder kernel on ids that are not in-order positions: no sparse table,
+        # the meeting node comes from the lock-step search on the ladder
+        dev.set_strategy("canopy")
+        dev.set_option("tile_sort", 1)
+        d, m = dev.distances_host(pairs, True, True)
+        assert_bits_equal(d, want_d, "tile-sorted, lock-step")
+        assert np.array_equal(m, want_m)
         dev.close()
 
 
