@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -250,6 +251,38 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
             store_result(out_d, out_m, i, r.dist, r.mrca);
         } else {
             out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, nullptr, P.rmq, P.n_nodes);
+        }
+    }
+}
+
+// The mailbox form of k_walk (small host batches, one lane per pair, no grid stride): pairs and
+// results live in pinned host memory, and so does a completion word -- the last workgroup to
+// finish publishes the call's sequence number there (system-scope release after every block's
+// system-scope fence), so the host learns of completion by polling its own memory instead of
+// paying a stream synchronisation (the driver's wake-up costs as much as the whole kernel).
+__global__ __launch_bounds__(64) void k_walk_mailbox(WalkParams P, const long long *__restrict__ pairs, int n,
+                                                     double *__restrict__ out_d, int *__restrict__ out_m,
+                                                     unsigned *block_counter, unsigned *done_word, unsigned seq)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];   // (ids were range-checked on the host)
+        if (out_d) {
+            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)v.x, (int32_t)v.y, P.rmq, P.n_nodes);
+            out_d[i] = (double)r.dist;
+            if (out_m) out_m[i] = r.mrca;
+        } else {
+            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)v.x, (int32_t)v.y, nullptr, P.rmq, P.n_nodes);
+        }
+    }
+    __threadfence_system();            // this lane's results are visible to the host ...
+    __syncthreads();                   // ... and so are the whole block's
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(block_counter, 1u);
+        if (done == gridDim.x - 1) {   // last block of the launch
+            *block_counter = 0;        // (launches on the mailbox stream are serial)
+            __threadfence_system();
+            __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -943,7 +976,8 @@ struct st_tree {
     std::mutex mb_mutex;
     void *mb_host = nullptr;      // [pairs int64 x2 | dist double | mrca int32] x kMailboxPairs
     void *mb_dev = nullptr;       // device alias of mb_host
-    Fault *d_fault_mb = nullptr;  // scratch fault word of that path (ids are checked on the host there)
+    Fault *d_fault_mb = nullptr;  // 16 device bytes of that path: the mailbox kernel's block counter
+    unsigned mb_seq = 0;          // sequence number of the last mailbox call (its completion word)
     hipStream_t mb_stream = nullptr;
     // multi-device handle (st_tree_create_multi): replicas of this tree on the other devices.
     // Host-path calls deal their chunks over {this, peers...}; everything else uses this tree.
@@ -1230,11 +1264,13 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
 {
     std::lock_guard<std::mutex> lock(t->mb_mutex);
     if (!t->mb_host) {
-        const size_t bytes = (size_t)kMailboxPairs * (16 + 8 + 4);
+        const size_t bytes = (size_t)kMailboxPairs * (16 + 8 + 4) + 64;     // + the completion word
         ST_HIP(hipHostMalloc(&t->mb_host, bytes, hipHostMallocMapped));
         ST_HIP(hipHostGetDevicePointer(&t->mb_dev, t->mb_host, 0));
-        ST_HIP(hipMalloc(reinterpret_cast<void **>(&t->d_fault_mb), sizeof(Fault)));
+        ST_HIP(hipMalloc(reinterpret_cast<void **>(&t->d_fault_mb), sizeof(Fault)));      // [0]: block counter of the mailbox kernel
+        ST_HIP(hipMemset(t->d_fault_mb, 0, sizeof(Fault)));
         ST_HIP(hipStreamCreateWithFlags(&t->mb_stream, hipStreamNonBlocking));
+        *reinterpret_cast<volatile unsigned *>(static_cast<char *>(t->mb_host) + (size_t)kMailboxPairs * 28) = 0;
     }
     int64_t *h_pairs = static_cast<int64_t *>(t->mb_host);
     double *h_dist = reinterpret_cast<double *>(h_pairs + 2 * kMailboxPairs);
@@ -1260,14 +1296,31 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
     P.stride = t->d_stride;
     P.rmq = t->d_tree_rmq;
     P.n_nodes = t->n_nodes;
-    const SrcContig src{reinterpret_cast<const long long *>(d_base)};
     double *d_dist = reinterpret_cast<double *>(d_base + (size_t)kMailboxPairs * 16);
     int32_t *d_mrca = reinterpret_cast<int32_t *>(d_base + (size_t)kMailboxPairs * 24);
-    hipLaunchKernelGGL(k_walk<SrcContig>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, t->mb_stream, P, src,
-                       (long long)n, DistSink{out_dist ? d_dist : nullptr, nullptr},
-                       out_mrca ? d_mrca : nullptr, t->d_fault_mb);
+    unsigned *d_done = reinterpret_cast<unsigned *>(d_base + (size_t)kMailboxPairs * 28);
+    volatile unsigned *h_done = reinterpret_cast<volatile unsigned *>(static_cast<char *>(t->mb_host) + (size_t)kMailboxPairs * 28);
+    unsigned seq = ++t->mb_seq;
+    if (seq == 0) seq = ++t->mb_seq;     // (0 is the word's initial value)
+    hipLaunchKernelGGL(k_walk_mailbox, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, t->mb_stream, P,
+                       reinterpret_cast<const long long *>(d_base), (int)n, out_dist ? d_dist : nullptr,
+                       out_mrca ? d_mrca : nullptr, reinterpret_cast<unsigned *>(t->d_fault_mb), d_done, seq);
     ST_HIP(hipGetLastError());
-    ST_HIP(hipStreamSynchronize(t->mb_stream));
+    // poll the completion word (pinned host memory); if it does not show up within a few
+    // milliseconds something is wrong: let the runtime report it
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(const_cast<unsigned *>(h_done), __ATOMIC_ACQUIRE) != seq) {
+            _mm_pause();
+            if ((++spins & 4095) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                ST_HIP(hipStreamSynchronize(t->mb_stream));
+                if (__atomic_load_n(const_cast<unsigned *>(h_done), __ATOMIC_ACQUIRE) != seq)
+                    return fail(ST_ERR_HIP, "mailbox kernel finished without publishing its completion word");
+                break;
+            }
+        }
+    }
     if (out_dist) std::memcpy(out_dist, h_dist, (size_t)n * 8);
     if (out_mrca) std::memcpy(out_mrca, h_mrca, (size_t)n * 4);
     return ST_OK;
