@@ -148,6 +148,7 @@ struct PipeSlot {
 struct HostPipe {
     PipeSlot slot[2];
     int64_t cap = 0;          // pairs per slot
+    void *h_fault = nullptr;  // pinned copy of the tree's fault word, fetched behind the last chunk (16 bytes)
     void *d_ids = nullptr;    // id list of the all-pairs generator
     int64_t ids_cap = 0;
     CopyPool pool;
@@ -163,6 +164,10 @@ struct HostPipe {
             if ((e = hipHostMalloc(&s.h_m, (size_t)pairs * 4, hipHostMallocDefault)) != hipSuccess) return e;
             if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
             if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if (!h_fault) {
+            const hipError_t e = hipHostMalloc(&h_fault, 64, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
         }
         cap = pairs;
         // copy threads: a quarter of the hardware threads, at most 16 (the three memory passes
@@ -237,6 +242,8 @@ struct HostPipe {
         (void)hipFree(d_ids);
         d_ids = nullptr;
         ids_cap = 0;
+        (void)hipHostFree(h_fault);
+        h_fault = nullptr;
         pool.stop();
     }
 };

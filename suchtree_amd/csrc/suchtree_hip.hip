@@ -1435,8 +1435,9 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
 // own result array is pinned (HostOut::direct_*), that array itself.  Caller holds the
 // device pipe's mutex.
 template <typename Pack, typename Launch>
-static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, const HostOut &out)
+static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, const HostOut &out, Fault &fault)
 {
+    fault = kFaultInit;
     // results the kernels write directly need neither unpacking nor pre-faulting
     double *const out_dist = out.direct_d ? nullptr : out.dist;
     int32_t *const out_mrca = out.direct_m ? nullptr : out.mrca;
@@ -1492,6 +1493,14 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         pack(s, off, m);
         const int rc = launch(s, off, m);
         if (rc != ST_OK) return bail(rc, g_last_error);
+        if ((c + seq.step) * seq.chunk >= seq.n) {
+            // last chunk of this device: fetch the fault word behind it (and behind the chunk
+            // still in flight on the other stream), so that one wait covers results and faults
+            PipeSlot &other = P.slot[(k + 1) & 1];
+            if (other.busy) e = hipStreamWaitEvent(s.stream, other.done, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(P.h_fault, t->d_fault_host, sizeof(Fault), hipMemcpyDeviceToHost, s.stream);
+            if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
+        }
         e = hipEventRecord(s.done, s.stream);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         s.busy = true;
@@ -1505,6 +1514,15 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         const hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
+    if (k > 0) {
+        fault = *static_cast<const Fault *>(P.h_fault);
+        if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) {     // fired: re-arm
+            hipStream_t s0 = P.slot[0].stream;
+            ST_HIP(hipMemcpyAsync(t->d_fault_host, &kFaultInit, sizeof(Fault), hipMemcpyHostToDevice, s0));
+            ST_HIP(hipStreamSynchronize(s0));
+        }
+    }
+    t->host_fault_dirty = false;
     return ST_OK;
 }
 
@@ -1968,9 +1986,7 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
             s0 = r->dp->pipe.slot[0].stream;
         }
         int rc = begin_host_faults(r, s0);
-        if (rc == ST_OK) rc = run_pipe(r, seq, pack, launch, out);
-        if (rc != ST_OK) return rc;
-        rc = end_host_faults(r, s0, fault);
+        if (rc == ST_OK) rc = run_pipe(r, seq, pack, launch, out, fault);
         if (rc != ST_OK) return rc;
         // a clamped id always trips the device check as well; its exact value replaces the clamp
         if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) merge_fault(fault, wide);
@@ -2051,9 +2067,7 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
             const SrcTriangle src{static_cast<const long long *>(P.d_ids), 1, (long long)(k_begin + off)};
             return launch_chunk(r, s, off, c, 0, out, [&](const void *) { return src; });
         };
-        const int rc2 = run_pipe(r, seq, pack, launch, out);
-        if (rc2 != ST_OK) return rc2;
-        return end_host_faults(r, s0, fault);
+        return run_pipe(r, seq, pack, launch, out, fault);
     };
     Fault fault;
     rc = for_each_replica(t, k_count, fault, work);
@@ -2099,9 +2113,7 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
             const SrcGrid src{d_rows, d_cols, (long long)n_cols, (long long)(e_begin + off), symmetric};
             return launch_chunk(r, s, off, c, 0, out, [&](const void *) { return src; });
         };
-        const int rc2 = run_pipe(r, seq, pack, launch, out);
-        if (rc2 != ST_OK) return rc2;
-        return end_host_faults(r, s0, fault);
+        return run_pipe(r, seq, pack, launch, out, fault);
     };
     Fault fault;
     rc = for_each_replica(t, e_count, fault, work);
