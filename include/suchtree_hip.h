@@ -229,7 +229,8 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
  * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
- * device-mapped mailbox (one launch + one synchronisation), 0 = through the staged pipe. */
+ * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
+ * staged pipe. */
 int st_tree_set_option(st_tree *tree, const char *name, int64_t value);
 
 /*
