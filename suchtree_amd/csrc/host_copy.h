@@ -109,6 +109,25 @@ inline void populate_for_write(void *p, int64_t bytes)
     for (uintptr_t q = b; q < e; q += (uintptr_t)page) *reinterpret_cast<volatile char *>(q) = 0;
 }
 
+// Are the pages of [p, p + bytes) already resident?  Judged from its first, middle and last
+// page (mincore): result arrays are either fresh from mmap (nothing resident: populate them)
+// or recycled by the allocator / the caller (everything resident: MADV_POPULATE_WRITE would
+// still walk every page, several hundred microseconds per million pairs).  A wrong guess on a
+// partly touched range only costs ordinary page faults in the unpack loops.
+inline bool looks_resident(const void *p, int64_t bytes)
+{
+    static const long page = sysconf(_SC_PAGESIZE);
+    if (bytes <= 0) return true;
+    const uintptr_t first = reinterpret_cast<uintptr_t>(p) & ~((uintptr_t)page - 1);
+    const uintptr_t last = (reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes - 1) & ~((uintptr_t)page - 1);
+    const uintptr_t mid = (first + (last - first) / 2) & ~((uintptr_t)page - 1);
+    for (uintptr_t q : {first, mid, last}) {
+        unsigned char vec = 0;
+        if (mincore(reinterpret_cast<void *>(q), (size_t)page, &vec) != 0 || !(vec & 1)) return false;
+    }
+    return true;
+}
+
 inline void advise_huge(void *p, int64_t bytes)
 {
     const uintptr_t huge = (uintptr_t)2 << 20;

@@ -1,17 +1,18 @@
-// host_pipe.h -- the host-buffer path of the C ABI: pinned, double-buffered, zero-copy.
+// host_pipe.h -- the host-buffer path of the C ABI: pinned, multi-buffered, zero-copy.
 //
 // Callers of st_distances_host / st_triangle_host own ordinary (pageable) memory, which
-// the HIP runtime copies at ~10 GB/s.  The pipe keeps two slots of pinned staging memory
-// that the GPU reads and writes DIRECTLY over PCIe, two streams and a pool of copy threads:
+// the HIP runtime copies at ~10 GB/s.  The pipe keeps a few slots of pinned staging memory
+// that the GPU reads and writes DIRECTLY over PCIe (kPipeSlots of them, one stream each)
+// and a pool of copy threads:
 //
 //   pack(c)   : caller's pairs  -> pinned (parallel narrowing copy / strided gather)
-//   gpu(c)    : one kernel on stream c&1 that loads its pairs from the pinned slot and
+//   gpu(c)    : one kernel on the slot's stream that loads its pairs from the pinned slot and
 //               stores its results into the pinned slot; distances travel as float32
 //               (they are float32 sums), MRCA ids as int32
 //   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / copy)
 //
-// unpack(c-1) and pack(c+1) run on the CPU while gpu(c) is in flight.  There are no
-// hipMemcpyAsync calls and no device staging buffers: a kernel that reads 8 B and writes
+// unpack(c-2) and pack(c+1) run on the CPU while gpu(c-1) and gpu(c) are in flight.
+// There are no hipMemcpyAsync calls and no device staging buffers: a kernel that reads 8 B and writes
 // 8 B per lane from / to pinned host memory moves 96 GB/s over the link (both directions at
 // once), the same as one large H2D and one large D2H copy running concurrently, while
 // per-chunk H2D -> kernel -> D2H sequences on two streams fall into lock step (both
@@ -145,8 +146,13 @@ struct PipeSlot {
     bool busy = false;
 };
 
+// Three slots: while the host unpacks chunk c-2 and packs chunk c+1, chunks c-1 and c are on
+// the GPU / the link.  With two, the GPU idled through every unpack + pack + launch of the
+// host thread (a third of a million-pair call; SUCHTREE_AMD_TRACE_PIPE shows it as "wait").
+constexpr int kPipeSlots = 3;
+
 struct HostPipe {
-    PipeSlot slot[2];
+    PipeSlot slot[kPipeSlots];
     int64_t cap = 0;          // pairs per slot
     void *h_fault = nullptr;  // pinned copy of the tree's fault word, fetched behind the last chunk (16 bytes)
     void *d_ids = nullptr;    // id list of the all-pairs generator

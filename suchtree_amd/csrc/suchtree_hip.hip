@@ -902,7 +902,7 @@ __global__ void k_graph_laplacian(const double *__restrict__ A, const double *__
 // --------------------------------------------------------------------------
 using namespace st;
 
-// One staging pipe (pinned + device buffers, two streams, copy pool) per GPU, shared by every
+// One staging pipe (pinned + device buffers, one stream per slot, copy pool) per GPU, shared by every
 // tree of the process on that GPU: SuchLinkedTrees holds two trees, applications hold many,
 // and the staging is ~200 MB of pinned memory and up to 15 threads per pipe.  Reference
 // counted; the mutex admits one host-path call at a time per device.
@@ -1240,6 +1240,11 @@ constexpr int64_t kMailboxPairs = 8192;   // largest batch served through the ma
 // several devices the chunk shrinks (down to kHostChunkMin) so that every device gets work.
 static int64_t host_chunk_pairs(int64_t n, int n_dev)
 {
+    static const int64_t forced = [] {     // tuning experiments
+        const char *env = std::getenv("SUCHTREE_AMD_HOST_CHUNK");
+        return env ? std::max<int64_t>(1024, std::atoll(env)) / 1024 * 1024 : (int64_t)0;
+    }();
+    if (forced) return n <= forced ? std::max<int64_t>(n, 1) : forced;
     if (n <= kHostChunkMin) return std::max<int64_t>(n, 1);
     // at least eight chunks per device, so that packing, the link and unpacking overlap even
     // on batches of a few million pairs; never below kHostChunkMin, never above kHostChunk
@@ -1428,7 +1433,7 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
     return ST_OK;
 }
 
-// Push this device's chunks of a batch through the two-slot pipe (host_pipe.h).
+// Push this device's chunks of a batch through the slots of the pipe (host_pipe.h).
 // pack(slot, off, m) fills slot.h_in for chunk [off, off+m); launch(slot, off, m) enqueues
 // the kernel on slot.stream, reading slot.h_in and writing slot.h_d / slot.h_m -- pinned
 // host memory, accessed by the kernel over PCIe (see host_pipe.h) -- or, where the caller's
@@ -1438,6 +1443,17 @@ template <typename Pack, typename Launch>
 static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, const HostOut &out, Fault &fault)
 {
     fault = kFaultInit;
+    // SUCHTREE_AMD_TRACE_PIPE=1: one line per call on stderr with the host thread's time by phase
+    static const bool trace = std::getenv("SUCHTREE_AMD_TRACE_PIPE") != nullptr;
+    using Clock = std::chrono::steady_clock;
+    double t_wait = 0, t_unpack = 0, t_pack = 0, t_launch = 0, t_prefault = 0;
+    const Clock::time_point t_begin = Clock::now();
+    auto lap = [&](double &acc, Clock::time_point &since) {
+        if (!trace) return;
+        const Clock::time_point now = Clock::now();
+        acc += std::chrono::duration<double, std::micro>(now - since).count();
+        since = now;
+    };
     // results the kernels write directly need neither unpacking nor pre-faulting
     double *const out_dist = out.direct_d ? nullptr : out.dist;
     int32_t *const out_mrca = out.direct_m ? nullptr : out.mrca;
@@ -1452,8 +1468,10 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     auto drain = [&](PipeSlot &s) -> hipError_t {
         if (!s.busy) return hipSuccess;
         s.busy = false;
+        Clock::time_point tp = trace ? Clock::now() : Clock::time_point();
         const hipError_t e = hipEventSynchronize(s.done);
         if (e != hipSuccess) return e;
+        lap(t_wait, tp);
         // distances crossed PCIe as float32 and are widened into the caller's float64 array;
         // MRCA ids are copied; one pass of the pool over the chunk does both
         const float *src_d = static_cast<const float *>(s.h_d);
@@ -1465,15 +1483,20 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
                 if (dst_d) widen_f32_to_f64(dst_d + b, src_d + b, e - b);
                 if (dst_m) copy_stream(dst_m + b, src_m + b, (e - b) * 4);
             });
+        lap(t_unpack, tp);
         return hipSuccess;
     };
     // pages of a freshly allocated result array are populated here, by the pool, while the
     // chunk is on the GPU -- not one fault at a time inside the unpack loops
+    // (only pages that are not there yet: a recycled result array is resident already, and
+    // populating resident pages costs more than everything else a mid-sized call does)
     auto prefault = [&](int64_t off, int64_t m) {
-        if (!out_dist && !out_mrca) return;
+        double *const pd = out_dist && !looks_resident(out_dist + off, m * 8) ? out_dist : nullptr;
+        int32_t *const pm = out_mrca && !looks_resident(out_mrca + off, m * 4) ? out_mrca : nullptr;
+        if (!pd && !pm) return;
         P.pool.parallel_for(m, [=](int64_t b, int64_t e) {
-            if (out_dist) populate_for_write(out_dist + off + b, (e - b) * 8);
-            if (out_mrca) populate_for_write(out_mrca + off + b, (e - b) * 4);
+            if (pd) populate_for_write(pd + off + b, (e - b) * 8);
+            if (pm) populate_for_write(pm + off + b, (e - b) * 4);
         });
     };
     auto bail = [&](int code, const std::string &msg) {
@@ -1487,17 +1510,19 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     for (int64_t c = seq.first; c * seq.chunk < seq.n; c += seq.step, k++) {
         const int64_t off = c * seq.chunk;
         const int64_t m = std::min(seq.chunk, seq.n - off);
-        PipeSlot &s = P.slot[k & 1];
+        PipeSlot &s = P.slot[k % kPipeSlots];
         hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
+        Clock::time_point tp = trace ? Clock::now() : Clock::time_point();
         pack(s, off, m);
+        lap(t_pack, tp);
         const int rc = launch(s, off, m);
         if (rc != ST_OK) return bail(rc, g_last_error);
         if ((c + seq.step) * seq.chunk >= seq.n) {
             // last chunk of this device: fetch the fault word behind it (and behind the chunk
             // still in flight on the other stream), so that one wait covers results and faults
-            PipeSlot &other = P.slot[(k + 1) & 1];
-            if (other.busy) e = hipStreamWaitEvent(s.stream, other.done, 0);
+            for (PipeSlot &other : P.slot)
+                if (&other != &s && other.busy && e == hipSuccess) e = hipStreamWaitEvent(s.stream, other.done, 0);
             if (e == hipSuccess) e = hipMemcpyAsync(P.h_fault, t->d_fault_host, sizeof(Fault), hipMemcpyDeviceToHost, s.stream);
             if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         }
@@ -1506,12 +1531,14 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         s.busy = true;
         s.off = off;
         s.m = m;
+        lap(t_launch, tp);
         prefault(off, m);
-        e = drain(P.slot[(k + 1) & 1]);   // unpack the previous chunk while this one is in flight
+        lap(t_prefault, tp);
+        e = drain(P.slot[(k + 1) % kPipeSlots]);   // unpack the oldest chunk while the newer ones are in flight
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
-    for (auto &s : P.slot) {
-        const hipError_t e = drain(s);
+    for (int j = 0; j < kPipeSlots; j++) {     // oldest first
+        const hipError_t e = drain(P.slot[(k + j) % kPipeSlots]);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
     if (k > 0) {
@@ -1523,6 +1550,11 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         }
     }
     t->host_fault_dirty = false;
+    if (trace)
+        std::fprintf(stderr, "[pipe] n %lld chunk %lld chunks %lld total %.1f us: pack %.1f launch %.1f prefault %.1f wait %.1f unpack %.1f\n",
+                     (long long)seq.n, (long long)seq.chunk, (long long)k,
+                     std::chrono::duration<double, std::micro>(Clock::now() - t_begin).count(), t_pack, t_launch, t_prefault,
+                     t_wait, t_unpack);
     return ST_OK;
 }
 
@@ -1935,8 +1967,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
     }
     const HostOut out = make_host_out(out_dist, out_mrca, n);
     // fresh result arrays: ask for huge pages before the first touch (a no-op on resident memory)
-    if (out_dist && !out.direct_d) advise_huge(out_dist, n * 8);
-    if (out_mrca && !out.direct_m) advise_huge(out_mrca, n * 4);
+    if (out_dist && !out.direct_d && !looks_resident(out_dist, n * 8)) advise_huge(out_dist, n * 8);
+    if (out_mrca && !out.direct_m && !looks_resident(out_mrca, n * 4)) advise_huge(out_mrca, n * 4);
 
     // Ids cross PCIe as int32 (half the H2D bytes).  Values that do not fit are clamped to
     // INT32_MAX / INT32_MIN -- still out of range for the kernel -- and their exact extremes
@@ -2044,8 +2076,8 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
     const HostOut out = make_host_out(out_dist, out_mrca, k_count);
-    if (out_dist && !out.direct_d) advise_huge(out_dist, k_count * 8);
-    if (out_mrca && !out.direct_m) advise_huge(out_mrca, k_count * 4);
+    if (out_dist && !out.direct_d && !looks_resident(out_dist, k_count * 8)) advise_huge(out_dist, k_count * 8);
+    if (out_mrca && !out.direct_m && !looks_resident(out_mrca, k_count * 4)) advise_huge(out_mrca, k_count * 4);
     // the id list goes up once per device (packed); results stream back through the pipe
     std::vector<int64_t> packed;
     const int64_t *src_ids = ids;
@@ -2096,8 +2128,8 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
     if (symmetric && (n_rows != n_cols)) return fail(ST_ERR_ARG, "symmetric grid needs n_rows == n_cols");
     if (e_count == 0) return ST_OK;
     const HostOut out = make_host_out(out_dist, out_mrca, e_count);
-    if (out_dist && !out.direct_d) advise_huge(out_dist, e_count * 8);
-    if (out_mrca && !out.direct_m) advise_huge(out_mrca, e_count * 4);
+    if (out_dist && !out.direct_d && !looks_resident(out_dist, e_count * 8)) advise_huge(out_dist, e_count * 8);
+    if (out_mrca && !out.direct_m && !looks_resident(out_mrca, e_count * 4)) advise_huge(out_mrca, e_count * 4);
     auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
         HostPipe &P = r->dp->pipe;
         hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/suchtree_hip.h"
+#include "../../suchtree_amd/csrc/host_copy.h"
 #include "../../suchtree_amd/csrc/pair_math.h"
 #include "../../suchtree_amd/csrc/tree_prep.h"
 
@@ -106,9 +107,70 @@ static int check_newick(std::mt19937_64 &rng)
     return 0;
 }
 
+// The host path's memory passes (host_copy.h) at random sizes and alignments, against the
+// plain loops they replace; residency probe and pre-faulting on a fresh mapping.
+static int check_host_copy(std::mt19937_64 &rng)
+{
+    for (int round = 0; round < 300; round++) {
+        const int64_t m = (int64_t)(rng() % 5000);
+        const int skew_in = (int)(rng() % 4), skew_out = (int)(rng() % 4);
+        std::vector<int64_t> src((size_t)(2 * m + 4));
+        for (auto &v : src) v = (int64_t)(rng() % 3000000) - 5;
+        long long want_hi = std::numeric_limits<long long>::min(), want_lo = std::numeric_limits<long long>::max();
+        if (m > 0 && round % 3 == 0) {          // a few ids that do not fit int32
+            for (int k = 0; k < 3; k++) {
+                const long long big = (round % 2 ? 1 : -1) * ((long long)1 << (32 + k)) + (long long)(rng() % 1000);
+                src[(size_t)skew_in + (size_t)(rng() % (uint64_t)(2 * m))] = big;
+            }
+        }
+        std::vector<int32_t> got((size_t)(2 * m + 8), 77), want((size_t)(2 * m + 8), 77);
+        for (int64_t q = 0; q < 2 * m; q++) {
+            const long long v = src[(size_t)(skew_in + q)];
+            int32_t w = (int32_t)v;
+            if (v > INT32_MAX) { w = INT32_MAX; want_hi = std::max(want_hi, v); }
+            else if (v < INT32_MIN) { w = INT32_MIN; want_lo = std::min(want_lo, v); }
+            want[(size_t)(skew_out + q)] = w;
+        }
+        long long hi = std::numeric_limits<long long>::min(), lo = std::numeric_limits<long long>::max();
+        st::narrow_pairs_i64(got.data() + skew_out, src.data() + skew_in, m, hi, lo);
+        if (got != want || hi != want_hi || lo != want_lo) return 21;
+
+        std::vector<float> f((size_t)(m + 4));
+        for (auto &v : f) v = (float)((double)(rng() % 100000) / 977.0);
+        std::vector<double> dgot((size_t)(m + 4), -1.0), dwant((size_t)(m + 4), -1.0);
+        const int so = (int)(rng() % 3);
+        for (int64_t q = 0; q < m; q++) dwant[(size_t)(so + q)] = (double)f[(size_t)(skew_in + q)];
+        st::widen_f32_to_f64(dgot.data() + so, f.data() + skew_in, m);
+        if (std::memcmp(dgot.data(), dwant.data(), dgot.size() * 8) != 0) return 22;
+
+        std::vector<char> a((size_t)(m * 4 + 70)), b((size_t)(m * 4 + 70), 3), c((size_t)(m * 4 + 70), 3);
+        for (auto &v : a) v = (char)rng();
+        const int64_t bytes = (int64_t)(rng() % (uint64_t)(m * 4 + 1));
+        const int ao = (int)(rng() % 33), bo = (int)(rng() % 33);
+        std::memcpy(c.data() + bo, a.data() + ao, (size_t)bytes);
+        st::copy_stream(b.data() + bo, a.data() + ao, bytes);
+        if (b != c) return 23;
+    }
+    // a fresh anonymous mapping is not resident; after populate_for_write it is
+    const size_t len = (size_t)8 << 20;
+    void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return 24;
+    char *q = static_cast<char *>(p) + 24;      // (numpy-like: data starts a few bytes into the mapping)
+    if (st::looks_resident(q, (int64_t)len - 24)) return 25;
+    st::advise_huge(q, (int64_t)len - 24);
+    st::populate_for_write(q, (int64_t)len - 24);
+    q[0] = 1;                                   // the partial first and last pages are the copy loops' to touch
+    q[len - 25] = 1;
+    if (!st::looks_resident(q, (int64_t)len - 24)) return 26;
+    if (!st::looks_resident(q, 0)) return 27;
+    munmap(p, len);
+    return 0;
+}
+
 int main()
 {
     std::mt19937_64 rng(12345);
+    if (const int rc = check_host_copy(rng)) { std::printf("FAILED host_copy rc=%d\n", rc); return rc; }
     const int sizes[] = {1, 2, 3, 7, 64, 1000, 20000};
     const double skews[] = {0.0, 0.5, 0.9, 0.999};
     for (int n : sizes)
