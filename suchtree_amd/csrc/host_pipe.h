@@ -12,7 +12,8 @@
 //   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / copy)
 //
 // unpack(c-2) and pack(c+1) run on the CPU while gpu(c-1) and gpu(c) are in flight.
-// There are no hipMemcpyAsync calls and no device staging buffers: a kernel that reads 8 B and writes
+// On this direct form there are no hipMemcpyAsync calls and no device staging buffers (trees
+// served by the tile-sorted kernel stage their slots in device memory, ensure_device_stage): a kernel that reads 8 B and writes
 // 8 B per lane from / to pinned host memory moves 96 GB/s over the link (both directions at
 // once), the same as one large H2D and one large D2H copy running concurrently, while
 // per-chunk H2D -> kernel -> D2H sequences on two streams fall into lock step (both

@@ -1344,10 +1344,14 @@ __global__ __launch_bounds__(1024) void k_words_copy(const uint32_t *__restrict_
     for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) dst[i] = src[i];
 }
 
+// Copy kernels run beside the compute kernels of the other slots: a few dozen workgroups keep
+// the link busy and leave the CUs to them (with 512 the host path of ml.tree is 10 % slower).
+constexpr int64_t kCopyKernelBlocks = 32;
+
 static hipError_t enqueue_words_copy(const void *src, void *dst, int64_t n_words, hipStream_t stream)
 {
     if (n_words <= 0) return hipSuccess;
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n_words / 4 + 1023) / 1024, 512));
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n_words / 4 + 1023) / 1024, kCopyKernelBlocks));
     hipLaunchKernelGGL(k_words_copy, dim3((unsigned)blocks), dim3(1024), 0, stream, static_cast<const uint32_t *>(src),
                        static_cast<uint32_t *>(dst), (long long)n_words);
     return hipGetLastError();
@@ -1415,14 +1419,19 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
         int32_t *mrca = !out.mrca ? nullptr : out.direct_m ? out.mrca + off : static_cast<int32_t *>(s.h_m);
         return enqueue_src(r, make_src(s.h_in), m, sink, mrca, r->d_fault_host, s.stream);
     }
+    // Pairs come in through the copy engine, results go out through copy kernels: the two
+    // directions then overlap and the engine takes no CUs from the tile-sorted kernel (ml.tree,
+    // 2e7 pairs, both outputs: input by copy kernel as well 2.7e9 pairs/s, this way 3.7-4.0e9,
+    // both directions by the copy engine 3.3-3.5e9).
     hipError_t e = r->dp->pipe.ensure_device_stage();
-    if (e == hipSuccess && in_words_per_pair) e = enqueue_words_copy(s.h_in, s.d_in, m * in_words_per_pair, s.stream);
+    if (e == hipSuccess && in_words_per_pair)
+        e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * in_words_per_pair * 4, hipMemcpyHostToDevice, s.stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, out.dist ? static_cast<float *>(s.d_d) : nullptr},
                                out.mrca ? static_cast<int32_t *>(s.d_m) : nullptr, r->d_fault_host, s.stream);
     if (rc != ST_OK) return rc;
     if (out.dist && out.direct_d) {
-        hipLaunchKernelGGL(k_widen_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, 512))),
+        hipLaunchKernelGGL(k_widen_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, kCopyKernelBlocks))),
                            dim3(1024), 0, s.stream, static_cast<const float *>(s.d_d), out.dist + off, (long long)m);
         e = hipGetLastError();
     } else if (out.dist) {
