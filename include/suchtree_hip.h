@@ -228,6 +228,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * form (default for deep canopies).
  * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
  * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
+ * "lineage_sums": 1 (default) = on deep canopies with in-order ids the tile-sorted kernel reads
+ * the first node's whole side of a pair from a table of per-node lineage sums (one 4-byte read;
+ * table built when it stays below 1 GiB); 0 = it climbs that side through the canopy as well.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe. */

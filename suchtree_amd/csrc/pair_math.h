@@ -234,6 +234,41 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
     return r;
 }
 
+// pair_ladder_sums with a's side read from the lineage-sum table (tree_prep.h): `s_a` is the
+// reference's accumulator after a's edges up to the meeting node (canopy index `meet_index`);
+// b's understory and its `kb` canopy edges continue it, in lineage order, three canopy edges
+// per 16-byte entry.
+template <int CAP, typename LadPtr>
+ST_HD PairResult pair_ladder_sums_b(LadPtr lad, const int32_t *__restrict__ canopy_id, uint32_t meet_index,
+                                    uint32_t kb, float s_a, uint32_t pb, const float *D_b, uint32_t nb_b)
+{
+    float s = s_a;
+    if (CAP > 0) {
+#pragma unroll
+        for (int i = 0; i < CAP; i++)
+            if ((uint32_t)i < nb_b) s += D_b[i];
+    } else {
+        for (uint32_t i = 0; i < nb_b; i++) s += D_b[i];
+    }
+    uint32_t k = kb;
+    uint32_t v = pb;
+    while (k >= 3) {
+        const LadderEntry e = lad[v];
+        s += e.d0; s += e.d1; s += e.d2;
+        v = e.link & 0xFFFFu;
+        k -= 3;
+    }
+    if (k) {
+        const LadderEntry e = lad[v];
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    PairResult r;
+    r.dist = s;
+    r.mrca = canopy_id[meet_index];
+    return r;
+}
+
 // Ladder form of pair_canopy_split for trees whose ids are NOT an in-order numbering (no
 // sparse table): lock-step search for the meeting node.  `lad` is the ladder table, `cdepth` the
 // canopy depths (both LDS on the device).  Phase 1 finds the meeting node with integer work

@@ -389,6 +389,8 @@ struct CanopyParams {
     const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
+    const uint8_t *rec_p;          // [n_nodes * 8]            {word0, offset into lineage}; NULL without lineage sums
+    const float *lineage;          // lineage sums (tree_prep.h): a's whole side of a pair in one read
     long long n_nodes;
     long long n_leaves;
     int32_t canopy_nodes;
@@ -422,13 +424,10 @@ struct PairRecs {
     __device__ __forceinline__ const float *chain() const { return CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4); }
 };
 
+// b's record (L.rb set): word0 + chain
 template <int CAP>
-__device__ __forceinline__ void load_pair_recs(const CanopyParams &P, long long sa, long long sb, int rec_bytes, PairRecs<CAP> &L)
+__device__ __forceinline__ void load_rec_b(PairRecs<CAP> &L)
 {
-    L.rb = P.rec_b + sb * (rec_bytes / 2);
-    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-    L.wa = va.x;
-    L.pbot_a = __uint_as_float(va.y);
     if (CAP == 1) {
         const uint2 v = *reinterpret_cast<const uint2 *>(L.rb);
         L.wb = v.x;
@@ -447,6 +446,16 @@ __device__ __forceinline__ void load_pair_recs(const CanopyParams &P, long long 
         L.wb = *reinterpret_cast<const uint32_t *>(L.rb);
         L.Db[0] = 0.0f;
     }
+}
+
+template <int CAP>
+__device__ __forceinline__ void load_pair_recs(const CanopyParams &P, long long sa, long long sb, int rec_bytes, PairRecs<CAP> &L)
+{
+    L.rb = P.rec_b + sb * (rec_bytes / 2);
+    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+    L.wa = va.x;
+    L.pbot_a = __uint_as_float(va.y);
+    load_rec_b<CAP>(L);
 }
 
 // One pair, scalar, after its record reads: the climb, for a valid pair with record slots sa / sb.
@@ -689,9 +698,9 @@ constexpr int kSortBuckets = 256;
 // LDS scratch of a tile of Q * 1024 pairs: per pair one uint16 (the sorted order) and -- when
 // the meeting nodes come from the sparse table -- one uint32 (the pair's meeting node), then
 // the bucket array and the scan carries
-__host__ __device__ constexpr size_t sort_scratch_bytes(int q, bool rmq)
+__host__ __device__ constexpr size_t sort_scratch_bytes(int q, bool rmq, bool sums = false)
 {
-    return (size_t)q * kCanopyBlock * (2 + (rmq ? 4 : 0)) + (size_t)kSortBuckets * 4 + 64;
+    return (size_t)q * kCanopyBlock * (2 + (rmq ? 4 : 0) + (sums ? 8 : 0)) + (size_t)kSortBuckets * 4 + 64;
 }
 
 template <int CAP, int Q, typename Src>
@@ -705,10 +714,13 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
     stage_ladder(P, lds_raw);
     unsigned char *scratch = lds_raw + ladder_image_bytes(P.canopy_nodes);
     const bool have_rmq = P.rmq != nullptr;
+    const bool have_sums = have_rmq && P.lineage != nullptr;
     uint32_t *HIST = reinterpret_cast<uint32_t *>(scratch);          // [kSortBuckets] counts, then exclusive starts
     uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
     uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
     uint32_t *MEET = reinterpret_cast<uint32_t *>(PERM + kSortTile); // [kSortTile] meeting node (depth << 16 | index), sparse-table mode
+    float *SIDE_A = reinterpret_cast<float *>(MEET + kSortTile);     // [kSortTile] a's side of the pair, lineage-sum mode
+    uint32_t *SLOT_B = reinterpret_cast<uint32_t *>(SIDE_A + kSortTile);   // [kSortTile] b's record slot, lineage-sum mode
 
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const int half = rec_bytes / 2;
@@ -737,11 +749,30 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 } else {
                     const long long sa = record_slot(a, parity, P.n_leaves);
                     const long long sb = record_slot(b, parity, P.n_leaves);
-                    const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
+                    uint2 va;
+                    if (have_sums) va = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
+                    else va.x = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8);
+                    const uint32_t pa = va.x & 0xFFFFu;
                     const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
                     const uint32_t da = cdep[pa], db = cdep[pb];
                     uint32_t k;
-                    if (have_rmq) {
+                    if (have_sums) {
+                        // a's whole side is fetched here, where every lane of the workgroup has
+                        // its reads in flight together; the sorted phase climbs b's canopy edges only
+                        if (pa == pb) {     // shared portal: left to the general form
+                            MEET[j] = 0xFFFFFFFFu;
+                            k = 0;
+                        } else {
+                            // everything the sorted phase needs besides b's record stays in LDS:
+                            // b's canopy edges << 16 | meeting node, a's side, b's record slot
+                            const uint32_t meet = canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb);
+                            const uint32_t kb = db - (meet >> 16);
+                            MEET[j] = (kb << 16) | (meet & 0xFFFFu);
+                            SIDE_A[j] = P.lineage[(size_t)va.y + ((va.x >> 16) + da - (meet >> 16))];
+                            SLOT_B[j] = (uint32_t)sb;
+                            k = kb >> key_shift;
+                        }
+                    } else if (have_rmq) {
                         const uint32_t meet = canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb);
                         MEET[j] = meet;
                         k = (da + db - 2 * (meet >> 16)) >> key_shift;
@@ -780,16 +811,55 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
         __syncthreads();
         const uint32_t total = WSUM[4];
         // wave w: sorted groups w, 31 - w, 32 + w, 63 - w (short pairs with long pairs)
+        if (have_sums) {
+            // lineage-sum mode: per pair one global read is left (b's record), issued one
+            // group ahead of the climb that uses it
+            int jq[Q];
+            bool ok[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
+                ok[q] = pos < total;
+                jq[q] = ok[q] ? (int)PERM[pos] : 0;
+            }
+            PairRecs<CAP> cur, nxt;
+            cur.rb = P.rec_b + (long long)(ok[0] ? SLOT_B[jq[0]] : 0u) * half;
+            if (ok[0] && MEET[jq[0]] != 0xFFFFFFFFu) load_rec_b<CAP>(cur);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                if (q + 1 < Q) {
+                    nxt.rb = P.rec_b + (long long)(ok[q + 1] ? SLOT_B[jq[q + 1]] : 0u) * half;
+                    if (ok[q + 1] && MEET[jq[q + 1]] != 0xFFFFFFFFu) load_rec_b<CAP>(nxt);
+                }
+                if (ok[q]) {
+                    const int j = jq[q];
+                    const uint32_t meet = MEET[j];
+                    PairResult r;
+                    if (meet != 0xFFFFFFFFu) {
+                        r = pair_ladder_sums_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), P.canopy_id, meet & 0xFFFFu,
+                                                    meet >> 16, SIDE_A[j], cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
+                    } else {     // shared portal
+                        long long a, b;
+                        src.load(base + j, a, b);
+                        r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
+                                                          record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
+                    }
+                    store_result(out_d, out_m, base + j, r.dist, r.mrca);
+                }
+                if (q + 1 < Q) cur = nxt;
+            }
+        } else {
 #pragma unroll 1
-        for (int q = 0; q < Q; q++) {
-            const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
-            if (pos >= total) continue;
-            const int j = PERM[pos];
-            long long a, b;
-            src.load(base + j, a, b);     // (the tile was read a moment ago: an L2 hit; validated then)
-            const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-            const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes, have_rmq ? MEET[j] : 0xFFFFFFFFu);
-            store_result(out_d, out_m, base + j, r.dist, r.mrca);
+            for (int q = 0; q < Q; q++) {
+                const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
+                if (pos >= total) continue;
+                const int j = PERM[pos];
+                long long a, b;
+                src.load(base + j, a, b);     // (the tile was read a moment ago: an L2 hit; validated then)
+                const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+                const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes, have_rmq ? MEET[j] : 0xFFFFFFFFu);
+                store_result(out_d, out_m, base + j, r.dist, r.mrca);
+            }
         }
         __syncthreads();     // the next tile overwrites PERM and MEET
     }
@@ -951,6 +1021,8 @@ struct st_tree {
     CanopyEntry *d_canopy = nullptr;
     int32_t *d_canopy_id = nullptr;
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
+    uint8_t *d_rec_p = nullptr;       // lineage sums (deep canopies with a sparse table), else NULL
+    float *d_lineage = nullptr;
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the
     // device pipe's mutex) and is never confused by a caller who skipped st_fault_check
@@ -962,6 +1034,7 @@ struct st_tree {
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
+    int lineage_sums = 1;     // tuning: 0 = the tile-sorted kernel climbs a's canopy lineage even when the lineage-sum table exists
     LadderEntry *d_ladder = nullptr;
     uint16_t *d_cdepth = nullptr;
     uint16_t *d_cpos = nullptr;     // sparse table for the meeting node (in-order ids only)
@@ -1022,6 +1095,7 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
 struct SortedShape {
     int q;
     bool rmq;
+    bool sums;   // a's side from the lineage-sum table (needs rmq and 4 more bytes of scratch per pair)
 };
 
 static SortedShape sorted_shape(const st_tree *t)
@@ -1029,14 +1103,19 @@ static SortedShape sorted_shape(const st_tree *t)
     const size_t image = ladder_image_bytes(t->canopy_nodes);
     static const int forced = std::getenv("SUCHTREE_AMD_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_SORT_Q")) : 0;   // tuning experiments
     const bool table = t->d_rmq != nullptr;
-    for (const bool rmq : {table, false}) {
-        if (rmq != table && !table) break;
-        if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, rmq) <= 160 * 1024) return {forced, rmq};
-        if (image + sort_scratch_bytes(2, rmq) <= 80 * 1024) return {2, rmq};
-        if (image + sort_scratch_bytes(4, rmq) <= 160 * 1024) return {4, rmq};
+    const bool lineage = table && t->d_lineage != nullptr && t->lineage_sums;
+    struct Mode { bool rmq, sums; };
+    for (const Mode m : {Mode{true, true}, Mode{true, false}}) {
+        if (!table || (m.sums && !lineage)) continue;
+        if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, m.rmq, m.sums) <= 160 * 1024) return {forced, m.rmq, m.sums};
+        if (image + sort_scratch_bytes(2, m.rmq, m.sums) <= 80 * 1024) return {2, m.rmq, m.sums};
+        if (image + sort_scratch_bytes(4, m.rmq, m.sums) <= 160 * 1024) return {4, m.rmq, m.sums};
     }
-    if (image + sort_scratch_bytes(2, false) <= 160 * 1024) return {2, false};
-    return {0, false};
+    if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, false) <= 160 * 1024) return {forced, false, false};
+    if (image + sort_scratch_bytes(2, false) <= 80 * 1024) return {2, false, false};
+    if (image + sort_scratch_bytes(4, false) <= 160 * 1024) return {4, false, false};
+    if (image + sort_scratch_bytes(2, false) <= 160 * 1024) return {2, false, false};
+    return {0, false, false};
 }
 
 static int sorted_q(const st_tree *t) { return sorted_shape(t).q; }
@@ -1052,9 +1131,10 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
 {
     const SortedShape shape = sorted_shape(t);
     const int q = shape.q;
-    const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q, shape.rmq);
+    const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q, shape.rmq, shape.sums);
     CanopyParams Pk = P;
     if (!shape.rmq) { Pk.cpos = nullptr; Pk.rmq = nullptr; }
+    if (!shape.sums) { Pk.rec_p = nullptr; Pk.lineage = nullptr; }
     const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t tile = (int64_t)q * kCanopyBlock;
     int64_t blocks = (n + tile - 1) / tile;
@@ -1108,6 +1188,8 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.rec_a = t->d_rec_a;
     P.rec_b = t->d_rec_b;
     P.rec_i = t->d_rec_i;
+    P.rec_p = t->d_rec_p;
+    P.lineage = t->d_lineage;
     P.n_nodes = t->n_nodes;
     P.n_leaves = t->n_leaves;
     P.canopy_nodes = t->canopy_nodes;
@@ -1116,7 +1198,7 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
     // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
     if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 &&
-        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq) > 80 * 1024)
+        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq, sorted_shape(t).sums) > 80 * 1024)
         return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
     switch (t->rec_cap) {
         case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream);
@@ -1233,6 +1315,7 @@ constexpr int64_t kHostChunk = (int64_t)1 << 22;      // most pairs per pipeline
 constexpr int64_t kHostChunkMin = (int64_t)1 << 18;   // fewest, when a batch is dealt over several GPUs
 constexpr int kDeepCanopyDepth = 100;     // canopies deeper than this (edges) are "deep"
 constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
+constexpr int64_t kMaxLineageEntries = (int64_t)1 << 28;   // 1 GiB of lineage sums at most (ml.tree: 48 MB)
 constexpr int64_t kMailboxPairs = 8192;   // largest batch served through the mailbox (beyond it the staged pipe's fixed ~60 us pay off)
 
 // How a host batch of n pairs is cut into pipeline chunks and dealt over n_dev devices:
@@ -1639,6 +1722,9 @@ static int build_tables(const int32_t *parent, const float *distance, int64_t n_
                     TreeTables T2 = B.T;
                     if (prepare_canopy(parent, distance, T2, deep_nodes)) B.T = std::move(T2);
                 }
+                // a's side of every pair from one read (tree_prep.h: lineage sums); 4 bytes per
+                // node and level, so only while the table stays below kMaxLineageEntries
+                (void)prepare_lineage_sums(B.T, kMaxLineageEntries);
             }
         }
     }
@@ -1696,6 +1782,10 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
         if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
+        if (rc == ST_OK && t->d_rmq && !T.lineage_sum.empty()) {
+            rc = upload(&t->d_rec_p, T.rec_p, &bytes);
+            if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
+        }
     }
     if (rc == ST_OK) {
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), 2 * sizeof(Fault));
@@ -1853,6 +1943,8 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_rec_a);
         (void)hipFree(t->d_rec_b);
         (void)hipFree(t->d_rec_i);
+        (void)hipFree(t->d_rec_p);
+        (void)hipFree(t->d_lineage);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
@@ -1905,6 +1997,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "tile_sort") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tile_sort must be 0 or 1");
         t->tile_sort = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "lineage_sums") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "lineage_sums must be 0 or 1");
+        t->lineage_sums = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "small_batch_path") == 0) {

@@ -276,4 +276,37 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     return true;
 }
 
+bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
+{
+    T.lineage_sum.clear();
+    T.rec_p.clear();
+    if (!T.has_canopy || !T.inorder_ids || T.canopy_rmq.empty()) return false;
+    const int64_t n = T.n;
+    int64_t entries = 0;
+    for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
+    if (entries > max_entries || entries >= ((int64_t)1 << 32)) return false;
+    T.lineage_sum.resize((size_t)entries);
+    T.rec_p.assign((size_t)n * 8, 0);
+    int64_t off = 0;
+    for (int64_t x = 0; x < n; x++) {
+        const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
+        const uint32_t off32 = (uint32_t)off;
+        std::memcpy(T.rec_p.data() + slot * 8, T.rec_a.data() + slot * 8, 4);
+        std::memcpy(T.rec_p.data() + slot * 8 + 4, &off32, 4);
+        // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
+        volatile float acc = 0.0f;
+        float *dst = T.lineage_sum.data() + off;
+        int32_t v = (int32_t)x;
+        const int32_t k_max = T.depth[(size_t)x];
+        dst[0] = 0.0f;
+        for (int32_t k = 1; k <= k_max; k++) {
+            acc = acc + T.nodes[(size_t)v].dist;
+            dst[k] = acc;
+            v = T.nodes[(size_t)v].parent;
+        }
+        off += (int64_t)k_max + 1;
+    }
+    return true;
+}
+
 }  // namespace st

@@ -120,6 +120,15 @@ struct TreeTables {
     std::vector<uint8_t> rec_a;         // [n * 8], slot order
     std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
     std::vector<uint8_t> rec_i;         // [n * record_bytes/2]
+    // Lineage sums (deep canopies with a sparse table; prepare_lineage_sums): the a side of a
+    // pair is a sum that STARTS at a -- d = 0; d += dist[n] for n = a, parent(a), ... (pyx:934-936)
+    // -- so every prefix of it can be tabulated per node, bit for bit: lineage_sum[off(x) + k] =
+    // the reference's accumulator after the first k edges of x's lineage (k = 0 .. depth(x)).
+    // With the meeting node known from the sparse table the whole a side of a pair is one 4-byte
+    // read; only b's edges, which continue a's sum, are still added one by one.
+    // rec_p[slot] = {word0 as in rec_a, off(x)}: what a's side reads instead of rec_a.
+    std::vector<float> lineage_sum;     // [sum over nodes of depth + 1] or empty
+    std::vector<uint8_t> rec_p;         // [n * 8], slot order, or empty
 };
 
 // Record slot of node id x.  With the parity layout leaf records come first
@@ -132,6 +141,10 @@ ST_HD int64_t record_slot(int64_t x, bool parity, int64_t n_leaves) {
 // set when it is not a single rooted tree.
 bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
                    TreeTables &T, std::string &err);
+
+// Lineage sums of every node (see TreeTables), for trees with a canopy and a sparse table and
+// at most max_entries table entries; returns false (tables left empty) otherwise.
+bool prepare_lineage_sums(TreeTables &T, int64_t max_entries);
 
 // Chooses the canopy and builds canopy + records.  Returns false (without
 // error) when the tree does not admit the canopy family (lineages below any

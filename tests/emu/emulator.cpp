@@ -33,9 +33,11 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     TreeTables T;
     if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
     bool canopy = false;
+    bool lineage = false;
     if (strategy == 2) {
         canopy = prepare_canopy(parent, distance, T);
         if (!canopy) { g_err = "canopy not admitted"; return 2; }
+        lineage = prepare_lineage_sums(T, (int64_t)1 << 27);   // (in-order ids only)
     }
     if (info) {
         info->n_leaves = T.n_leaves;
@@ -93,6 +95,19 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                     if (l2.mrca != l.mrca || std::memcmp(&l2.dist, &l.dist, 4) != 0) {
                         g_err = "sparse-table form disagrees with the lock-step ladder form";
                         return 5;
+                    }
+                    if (lineage) {     // a's side from the lineage-sum table (what the deep kernel reads: rec_p)
+                        uint32_t wp, off;
+                        std::memcpy(&wp, T.rec_p.data() + sa * 8, 4);
+                        std::memcpy(&off, T.rec_p.data() + sa * 8 + 4, 4);
+                        const uint32_t k_a = (wp >> 16) + T.canopy_depth[wp & 0xFFFFu] - (meet >> 16);
+                        const PairResult l3 = pair_ladder_sums_b<0>(T.ladder.data(), T.canopy_id.data(), meet & 0xFFFFu,
+                                                                    T.canopy_depth[pb] - (meet >> 16), T.lineage_sum[(size_t)off + k_a],
+                                                                    pb, B.D, B.nb);
+                        if (wp != wa || l3.mrca != l.mrca || std::memcmp(&l3.dist, &l.dist, 4) != 0) {
+                            g_err = "lineage-sum form disagrees with the ladder form";
+                            return 6;
+                        }
                     }
                 } else {
                     l = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(), pa, pbot_a, pb, B.D, B.nb);
