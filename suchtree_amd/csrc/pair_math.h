@@ -170,10 +170,9 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
 
 // Meeting node of two canopy nodes from the sparse table (tree_prep.h): two 2-byte rank reads
 // and two 4-byte table reads, no climbing.  Returns depth << 16 | canopy index.
-ST_HD uint32_t canopy_meet(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ rmq, int32_t n_canopy,
-                           uint32_t pa, uint32_t pb)
+// (from the ranks of the two canopy nodes: one 4-byte table read per half of the query)
+ST_HD uint32_t canopy_meet_ranks(const uint32_t *__restrict__ rmq, int32_t n_canopy, uint32_t ra, uint32_t rb)
 {
-    const uint32_t ra = pos[pa], rb = pos[pb];
     const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
     const uint32_t len = r - l + 1;
     uint32_t k = 0;
@@ -181,6 +180,12 @@ ST_HD uint32_t canopy_meet(const uint16_t *__restrict__ pos, const uint32_t *__r
     const uint32_t e1 = rmq[(size_t)k * (size_t)n_canopy + l];
     const uint32_t e2 = rmq[(size_t)k * (size_t)n_canopy + (r + 1 - (1u << k))];
     return (e2 >> 16) < (e1 >> 16) ? e2 : e1;
+}
+
+ST_HD uint32_t canopy_meet(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ rmq, int32_t n_canopy,
+                           uint32_t pa, uint32_t pb)
+{
+    return canopy_meet_ranks(rmq, n_canopy, pos[pa], pos[pb]);
 }
 
 // Ladder form of pair_canopy_split (deep canopies).  `lad` is the ladder table (LDS on the

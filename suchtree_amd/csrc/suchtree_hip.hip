@@ -749,30 +749,35 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 } else {
                     const long long sa = record_slot(a, parity, P.n_leaves);
                     const long long sb = record_slot(b, parity, P.n_leaves);
-                    uint2 va;
-                    if (have_sums) va = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
-                    else va.x = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8);
-                    const uint32_t pa = va.x & 0xFFFFu;
-                    const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
-                    const uint32_t da = cdep[pa], db = cdep[pb];
                     uint32_t k;
                     if (have_sums) {
-                        // a's whole side is fetched here, where every lane of the workgroup has
-                        // its reads in flight together; the sorted phase climbs b's canopy edges only
-                        if (pa == pb) {     // shared portal: left to the general form
+                        // Lineage-sum mode.  rec_p of either node = {rank of its portal | its depth << 16,
+                        // offset of its lineage sums}: the meeting node comes from the two ranks,
+                        // a's whole side is one table read -- fetched here, where every lane of the
+                        // workgroup has its reads in flight together -- and the sorted phase only
+                        // climbs b's edges.  What it needs besides b's record stays in LDS:
+                        // b's edges below the meeting node << 16 | meeting node, a's side, b's slot.
+                        const uint2 va = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
+                        const uint2 vb = reinterpret_cast<const uint2 *>(P.rec_p)[sb];
+                        if ((va.x & 0xFFFFu) == (vb.x & 0xFFFFu)) {     // shared portal: left to the general form
                             MEET[j] = 0xFFFFFFFFu;
                             k = 0;
                         } else {
-                            // everything the sorted phase needs besides b's record stays in LDS:
-                            // b's canopy edges << 16 | meeting node, a's side, b's record slot
-                            const uint32_t meet = canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb);
-                            const uint32_t kb = db - (meet >> 16);
+                            const uint32_t meet = canopy_meet_ranks(P.rmq, P.canopy_nodes, va.x & 0xFFFFu, vb.x & 0xFFFFu);
+                            const uint32_t kb = (vb.x >> 16) - (meet >> 16);
                             MEET[j] = (kb << 16) | (meet & 0xFFFFu);
-                            SIDE_A[j] = P.lineage[(size_t)va.y + ((va.x >> 16) + da - (meet >> 16))];
+                            SIDE_A[j] = P.lineage[(size_t)va.y + ((va.x >> 16) - (meet >> 16))];
                             SLOT_B[j] = (uint32_t)sb;
                             k = kb >> key_shift;
                         }
-                    } else if (have_rmq) {
+                        key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
+                        rank[q] = atomicAdd(&HIST[key[q]], 1u);
+                        continue;
+                    }
+                    const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
+                    const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
+                    const uint32_t da = cdep[pa], db = cdep[pb];
+                    if (have_rmq) {
                         const uint32_t meet = canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb);
                         MEET[j] = meet;
                         k = (da + db - 2 * (meet >> 16)) >> key_shift;
@@ -837,7 +842,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                     PairResult r;
                     if (meet != 0xFFFFFFFFu) {
                         r = pair_ladder_sums_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), P.canopy_id, meet & 0xFFFFu,
-                                                    meet >> 16, SIDE_A[j], cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
+                                                    (meet >> 16) - (cur.wb >> 16), SIDE_A[j], cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
                     } else {     // shared portal
                         long long a, b;
                         src.load(base + j, a, b);
@@ -1139,8 +1144,9 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
     const int64_t tile = (int64_t)q * kCanopyBlock;
     int64_t blocks = (n + tile - 1) / tile;
     blocks = std::max<int64_t>(std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu), 1);
-    int key_shift = 0;     // keys are edge counts of up to twice the canopy's depth
-    while (((2 * t->canopy_depth) >> key_shift) >= kSortBuckets) key_shift++;
+    int key_shift = 0;     // keys are edge counts: of both canopy lineages, or (lineage sums) of b's whole lineage
+    const int key_max = shape.sums ? t->canopy_depth + t->rec_cap : 2 * t->canopy_depth;
+    while ((key_max >> key_shift) >= kSortBuckets) key_shift++;
     auto go = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

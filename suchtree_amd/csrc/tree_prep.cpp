@@ -284,14 +284,17 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
     const int64_t n = T.n;
     int64_t entries = 0;
     for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
-    if (entries > max_entries || entries >= ((int64_t)1 << 32)) return false;
+    if (entries > max_entries || entries >= ((int64_t)1 << 32) || T.tree_depth > 65535) return false;
     T.lineage_sum.resize((size_t)entries);
     T.rec_p.assign((size_t)n * 8, 0);
     int64_t off = 0;
     for (int64_t x = 0; x < n; x++) {
         const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
         const uint32_t off32 = (uint32_t)off;
-        std::memcpy(T.rec_p.data() + slot * 8, T.rec_a.data() + slot * 8, 4);
+        uint32_t w0;
+        std::memcpy(&w0, T.rec_a.data() + slot * 8, 4);
+        const uint32_t wp = (uint32_t)T.canopy_pos[(size_t)(w0 & 0xFFFFu)] | ((uint32_t)T.depth[(size_t)x] << 16);
+        std::memcpy(T.rec_p.data() + slot * 8, &wp, 4);
         std::memcpy(T.rec_p.data() + slot * 8 + 4, &off32, 4);
         // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
         volatile float acc = 0.0f;

@@ -126,7 +126,9 @@ struct TreeTables {
     // the reference's accumulator after the first k edges of x's lineage (k = 0 .. depth(x)).
     // With the meeting node known from the sparse table the whole a side of a pair is one 4-byte
     // read; only b's edges, which continue a's sum, are still added one by one.
-    // rec_p[slot] = {word0 as in rec_a, off(x)}: what a's side reads instead of rec_a.
+    // rec_p[slot] = {rank of x's portal (canopy_pos) | depth(x) << 16, off(x)}: all the key phase
+    // of the deep kernel reads of either node of a pair -- the meeting node comes from the two
+    // ranks, a's edge count and b's from the depths.
     std::vector<float> lineage_sum;     // [sum over nodes of depth + 1] or empty
     std::vector<uint8_t> rec_p;         // [n * 8], slot order, or empty
 };

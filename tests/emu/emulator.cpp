@@ -96,15 +96,17 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                         g_err = "sparse-table form disagrees with the lock-step ladder form";
                         return 5;
                     }
-                    if (lineage) {     // a's side from the lineage-sum table (what the deep kernel reads: rec_p)
-                        uint32_t wp, off;
-                        std::memcpy(&wp, T.rec_p.data() + sa * 8, 4);
+                    if (lineage) {     // what the deep kernel reads: rec_p of both nodes, the lineage sum of a
+                        uint32_t wpa, off, wpb;
+                        std::memcpy(&wpa, T.rec_p.data() + sa * 8, 4);
                         std::memcpy(&off, T.rec_p.data() + sa * 8 + 4, 4);
-                        const uint32_t k_a = (wp >> 16) + T.canopy_depth[wp & 0xFFFFu] - (meet >> 16);
-                        const PairResult l3 = pair_ladder_sums_b<0>(T.ladder.data(), T.canopy_id.data(), meet & 0xFFFFu,
-                                                                    T.canopy_depth[pb] - (meet >> 16), T.lineage_sum[(size_t)off + k_a],
-                                                                    pb, B.D, B.nb);
-                        if (wp != wa || l3.mrca != l.mrca || std::memcmp(&l3.dist, &l.dist, 4) != 0) {
+                        std::memcpy(&wpb, T.rec_p.data() + sb * 8, 4);
+                        const uint32_t meet_r = canopy_meet_ranks(T.canopy_rmq.data(), T.canopy_nodes, wpa & 0xFFFFu, wpb & 0xFFFFu);
+                        const uint32_t k_a = (wpa >> 16) - (meet_r >> 16);
+                        const uint32_t kb_total = (wpb >> 16) - (meet_r >> 16);
+                        const PairResult l3 = pair_ladder_sums_b<0>(T.ladder.data(), T.canopy_id.data(), meet_r & 0xFFFFu,
+                                                                    kb_total - B.nb, T.lineage_sum[(size_t)off + k_a], pb, B.D, B.nb);
+                        if (meet_r != meet || l3.mrca != l.mrca || std::memcmp(&l3.dist, &l.dist, 4) != 0) {
                             g_err = "lineage-sum form disagrees with the ladder form";
                             return 6;
                         }
