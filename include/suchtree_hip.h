@@ -59,6 +59,7 @@ typedef struct st_tree_info {
     int32_t record_bytes;     /* stride of one understory record */
     int32_t n_devices;        /* GPUs holding a replica (1 unless st_tree_create_multi) */
     int64_t device_bytes;     /* HBM held by this tree */
+    int64_t lineage_entries;  /* float32 entries of the lineage-sum table (deep canopies, in-order ids), else 0 */
 } st_tree_info;
 
 /* Last error message of the calling thread ("" if none). */

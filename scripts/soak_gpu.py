@@ -55,6 +55,7 @@ def main():
                     dev.set_option("small_batch_path", int(rng.integers(0, 2)))
                     if k == 0:
                         dev.set_option("tile_sort", int(rng.integers(0, 2)))
+                        dev.set_option("lineage_sums", int(rng.integers(0, 2)))
                 if rng.random() < 0.2:
                     view = np.ascontiguousarray(view).astype(np.int32)      # the int32 entry point
                 d, m = dev.distances_host(view, want_d, want_m)

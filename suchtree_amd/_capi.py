@@ -43,6 +43,7 @@ class TreeInfo(ctypes.Structure):
         ("record_bytes", ctypes.c_int32),
         ("n_devices", ctypes.c_int32),
         ("device_bytes", ctypes.c_int64),
+        ("lineage_entries", ctypes.c_int64),
     ]
 
     def as_dict(self):

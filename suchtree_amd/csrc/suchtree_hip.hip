@@ -1817,6 +1817,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->info.record_bytes = B.canopy_ok ? T.record_bytes : 0;
     t->info.n_devices = 1;
     t->info.device_bytes = bytes;
+    t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
     *out = t;
     return ST_OK;
 }

@@ -370,6 +370,58 @@ def test_record_sizes_and_shapes_sweep():
     assert {16, 32, 64, 256, 512}.issubset(strides), seen
 
 
+def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
+    """Deep canopies with in-order ids: the tile-sorted kernel reads a's whole side of a pair from
+    the lineage-sum table.  Deep random shapes and ml.tree; leaf and internal nodes, pairs under a
+    shared portal, (x, x), ancestor / descendant pairs, generated triangle, out-of-range ids;
+    the table on and off."""
+    import torch
+    rng = np.random.default_rng(404)
+    trees = [_random_shape_tree(rng, 30000, 0.97), _random_shape_tree(rng, 9000, 0.995), (ml_arrays[0], ml_arrays[1])]
+    for parent, dist in trees:
+        n = len(parent)
+        O = OracleTree(parent, dist)
+        dev = _capi.DeviceTree(parent, dist)
+        info = dev.info()
+        assert info["strategy"] == "canopy" and info["lineage_entries"] > n, info
+        pairs = rng.integers(0, n, (200_000, 2))
+        a = rng.integers(0, n - 12, 50_000)
+        near = np.stack([a, a + rng.integers(0, 12, a.size)], 1)           # mostly one portal
+        up = rng.integers(0, n, 20_000)
+        anc = up.copy()
+        for _ in range(int(rng.integers(1, 60))):                           # an ancestor of `up`
+            anc = np.where(parent[anc] >= 0, parent[anc], anc)
+        lineage = np.concatenate([np.stack([up, anc], 1), np.stack([anc, up], 1), np.stack([up, up], 1)])
+        allp = np.concatenate([pairs, near, lineage]).astype(np.int64)
+        want_d, want_m = O.distances(allp), O.mrca_bulk(allp)
+        ids = rng.choice(n, size=400, replace=False).astype(np.int64)
+        i, j = np.tril_indices(len(ids), -1)
+        tri = np.stack([ids[j], ids[i]], 1)
+        t = torch.from_numpy(allp).cuda()
+        for on in (1, 0, 1):
+            dev.set_option("lineage_sums", on)
+            out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+            out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+            dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d.cpu().numpy(), want_d, "lineage_sums=%d" % on)
+            assert np.array_equal(out_m.cpu().numpy(), want_m)
+            d, m = dev.distances_host(allp[:70_001], True, True)
+            assert_bits_equal(d, want_d[:70_001], "host lineage_sums=%d" % on)
+            assert np.array_equal(m, want_m[:70_001])
+            m_only = dev.distances_host(allp[:9_000], False, True)[1]
+            assert np.array_equal(m_only, want_m[:9_000])
+            td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+            assert_bits_equal(td, O.distances(tri), "triangle lineage_sums=%d" % on)
+            assert np.array_equal(tm, O.mrca_bulk(tri))
+            bad = allp[:50_000].copy()
+            bad[31_337, 0] = n + 5
+            with pytest.raises(_capi.InvalidNodeError) as err:
+                dev.distances_host(bad, True, True)
+            assert err.value.node_id == n + 5
+        dev.close()
+
+
 def test_general_trees_through_the_c_abi():
     """Arbitrary arity and arbitrary node numbering (not what the facade produces, but what the
     C ABI accepts): records in identity order, checked against the plain-Python restatement."""
