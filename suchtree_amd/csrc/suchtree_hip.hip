@@ -685,7 +685,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 // Tile-sorted ladder form for deep canopies (the default there).  On trees like data/bigtrees/ml.tree
 // a pair's climb is anything from a few to several hundred LDS rounds, so in the kernels above
 // a wave is as slow as its longest lineage and keeps ~30 % of its lanes busy.  Here a workgroup
-// takes a tile of Q * 1024 pairs (Q = 2 with two workgroups per CU, 4 with one), estimates each pair's work from the depths of its two portals
+// takes a tile of Q * 1024 pairs (Q = 2 with two workgroups per CU, 4 with one; 2 or 1 when the canopy image leaves no room for more), estimates each pair's work from the depths of its two portals
 // (one 4-byte read of each record), counting-sorts the tile by that key in LDS, and hands
 // every wave 64 pairs of similar length: waves, not lanes, differ in run time, and a wave's
 // instructions serve 64 active lanes.  Wave w processes sorted groups w, 31-w (, 32+w, 63-w):
@@ -1110,16 +1110,21 @@ static SortedShape sorted_shape(const st_tree *t)
     const bool table = t->d_rmq != nullptr;
     const bool lineage = table && t->d_lineage != nullptr && t->lineage_sums;
     struct Mode { bool rmq, sums; };
-    for (const Mode m : {Mode{true, true}, Mode{true, false}}) {
-        if (!table || (m.sums && !lineage)) continue;
-        if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, m.rmq, m.sums) <= 160 * 1024) return {forced, m.rmq, m.sums};
+    // lineage sums first (they are worth a smaller tile), then the sparse table alone, then
+    // the lock-step search; within a mode the largest tile that fits, two workgroups per CU if possible
+    for (const Mode m : {Mode{true, true}, Mode{true, false}, Mode{false, false}}) {
+        if ((m.rmq && !table) || (m.sums && !lineage)) continue;
+        if ((forced == 1 || forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, m.rmq, m.sums) <= 160 * 1024)
+            return {forced, m.rmq, m.sums};
         if (image + sort_scratch_bytes(2, m.rmq, m.sums) <= 80 * 1024) return {2, m.rmq, m.sums};
-        if (image + sort_scratch_bytes(4, m.rmq, m.sums) <= 160 * 1024) return {4, m.rmq, m.sums};
+        // (measured on nj.tree, 9111 canopy nodes: lineage sums with 1024-pair tiles 1.37e10 pairs/s,
+        // lock-step search with 2048-pair tiles 1.19e10, sparse table alone with 2048-pair tiles 1.03e10)
+        for (const int q : {4, 2, 1}) {
+            if (q == 1 && !m.sums) continue;
+            if (q == 2 && m.rmq && !m.sums) continue;
+            if (image + sort_scratch_bytes(q, m.rmq, m.sums) <= 160 * 1024) return {q, m.rmq, m.sums};
+        }
     }
-    if ((forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, false) <= 160 * 1024) return {forced, false, false};
-    if (image + sort_scratch_bytes(2, false) <= 80 * 1024) return {2, false, false};
-    if (image + sort_scratch_bytes(4, false) <= 160 * 1024) return {4, false, false};
-    if (image + sort_scratch_bytes(2, false) <= 160 * 1024) return {2, false, false};
     return {0, false, false};
 }
 
@@ -1157,7 +1162,7 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
                            (long long)n, out_d, out_m, fault, key_shift);
         return hipGetLastError();
     };
-    return q == 2 ? go(k_canopy_sorted<CAP, 2, Src>) : go(k_canopy_sorted<CAP, 4, Src>);
+    return q == 1 ? go(k_canopy_sorted<CAP, 1, Src>) : q == 2 ? go(k_canopy_sorted<CAP, 2, Src>) : go(k_canopy_sorted<CAP, 4, Src>);
 }
 
 template <int CAP, typename Src>
