@@ -16,7 +16,7 @@ for name, T in (("balanced17", SuchTree(synth.balanced_tree(17))), ("ml", SuchTr
     T.to_device()
     leaves = np.asarray(T.leaf_node_ids, dtype=np.int64)
     rng = np.random.default_rng(1)
-    for n in (1, 64, 1000, 2048, 2049, 4095, 4096, 10_000, 30_000, 100_000, 300_000, 1_000_000, 3_000_000):
+    for n in (1, 64, 1000, 2048, 2049, 4095, 4096, 8192, 8193, 10_000, 30_000, 100_000, 300_000, 1_000_000, 3_000_000):
         pairs = rng.choice(leaves, size=(n, 2))
         reps = max(3, min(500, int(2e6 / n)))
         for _ in range(3):

@@ -78,14 +78,31 @@ ST_HD float walk_sum(const Stride3 *__restrict__ stride, float s, int32_t u, int
     return s;
 }
 
+// Lineage sums for the walk family (tree_prep.h; NULL when the tree has none): a's side of
+// a pair is lineage[offset of a + edges of a below the meeting node], the offset being the
+// second word of rec_p at a's record slot.
+struct LineageView {
+    const uint8_t *rec_p = nullptr;
+    const float *sums = nullptr;
+    int64_t n_leaves = 0;
+    bool parity = false;
+};
+
 ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
                            const Stride3 *__restrict__ stride, int32_t a, int32_t b,
-                           const uint64_t *__restrict__ rmq = nullptr, int64_t n_nodes = 0)
+                           const uint64_t *__restrict__ rmq = nullptr, int64_t n_nodes = 0,
+                           const LineageView &lin = LineageView())
 {
     int32_t dm;
     const int32_t da = depth[a], db = depth[b];
     const int32_t m = pair_walk_mrca(nodes, depth, stride, a, b, &dm, rmq, n_nodes);
-    float s = walk_sum(stride, 0.0f, a, da - dm);
+    float s;
+    if (lin.sums) {
+        const uint32_t off = *reinterpret_cast<const uint32_t *>(lin.rec_p + record_slot(a, lin.parity, lin.n_leaves) * 8 + 4);
+        s = lin.sums[(size_t)off + (size_t)(da - dm)];
+    } else {
+        s = walk_sum(stride, 0.0f, a, da - dm);
+    }
     s = walk_sum(stride, s, b, db - dm);
     PairResult r;
     r.dist = s;

@@ -229,6 +229,7 @@ struct WalkParams {
     const Stride3 *stride;
     const uint64_t *rmq;     // whole-tree sparse table for the meeting node, or NULL
     long long n_nodes;
+    LineageView lineage;     // a's side in one read (deep trees with lineage sums), else empty
 };
 
 template <typename Src>
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
             continue;
         }
         if (out_d.any()) {
-            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, P.rmq, P.n_nodes);
+            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, P.rmq, P.n_nodes, P.lineage);
             store_result(out_d, out_m, i, r.dist, r.mrca);
         } else {
             out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, nullptr, P.rmq, P.n_nodes);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(64) void k_walk_mailbox(WalkParams P, const long lo
     if (i < n) {
         const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];   // (ids were range-checked on the host)
         if (out_d) {
-            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)v.x, (int32_t)v.y, P.rmq, P.n_nodes);
+            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)v.x, (int32_t)v.y, P.rmq, P.n_nodes, P.lineage);
             out_d[i] = (double)r.dist;
             if (out_m) out_m[i] = r.mrca;
         } else {
@@ -1130,9 +1131,23 @@ static SortedShape sorted_shape(const st_tree *t)
 
 static int sorted_q(const st_tree *t) { return sorted_shape(t).q; }
 
+// Smallest batch the canopy kernels take.  The tile-sorted kernel has a fixed cost (every
+// workgroup stages a ladder image of up to 150 KiB, sorts, and on the host path its slot is
+// staged through device memory), and with lineage sums the walk kernel does 8e9 pairs/s on deep
+// trees: 10,000 pairs of ml.tree through the host path 73 us sorted, 40 us walked.
+constexpr int64_t kCanopyMinPairs = 4096;
+constexpr int64_t kSortedMinPairs = 32768;        // deep canopies with lineage sums: below this the walk kernel wins
+constexpr int64_t kSortedMinPairsHost = 131072;   // ... on the host path, where the tile-sorted kernel also needs its slot staged in device memory
+
+static int64_t canopy_min_pairs(const st_tree *t)
+{
+    return t->tile_sort && t->d_lineage && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
+}
+
 static bool wants_device_stage(const st_tree *t, int64_t m)
 {
-    return t->strategy == ST_STRATEGY_CANOPY && t->tile_sort && m >= 4096 && sorted_q(t) > 0;
+    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
+    return m >= (canopy_min_pairs(t) == kSortedMinPairs ? kSortedMinPairsHost : kCanopyMinPairs);
 }
 
 template <int CAP, typename Src>
@@ -1220,9 +1235,7 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     }
 }
 
-template <typename Src>
-static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                              int32_t *out_m, Fault *fault, hipStream_t stream)
+static WalkParams walk_params(const st_tree *t)
 {
     WalkParams P;
     P.nodes = t->d_nodes;
@@ -1230,6 +1243,20 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
     P.stride = t->d_stride;
     P.rmq = t->d_tree_rmq;
     P.n_nodes = t->n_nodes;
+    if (t->d_lineage && t->lineage_sums) {
+        P.lineage.rec_p = t->d_rec_p;
+        P.lineage.sums = t->d_lineage;
+        P.lineage.n_leaves = t->n_leaves;
+        P.lineage.parity = t->parity != 0;
+    }
+    return P;
+}
+
+template <typename Src>
+static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
+                              int32_t *out_m, Fault *fault, hipStream_t stream)
+{
+    const WalkParams P = walk_params(t);
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
     blocks = std::max<int64_t>(blocks, 1);
@@ -1239,16 +1266,18 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
 }
 
 // Small batches are not worth staging 128 KiB of canopy per workgroup.
-constexpr int64_t kCanopyMinPairs = 4096;
 
 template <typename Src>
 static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, int32_t *d_mrca,
-                       Fault *fault, hipStream_t stream)
+                       Fault *fault, hipStream_t stream, bool allow_sorted = true)
 {
     if (n == 0) return ST_OK;
     // MRCA-only requests (d_out == NULL) also go through the canopy kernels: the id comes out
     // of the same climb, and that is ~7x faster than walking the global table
-    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && n >= kCanopyMinPairs;
+    // (allow_sorted = false: pairs and results are in pinned host memory, which the tile-sorted
+    // kernel must not work on -- it reads every pair twice and scatters its stores)
+    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && n >= canopy_min_pairs(t) &&
+                        (allow_sorted || !(t->tile_sort && sorted_q(t) > 0));
     const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, fault, stream)
                                 : launch_walk(t, src, n, d_out, d_mrca, fault, stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1389,12 +1418,7 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
                                        std::to_string(t->n_nodes) + ")");
     }
     char *d_base = static_cast<char *>(t->mb_dev);
-    WalkParams P;
-    P.nodes = t->d_nodes;
-    P.depth = t->d_depth;
-    P.stride = t->d_stride;
-    P.rmq = t->d_tree_rmq;
-    P.n_nodes = t->n_nodes;
+    const WalkParams P = walk_params(t);
     double *d_dist = reinterpret_cast<double *>(d_base + (size_t)kMailboxPairs * 16);
     int32_t *d_mrca = reinterpret_cast<int32_t *>(d_base + (size_t)kMailboxPairs * 24);
     unsigned *d_done = reinterpret_cast<unsigned *>(d_base + (size_t)kMailboxPairs * 28);
@@ -1511,7 +1535,7 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
             else sink.f32 = static_cast<float *>(s.h_d);
         }
         int32_t *mrca = !out.mrca ? nullptr : out.direct_m ? out.mrca + off : static_cast<int32_t *>(s.h_m);
-        return enqueue_src(r, make_src(s.h_in), m, sink, mrca, r->d_fault_host, s.stream);
+        return enqueue_src(r, make_src(s.h_in), m, sink, mrca, r->d_fault_host, s.stream, false);
     }
     // Pairs come in through the copy engine, results go out through copy kernels: the two
     // directions then overlap and the engine takes no CUs from the tile-sorted kernel (ml.tree,
@@ -2079,7 +2103,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
     if (!out_dist && !out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
     if (n == 0) return ST_OK;
     // (deep canopies: beyond the walk/canopy switch the tile-sorted kernel beats the mailbox's walk)
-    if (n <= (t->tile_sort ? kCanopyMinPairs - 1 : kMailboxPairs) && t->small_batch_path) {
+    // (deep canopies without lineage sums: the walk is slow there, the tile-sorted kernel takes over at 4096 pairs)
+    if (n <= (t->tile_sort && !(t->d_lineage && t->lineage_sums) ? kCanopyMinPairs - 1 : kMailboxPairs) && t->small_batch_path) {
         ST_DEVICE(t->device);
         return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
     }
@@ -2346,12 +2371,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     }
     PipeSlot &in = pipe.slot[0], &out = pipe.slot[1];
     if (begin_host_faults(t, in.stream) != ST_OK) return ST_ERR_HIP;
-    WalkParams P;
-    P.nodes = t->d_nodes;
-    P.depth = t->d_depth;
-    P.stride = t->d_stride;
-    P.rmq = t->d_tree_rmq;
-    P.n_nodes = t->n_nodes;
+    const WalkParams P = walk_params(t);
     for (int64_t off = 0; off < n; off += chunk) {
         const int64_t m = std::min(chunk, n - off);
         int64_t *h = static_cast<int64_t *>(in.h_in);
@@ -2362,7 +2382,7 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         });
         ST_HIP(hipMemcpyAsync(in.d_in, in.h_in, (size_t)m * 32, hipMemcpyHostToDevice, in.stream));
         int64_t blocks = std::min<int64_t>((m + 255) / 256, (int64_t)t->n_cu * 16);
-        if (t->strategy == ST_STRATEGY_CANOPY && 6 * m >= kCanopyMinPairs) {
+        if (t->strategy == ST_STRATEGY_CANOPY && 6 * m >= canopy_min_pairs(t)) {
             // six MRCA ids per quartet out of the canopy kernels, then the pick
             if (t->q_tmp_cap < m) {
                 (void)hipFree(t->q_tmp);

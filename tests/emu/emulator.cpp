@@ -34,6 +34,13 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
     bool canopy = false;
     bool lineage = false;
+    if (strategy == 1) {   // the walk family uses the lineage sums of trees that have them
+        TreeTables C = T;
+        if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27)) {
+            T.lineage_sum = std::move(C.lineage_sum);
+            T.rec_p = std::move(C.rec_p);
+        }
+    }
     if (strategy == 2) {
         canopy = prepare_canopy(parent, distance, T);
         if (!canopy) { g_err = "canopy not admitted"; return 2; }
@@ -60,6 +67,22 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                 if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
                     g_err = "walk: sparse-table meeting node disagrees with the lock-step search";
                     return 7;
+                }
+            }
+            {   // a's side from the lineage sums, where the tree has them (deep canopies, in-order ids)
+                const TreeTables &L = T;
+                if (!L.lineage_sum.empty()) {
+                    LineageView lin;
+                    lin.rec_p = L.rec_p.data();
+                    lin.sums = L.lineage_sum.data();
+                    lin.n_leaves = L.n_leaves;
+                    lin.parity = L.parity_layout;
+                    const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
+                                                   T.tree_rmq.empty() ? nullptr : T.tree_rmq.data(), T.n, lin);
+                    if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
+                        g_err = "walk: lineage-sum form disagrees with the climb";
+                        return 8;
+                    }
                 }
             }
             if (out_m && !out_d) r.mrca = pair_walk_mrca(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b);

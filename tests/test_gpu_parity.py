@@ -406,16 +406,17 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
             dev.fault_check()
             assert_bits_equal(out_d.cpu().numpy(), want_d, "lineage_sums=%d" % on)
             assert np.array_equal(out_m.cpu().numpy(), want_m)
-            d, m = dev.distances_host(allp[:70_001], True, True)
-            assert_bits_equal(d, want_d[:70_001], "host lineage_sums=%d" % on)
-            assert np.array_equal(m, want_m[:70_001])
+            for n_host in (70_001, 140_001):       # walk kernel on pinned memory / staged tile-sorted kernel
+                d, m = dev.distances_host(allp[:n_host], True, True)
+                assert_bits_equal(d, want_d[:n_host], "host n=%d lineage_sums=%d" % (n_host, on))
+                assert np.array_equal(m, want_m[:n_host])
             m_only = dev.distances_host(allp[:9_000], False, True)[1]
             assert np.array_equal(m_only, want_m[:9_000])
             td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
             assert_bits_equal(td, O.distances(tri), "triangle lineage_sums=%d" % on)
             assert np.array_equal(tm, O.mrca_bulk(tri))
-            bad = allp[:50_000].copy()
-            bad[31_337, 0] = n + 5
+            bad = allp[:150_000].copy()
+            bad[131_337, 0] = n + 5
             with pytest.raises(_capi.InvalidNodeError) as err:
                 dev.distances_host(bad, True, True)
             assert err.value.node_id == n + 5
