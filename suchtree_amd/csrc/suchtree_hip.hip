@@ -746,7 +746,12 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
                     (unsigned long long)b >= (unsigned long long)P.n_nodes) {
                     record_fault(fault, a, b, P.n_nodes);
-                    store_result(out_d, out_m, i, __builtin_nanf(""), -1);
+                    if (have_sums) {     // (results of the tile leave LDS together, below)
+                        SIDE_A[j] = __builtin_nanf("");
+                        MEET[j] = 0xFFFFFFFFu;      // = -1
+                    } else {
+                        store_result(out_d, out_m, i, __builtin_nanf(""), -1);
+                    }
                 } else {
                     const long long sa = record_slot(a, parity, P.n_leaves);
                     const long long sb = record_slot(b, parity, P.n_leaves);
@@ -850,9 +855,19 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                         r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
                                                           record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
                     }
-                    store_result(out_d, out_m, base + j, r.dist, r.mrca);
+                    // the pair's two scratch words have served: its result waits there
+                    SIDE_A[j] = r.dist;
+                    MEET[j] = (uint32_t)r.mrca;
                 }
                 if (q + 1 < Q) cur = nxt;
+            }
+            // results leave in input order, coalesced (scattered 8- and 4-byte stores straight from
+            // the sorted phase cost a cache lookup per lane and wrote every output line several times)
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = (int)threadIdx.x + q * kCanopyBlock;
+                if (base + j < n) store_result(out_d, out_m, base + j, SIDE_A[j], (int)MEET[j]);
             }
         } else {
 #pragma unroll 1
