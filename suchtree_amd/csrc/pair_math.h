@@ -99,7 +99,7 @@ ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__res
     float s;
     if (lin.sums) {
         const uint32_t off = *reinterpret_cast<const uint32_t *>(lin.rec_p + record_slot(a, lin.parity, lin.n_leaves) * 8 + 4);
-        s = lin.sums[(size_t)off + (size_t)(da - dm)];
+        s = lin.sums[(size_t)(off & 0x0FFFFFFFu) + (size_t)(da - dm)];     // (the top 4 bits of the word are a chunk count)
     } else {
         s = walk_sum(stride, 0.0f, a, da - dm);
     }
@@ -199,6 +199,18 @@ ST_HD uint32_t canopy_meet_ranks(const uint32_t *__restrict__ rmq, int32_t n_can
     return (e2 >> 16) < (e1 >> 16) ? e2 : e1;
 }
 
+// The same query on the 64-bit table (tree_prep.h: canopy_rmq64): depth << 32 | node id.
+ST_HD uint64_t canopy_meet_ranks64(const uint64_t *__restrict__ rmq, int32_t n_canopy, uint32_t ra, uint32_t rb)
+{
+    const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
+    const uint32_t len = r - l + 1;
+    uint32_t k = 0;
+    while ((2u << k) <= len) k++;
+    const uint64_t e1 = rmq[(size_t)k * (size_t)n_canopy + l];
+    const uint64_t e2 = rmq[(size_t)k * (size_t)n_canopy + (r + 1 - (1u << k))];
+    return (e2 >> 32) < (e1 >> 32) ? e2 : e1;
+}
+
 ST_HD uint32_t canopy_meet(const uint16_t *__restrict__ pos, const uint32_t *__restrict__ rmq, int32_t n_canopy,
                            uint32_t pa, uint32_t pb)
 {
@@ -256,13 +268,11 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
     return r;
 }
 
-// pair_ladder_sums with a's side read from the lineage-sum table (tree_prep.h): `s_a` is the
-// reference's accumulator after a's edges up to the meeting node (canopy index `meet_index`);
-// b's understory and its `kb` canopy edges continue it, in lineage order, three canopy edges
-// per 16-byte entry.
+// b's side of a pair whose a side came from the lineage-sum table (tree_prep.h): `s_a` is the
+// reference's accumulator after a's edges up to the meeting node; b's understory and its `kb`
+// canopy edges continue it, in lineage order, three canopy edges per 16-byte entry.
 template <int CAP, typename LadPtr>
-ST_HD PairResult pair_ladder_sums_b(LadPtr lad, const int32_t *__restrict__ canopy_id, uint32_t meet_index,
-                                    uint32_t kb, float s_a, uint32_t pb, const float *D_b, uint32_t nb_b)
+ST_HD float ladder_sum_b(LadPtr lad, uint32_t kb, float s_a, uint32_t pb, const float *D_b, uint32_t nb_b)
 {
     float s = s_a;
     if (CAP > 0) {
@@ -285,10 +295,7 @@ ST_HD PairResult pair_ladder_sums_b(LadPtr lad, const int32_t *__restrict__ cano
         s += e.d0;
         if (k == 2) s += e.d1;
     }
-    PairResult r;
-    r.dist = s;
-    r.mrca = canopy_id[meet_index];
-    return r;
+    return s;
 }
 
 // Ladder form of pair_canopy_split for trees whose ids are NOT an in-order numbering (no

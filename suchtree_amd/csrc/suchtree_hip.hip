@@ -390,7 +390,8 @@ struct CanopyParams {
     const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
-    const uint8_t *rec_p;          // [n_nodes * 8]            {word0, offset into lineage}; NULL without lineage sums
+    const uint8_t *rec_p;          // [n_nodes * 8]            {portal rank | depth << 16, lineage offset | chunks << 28}; NULL without lineage sums
+    const uint64_t *rmq64;         // [levels * canopy_nodes] sparse table with node ids (tree_prep.h), lineage sums only
     const float *lineage;          // lineage sums (tree_prep.h): a's whole side of a pair in one read
     long long n_nodes;
     long long n_leaves;
@@ -446,6 +447,28 @@ __device__ __forceinline__ void load_rec_b(PairRecs<CAP> &L)
     } else {
         L.wb = *reinterpret_cast<const uint32_t *>(L.rb);
         L.Db[0] = 0.0f;
+    }
+}
+
+// b's record (L.rb set), only its first `chunks` 16-byte chunks (the rest of the chain slots are
+// never added: zero).  A lane that does not load a chunk does not cost a cache lookup.
+template <int CAP>
+__device__ __forceinline__ void load_rec_b_chunks(PairRecs<CAP> &L, uint32_t chunks)
+{
+    static_assert(CAP == 0 || CAP == 1 || (CAP + 1) % 4 == 0, "record layout");
+    if (CAP <= 1) {
+        load_rec_b<CAP>(L);
+    } else {
+        uint32_t w[CAP + 1];
+#pragma unroll
+        for (int q = 0; q < (CAP + 1) / 4; q++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)q < chunks) v = reinterpret_cast<const uint4 *>(L.rb)[q];
+            w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        L.wb = w[0];
+#pragma unroll
+        for (int q = 0; q < CAP; q++) L.Db[q] = __uint_as_float(w[q + 1]);
     }
 }
 
@@ -746,9 +769,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
                     (unsigned long long)b >= (unsigned long long)P.n_nodes) {
                     record_fault(fault, a, b, P.n_nodes);
-                    if (have_sums) {     // (results of the tile leave LDS together, below)
+                    if (have_sums) {     // (the distances of the tile leave LDS together, below)
                         SIDE_A[j] = __builtin_nanf("");
-                        MEET[j] = 0xFFFFFFFFu;      // = -1
+                        if (out_m) out_m[i] = -1;
                     } else {
                         store_result(out_d, out_m, i, __builtin_nanf(""), -1);
                     }
@@ -769,11 +792,16 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                             MEET[j] = 0xFFFFFFFFu;
                             k = 0;
                         } else {
-                            const uint32_t meet = canopy_meet_ranks(P.rmq, P.canopy_nodes, va.x & 0xFFFFu, vb.x & 0xFFFFu);
-                            const uint32_t kb = (vb.x >> 16) - (meet >> 16);
-                            MEET[j] = (kb << 16) | (meet & 0xFFFFu);
-                            SIDE_A[j] = P.lineage[(size_t)va.y + ((va.x >> 16) - (meet >> 16))];
-                            SLOT_B[j] = (uint32_t)sb;
+                            // depth << 32 | node id of the meeting node: the MRCA id is known here
+                            // and leaves at once, coalesced
+                            const uint64_t meet = canopy_meet_ranks64(P.rmq64, P.canopy_nodes, va.x & 0xFFFFu, vb.x & 0xFFFFu);
+                            const uint32_t dm = (uint32_t)(meet >> 32);
+                            const uint32_t kb = (vb.x >> 16) - dm;
+                            if (out_m) out_m[i] = (int)(uint32_t)meet;
+                            if (!out_d.any()) continue;      // MRCA ids only: this pair is done
+                            MEET[j] = kb;
+                            SIDE_A[j] = P.lineage[(size_t)(va.y & 0x0FFFFFFFu) + ((va.x >> 16) - dm)];
+                            SLOT_B[j] = (uint32_t)sb | (vb.y & 0xF0000000u);     // (+ how many 16-byte chunks of b's record matter)
                             k = kb >> key_shift;
                         }
                         key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
@@ -834,40 +862,43 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 jq[q] = ok[q] ? (int)PERM[pos] : 0;
             }
             PairRecs<CAP> cur, nxt;
-            cur.rb = P.rec_b + (long long)(ok[0] ? SLOT_B[jq[0]] : 0u) * half;
-            if (ok[0] && MEET[jq[0]] != 0xFFFFFFFFu) load_rec_b<CAP>(cur);
+            auto fetch = [&](PairRecs<CAP> &L, int q) {
+                const uint32_t w = ok[q] && MEET[jq[q]] != 0xFFFFFFFFu ? SLOT_B[jq[q]] : 0u;
+                L.rb = P.rec_b + (long long)(w & 0x0FFFFFFFu) * half;
+                if (ok[q] && MEET[jq[q]] != 0xFFFFFFFFu) load_rec_b_chunks<CAP>(L, (w >> 28) + 1);
+            };
+            fetch(cur, 0);
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                if (q + 1 < Q) {
-                    nxt.rb = P.rec_b + (long long)(ok[q + 1] ? SLOT_B[jq[q + 1]] : 0u) * half;
-                    if (ok[q + 1] && MEET[jq[q + 1]] != 0xFFFFFFFFu) load_rec_b<CAP>(nxt);
-                }
+                if (q + 1 < Q) fetch(nxt, q + 1);
                 if (ok[q]) {
                     const int j = jq[q];
-                    const uint32_t meet = MEET[j];
-                    PairResult r;
-                    if (meet != 0xFFFFFFFFu) {
-                        r = pair_ladder_sums_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), P.canopy_id, meet & 0xFFFFu,
-                                                    (meet >> 16) - (cur.wb >> 16), SIDE_A[j], cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
+                    const uint32_t kb = MEET[j];
+                    float dist;
+                    if (kb != 0xFFFFFFFFu) {
+                        dist = ladder_sum_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), kb - (cur.wb >> 16), SIDE_A[j],
+                                                 cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
                     } else {     // shared portal
                         long long a, b;
                         src.load(base + j, a, b);
-                        r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
-                                                          record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
+                        const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
+                                                                           record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
+                        dist = r.dist;
+                        if (out_m) out_m[base + j] = r.mrca;
                     }
-                    // the pair's two scratch words have served: its result waits there
-                    SIDE_A[j] = r.dist;
-                    MEET[j] = (uint32_t)r.mrca;
+                    SIDE_A[j] = dist;      // the pair's scratch word has served: its distance waits there
                 }
                 if (q + 1 < Q) cur = nxt;
             }
-            // results leave in input order, coalesced (scattered 8- and 4-byte stores straight from
-            // the sorted phase cost a cache lookup per lane and wrote every output line several times)
+            // distances leave in input order, coalesced (scattered stores straight from the sorted
+            // phase cost a cache lookup per lane and wrote every output line several times)
             __syncthreads();
+            if (out_d.any()) {
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const int j = (int)threadIdx.x + q * kCanopyBlock;
-                if (base + j < n) store_result(out_d, out_m, base + j, SIDE_A[j], (int)MEET[j]);
+                for (int q = 0; q < Q; q++) {
+                    const int j = (int)threadIdx.x + q * kCanopyBlock;
+                    if (base + j < n) store_result(out_d, nullptr, base + j, SIDE_A[j], 0);
+                }
             }
         } else {
 #pragma unroll 1
@@ -1043,6 +1074,7 @@ struct st_tree {
     int32_t *d_canopy_id = nullptr;
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
     uint8_t *d_rec_p = nullptr;       // lineage sums (deep canopies with a sparse table), else NULL
+    uint64_t *d_rmq64 = nullptr;
     float *d_lineage = nullptr;
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the
@@ -1174,7 +1206,7 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
     const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q, shape.rmq, shape.sums);
     CanopyParams Pk = P;
     if (!shape.rmq) { Pk.cpos = nullptr; Pk.rmq = nullptr; }
-    if (!shape.sums) { Pk.rec_p = nullptr; Pk.lineage = nullptr; }
+    if (!shape.sums) { Pk.rec_p = nullptr; Pk.lineage = nullptr; Pk.rmq64 = nullptr; }
     const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t tile = (int64_t)q * kCanopyBlock;
     int64_t blocks = (n + tile - 1) / tile;
@@ -1230,6 +1262,7 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.rec_b = t->d_rec_b;
     P.rec_i = t->d_rec_i;
     P.rec_p = t->d_rec_p;
+    P.rmq64 = t->d_rmq64;
     P.lineage = t->d_lineage;
     P.n_nodes = t->n_nodes;
     P.n_leaves = t->n_leaves;
@@ -1834,6 +1867,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
         if (rc == ST_OK && t->d_rmq && !T.lineage_sum.empty()) {
             rc = upload(&t->d_rec_p, T.rec_p, &bytes);
+            if (rc == ST_OK) rc = upload(&t->d_rmq64, T.canopy_rmq64, &bytes);
             if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
         }
     }
@@ -1995,6 +2029,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_rec_b);
         (void)hipFree(t->d_rec_i);
         (void)hipFree(t->d_rec_p);
+        (void)hipFree(t->d_rmq64);
         (void)hipFree(t->d_lineage);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->q_tmp);

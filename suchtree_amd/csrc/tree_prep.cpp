@@ -280,17 +280,28 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
 {
     T.lineage_sum.clear();
     T.rec_p.clear();
+    T.canopy_rmq64.clear();
     if (!T.has_canopy || !T.inorder_ids || T.canopy_rmq.empty()) return false;
     const int64_t n = T.n;
     int64_t entries = 0;
     for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
-    if (entries > max_entries || entries >= ((int64_t)1 << 32) || T.tree_depth > 65535) return false;
+    // (offsets share their word with a 4-bit chunk count; slots are kept in 28 bits by the kernel)
+    if (entries > max_entries || entries >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28) || T.tree_depth > 65535) return false;
+    T.canopy_rmq64.resize(T.canopy_rmq.size());
+    for (size_t i = 0; i < T.canopy_rmq.size(); i++) {
+        const uint32_t e = T.canopy_rmq[i];
+        T.canopy_rmq64[i] = ((uint64_t)(e >> 16) << 32) | (uint32_t)T.canopy_id[(size_t)(e & 0xFFFFu)];
+    }
     T.lineage_sum.resize((size_t)entries);
     T.rec_p.assign((size_t)n * 8, 0);
     int64_t off = 0;
     for (int64_t x = 0; x < n; x++) {
         const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
-        const uint32_t off32 = (uint32_t)off;
+        uint32_t w0a;
+        std::memcpy(&w0a, T.rec_a.data() + slot * 8, 4);
+        const uint32_t chain = w0a >> 16;                                 // nodes of x's understory chain
+        const uint32_t chunks = T.record_cap <= 31 ? (chain + 1 + 3) / 4 : 1;   // word0 + chain floats, 16 bytes at a time
+        const uint32_t off32 = (uint32_t)off | ((chunks - 1) << 28);
         uint32_t w0;
         std::memcpy(&w0, T.rec_a.data() + slot * 8, 4);
         const uint32_t wp = (uint32_t)T.canopy_pos[(size_t)(w0 & 0xFFFFu)] | ((uint32_t)T.depth[(size_t)x] << 16);

@@ -126,11 +126,15 @@ struct TreeTables {
     // the reference's accumulator after the first k edges of x's lineage (k = 0 .. depth(x)).
     // With the meeting node known from the sparse table the whole a side of a pair is one 4-byte
     // read; only b's edges, which continue a's sum, are still added one by one.
-    // rec_p[slot] = {rank of x's portal (canopy_pos) | depth(x) << 16, off(x)}: all the key phase
-    // of the deep kernel reads of either node of a pair -- the meeting node comes from the two
-    // ranks, a's edge count and b's from the depths.
+    // rec_p[slot] = {rank of x's portal (canopy_pos) | depth(x) << 16,
+    //               off(x) | (16-byte chunks of x's rec_b entry that hold its chain, minus one) << 28}:
+    // all the key phase of the deep kernel reads of either node of a pair -- the meeting node
+    // comes from the two ranks, a's edge count and b's from the depths.
+    // canopy_rmq64 = canopy_rmq with entries depth << 32 | NODE ID of the shallowest node (the
+    // MRCA id of a pair falls out of the same two reads that find its meeting depth).
     std::vector<float> lineage_sum;     // [sum over nodes of depth + 1] or empty
     std::vector<uint8_t> rec_p;         // [n * 8], slot order, or empty
+    std::vector<uint64_t> canopy_rmq64; // [rmq_levels * canopy_nodes] or empty
 };
 
 // Record slot of node id x.  With the parity layout leaf records come first

@@ -119,17 +119,22 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                         g_err = "sparse-table form disagrees with the lock-step ladder form";
                         return 5;
                     }
-                    if (lineage) {     // what the deep kernel reads: rec_p of both nodes, the lineage sum of a
-                        uint32_t wpa, off, wpb;
+                    if (lineage) {     // what the deep kernel reads: rec_p of both nodes, two 64-bit table entries, the lineage sum of a
+                        uint32_t wpa, ya, wpb, yb;
                         std::memcpy(&wpa, T.rec_p.data() + sa * 8, 4);
-                        std::memcpy(&off, T.rec_p.data() + sa * 8 + 4, 4);
+                        std::memcpy(&ya, T.rec_p.data() + sa * 8 + 4, 4);
                         std::memcpy(&wpb, T.rec_p.data() + sb * 8, 4);
-                        const uint32_t meet_r = canopy_meet_ranks(T.canopy_rmq.data(), T.canopy_nodes, wpa & 0xFFFFu, wpb & 0xFFFFu);
-                        const uint32_t k_a = (wpa >> 16) - (meet_r >> 16);
-                        const uint32_t kb_total = (wpb >> 16) - (meet_r >> 16);
-                        const PairResult l3 = pair_ladder_sums_b<0>(T.ladder.data(), T.canopy_id.data(), meet_r & 0xFFFFu,
-                                                                    kb_total - B.nb, T.lineage_sum[(size_t)off + k_a], pb, B.D, B.nb);
-                        if (meet_r != meet || l3.mrca != l.mrca || std::memcmp(&l3.dist, &l.dist, 4) != 0) {
+                        std::memcpy(&yb, T.rec_p.data() + sb * 8 + 4, 4);
+                        const uint64_t m64 = canopy_meet_ranks64(T.canopy_rmq64.data(), T.canopy_nodes, wpa & 0xFFFFu, wpb & 0xFFFFu);
+                        const uint32_t dm = (uint32_t)(m64 >> 32);
+                        const uint32_t k_a = (wpa >> 16) - dm, kb_total = (wpb >> 16) - dm;
+                        const uint32_t chunks_b = (yb >> 28) + 1;       // 16-byte chunks of b's record the kernel loads
+                        if (T.record_cap <= 31 && 4 * chunks_b < B.nb + 1) {
+                            g_err = "rec_p: chunk count does not cover b's chain";
+                            return 9;
+                        }
+                        const float d3 = ladder_sum_b<0>(T.ladder.data(), kb_total - B.nb, T.lineage_sum[(size_t)(ya & 0x0FFFFFFFu) + k_a], pb, B.D, B.nb);
+                        if (dm != (meet >> 16) || (int32_t)(uint32_t)m64 != l.mrca || std::memcmp(&d3, &l.dist, 4) != 0) {
                             g_err = "lineage-sum form disagrees with the ladder form";
                             return 6;
                         }

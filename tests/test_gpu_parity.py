@@ -412,6 +412,16 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
                 assert np.array_equal(m, want_m[:n_host])
             m_only = dev.distances_host(allp[:9_000], False, True)[1]
             assert np.array_equal(m_only, want_m[:9_000])
+            # MRCA ids only through the tile-sorted kernel (they are complete after its key phase)
+            out_m.fill_(-5)
+            dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())
+            dev.fault_check()
+            assert np.array_equal(out_m.cpu().numpy(), want_m)
+            # distances only
+            out_d.fill_(-5.0)
+            dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), 0)
+            dev.fault_check()
+            assert_bits_equal(out_d.cpu().numpy(), want_d, "distances only, lineage_sums=%d" % on)
             td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
             assert_bits_equal(td, O.distances(tri), "triangle lineage_sums=%d" % on)
             assert np.array_equal(tm, O.mrca_bulk(tri))
