@@ -56,6 +56,30 @@ def build_microbench(force=False, verbose=False):
     return MICRO_LIB
 
 
+NAMES_SRC = os.path.join(CSRC, "names_ext.c")
+
+
+def names_ext_path():
+    import sysconfig
+    return os.path.join(HERE, "_names" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_names_ext(force=False, verbose=False):
+    """_names extension (CPython C API, host only): the name -> id loop of distances_by_name."""
+    import sysconfig
+    lib = names_ext_path()
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(NAMES_SRC):
+        return lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler for the _names extension")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I", sysconfig.get_paths()["include"], "-o", lib, NAMES_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return lib
+
+
 def build(force=False, verbose=False, extra=()):
     if not force and not stale():
         return LIB

@@ -21,6 +21,26 @@ from . import _capi
 from .exceptions import InvalidNodeError, NodeNotFoundError
 from .newick import EPSILON, FlatTree, flat_tree_from_arrays, flat_tree_from_newick
 
+_NAMES_EXT = False      # not looked for yet
+
+
+def _names_ext():
+    """The optional _names extension (host-side name -> id loop of distances_by_name), or None."""
+    global _NAMES_EXT
+    if _NAMES_EXT is False:
+        try:
+            from . import _names
+            _NAMES_EXT = _names
+        except ImportError:
+            try:                                    # not built yet: a one-second gcc job
+                from . import build as _build
+                _build.build_names_ext()
+                from . import _names
+                _NAMES_EXT = _names
+            except Exception:                       # noqa: BLE001 -- no compiler, read-only tree, ...
+                _NAMES_EXT = None
+    return _NAMES_EXT
+
 
 def _deprecation_warning(old_name: str, new_name: str, version: str = "2.0") -> None:
     # wording of MuchTree.pyx:33-42
@@ -323,6 +343,13 @@ class SuchTree:
         if not isinstance(pairs, list):
             raise TypeError("pairs must be a list of tuples")
         leaves = self.leaves
+        names_ext = _names_ext()
+        if names_ext is not None and pairs:
+            # fastest path: the lookup loop in C (csrc/names_ext.c); -1 = something unexpected,
+            # left to the code below
+            ids = np.empty((len(pairs), 2), dtype=np.int64)
+            if names_ext.lookup_pairs(pairs, leaves, ids) == 0:
+                return self.distances_bulk(ids).tolist()
         try:
             # fast path: the dict lookups run at C speed over the flattened names, no per-element
             # checks (keys are str only, so anything that is not a known leaf name raises here

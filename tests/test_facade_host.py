@@ -128,3 +128,27 @@ def test_pickle_round_trip_drops_the_device_handle(T):
     assert T2.leaves == T.leaves and T2.size == T.size and T2._dev_tree is None
     assert np.array_equal(T2._flat.parent, T._flat.parent)
     assert "29 nodes" in repr(T2)
+
+
+def test_names_extension_matches_the_python_loop():
+    """csrc/names_ext.c (the C form of the name -> id loop of distances_by_name): same ids as
+    the dict lookups; anything unexpected is handed back to the Python loop (-1, no exception)."""
+    from suchtree_amd import build as st_build
+    st_build.build_names_ext()
+    from suchtree_amd import _names
+    rng = np.random.default_rng(3)
+    leaves = {"leaf_%d" % i: 2 * i for i in range(5000)}
+    names = list(leaves)
+    pairs = [(names[int(a)], names[int(b)]) for a, b in rng.integers(0, len(names), (20000, 2))]
+    out = np.full((len(pairs), 2), -1, dtype=np.int64)
+    assert _names.lookup_pairs(pairs, leaves, out) == 0
+    assert np.array_equal(out, np.array([(leaves[a], leaves[b]) for a, b in pairs]))
+    assert _names.lookup_pairs([], leaves, out) == 0
+    for bad in ([("leaf_1", "nope")], [("leaf_1",)], [["leaf_1", "leaf_2"]], [("leaf_1", 3)], [("leaf_1", "leaf_2", "leaf_3")],
+                [("leaf_1", "leaf_2"), None]):
+        assert _names.lookup_pairs(bad, leaves, out) == -1
+    assert _names.lookup_pairs([("a", "b")], {"a": 1, "b": "x"}, out) == -1          # value that is not an int
+    with pytest.raises(ValueError):
+        _names.lookup_pairs(pairs, leaves, np.empty(10, dtype=np.int64))              # buffer too small
+    with pytest.raises(TypeError):
+        _names.lookup_pairs(tuple(pairs), leaves, out)                                # not a list
