@@ -757,6 +757,84 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
         // node comes out of the sparse table right here), or -- ids not in order, no table -- the
         // depth of its deeper portal
         uint32_t key[Q], rank[Q];
+        if (have_sums) {
+            // Lineage-sum mode.  rec_p of either node = {rank of its portal | its depth << 16, offset
+            // of its lineage sums | record chunks << 28}: the meeting node (depth << 32 | node id)
+            // comes from the two ranks, a's whole side is one table read, and the sorted phase only
+            // climbs b's edges.  The gathers of the lane's Q pairs are issued level by level --
+            // pairs, records, sparse table, lineage sums -- without branches in between, so that
+            // all Q chains are in flight together (written pair by pair, each chain waited for the
+            // one before).  What the sorted phase needs besides b's record stays in LDS: b's edges
+            // below the meeting node, a's side, b's slot.
+            long long a_[Q], b_[Q];
+            bool in_[Q], valid_[Q];
+            uint2 va_[Q], vb_[Q];
+            uint64_t e1_[Q], e2_[Q];
+            float side_[Q];
+            const bool want_d = out_d.any();
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const long long i = base + (int)threadIdx.x + q * kCanopyBlock;
+                in_[q] = i < n;
+                a_[q] = 0;
+                b_[q] = 0;
+                if (in_[q]) src.load(i, a_[q], b_[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                valid_[q] = (unsigned long long)a_[q] < (unsigned long long)P.n_nodes &&
+                            (unsigned long long)b_[q] < (unsigned long long)P.n_nodes;
+                const long long sa = record_slot(valid_[q] ? a_[q] : 0, parity, P.n_leaves);
+                const long long sb = record_slot(valid_[q] ? b_[q] : 0, parity, P.n_leaves);
+                va_[q] = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
+                vb_[q] = reinterpret_cast<const uint2 *>(P.rec_p)[sb];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const uint32_t ra = va_[q].x & 0xFFFFu, rb = vb_[q].x & 0xFFFFu;
+                const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
+                const uint32_t len = r - l + 1;
+                const uint32_t k = 31u - (uint32_t)__clz((int)len);      // floor(log2(len))
+                e1_[q] = P.rmq64[(size_t)k * (size_t)P.canopy_nodes + l];
+                e2_[q] = P.rmq64[(size_t)k * (size_t)P.canopy_nodes + (r + 1 - (1u << k))];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                e1_[q] = (e2_[q] >> 32) < (e1_[q] >> 32) ? e2_[q] : e1_[q];     // the meeting node
+                side_[q] = 0.0f;
+                if (want_d)
+                    side_[q] = P.lineage[(size_t)(va_[q].y & 0x0FFFFFFFu) + ((va_[q].x >> 16) - (uint32_t)(e1_[q] >> 32))];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = (int)threadIdx.x + q * kCanopyBlock;
+                const long long i = base + j;
+                key[q] = 0xFFFFFFFFu;
+                rank[q] = 0;
+                if (!in_[q]) continue;
+                if (!valid_[q]) {
+                    record_fault(fault, a_[q], b_[q], P.n_nodes);
+                    SIDE_A[j] = __builtin_nanf("");      // (the distances of the tile leave LDS together, below)
+                    if (out_m) out_m[i] = -1;
+                    continue;
+                }
+                uint32_t k = 0;
+                if ((va_[q].x & 0xFFFFu) == (vb_[q].x & 0xFFFFu)) {     // shared portal: left to the general form
+                    MEET[j] = 0xFFFFFFFFu;
+                } else {
+                    // the MRCA id is known here and leaves at once, coalesced
+                    if (out_m) out_m[i] = (int)(uint32_t)e1_[q];
+                    if (!want_d) continue;      // MRCA ids only: this pair is done
+                    const uint32_t kb = (vb_[q].x >> 16) - (uint32_t)(e1_[q] >> 32);
+                    MEET[j] = kb;
+                    SIDE_A[j] = side_[q];
+                    SLOT_B[j] = (uint32_t)record_slot(b_[q], parity, P.n_leaves) | (vb_[q].y & 0xF0000000u);   // (+ how many 16-byte chunks of b's record matter)
+                    k = kb >> key_shift;
+                }
+                key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
+                rank[q] = atomicAdd(&HIST[key[q]], 1u);
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < Q; q++) {
             const int j = (int)threadIdx.x + q * kCanopyBlock;
@@ -769,45 +847,11 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
                     (unsigned long long)b >= (unsigned long long)P.n_nodes) {
                     record_fault(fault, a, b, P.n_nodes);
-                    if (have_sums) {     // (the distances of the tile leave LDS together, below)
-                        SIDE_A[j] = __builtin_nanf("");
-                        if (out_m) out_m[i] = -1;
-                    } else {
-                        store_result(out_d, out_m, i, __builtin_nanf(""), -1);
-                    }
+                    store_result(out_d, out_m, i, __builtin_nanf(""), -1);
                 } else {
                     const long long sa = record_slot(a, parity, P.n_leaves);
                     const long long sb = record_slot(b, parity, P.n_leaves);
                     uint32_t k;
-                    if (have_sums) {
-                        // Lineage-sum mode.  rec_p of either node = {rank of its portal | its depth << 16,
-                        // offset of its lineage sums}: the meeting node comes from the two ranks,
-                        // a's whole side is one table read -- fetched here, where every lane of the
-                        // workgroup has its reads in flight together -- and the sorted phase only
-                        // climbs b's edges.  What it needs besides b's record stays in LDS:
-                        // b's edges below the meeting node << 16 | meeting node, a's side, b's slot.
-                        const uint2 va = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
-                        const uint2 vb = reinterpret_cast<const uint2 *>(P.rec_p)[sb];
-                        if ((va.x & 0xFFFFu) == (vb.x & 0xFFFFu)) {     // shared portal: left to the general form
-                            MEET[j] = 0xFFFFFFFFu;
-                            k = 0;
-                        } else {
-                            // depth << 32 | node id of the meeting node: the MRCA id is known here
-                            // and leaves at once, coalesced
-                            const uint64_t meet = canopy_meet_ranks64(P.rmq64, P.canopy_nodes, va.x & 0xFFFFu, vb.x & 0xFFFFu);
-                            const uint32_t dm = (uint32_t)(meet >> 32);
-                            const uint32_t kb = (vb.x >> 16) - dm;
-                            if (out_m) out_m[i] = (int)(uint32_t)meet;
-                            if (!out_d.any()) continue;      // MRCA ids only: this pair is done
-                            MEET[j] = kb;
-                            SIDE_A[j] = P.lineage[(size_t)(va.y & 0x0FFFFFFFu) + ((va.x >> 16) - dm)];
-                            SLOT_B[j] = (uint32_t)sb | (vb.y & 0xF0000000u);     // (+ how many 16-byte chunks of b's record matter)
-                            k = kb >> key_shift;
-                        }
-                        key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
-                        rank[q] = atomicAdd(&HIST[key[q]], 1u);
-                        continue;
-                    }
                     const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
                     const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
                     const uint32_t da = cdep[pa], db = cdep[pb];
@@ -822,6 +866,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                     rank[q] = atomicAdd(&HIST[key[q]], 1u);
                 }
             }
+        }
         }
         __syncthreads();
         // exclusive scan of the 256 bucket counts (4 waves of 64)

@@ -412,6 +412,18 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
                 assert np.array_equal(m, want_m[:n_host])
             m_only = dev.distances_host(allp[:9_000], False, True)[1]
             assert np.array_equal(m_only, want_m[:9_000])
+            if on:      # either side of the walk / tile-sorted switch: 32768 pairs in HBM, 131072 from the host
+                for n_dev in (32767, 32768, 32769):
+                    out_d.fill_(-5.0)
+                    dev.distances_device(t.data_ptr(), n_dev, out_d.data_ptr(), out_m.data_ptr())
+                    dev.fault_check()
+                    assert_bits_equal(out_d[:n_dev].cpu().numpy(), want_d[:n_dev], "device n=%d" % n_dev)
+                    assert np.array_equal(out_m[:n_dev].cpu().numpy(), want_m[:n_dev])
+                    assert out_d[n_dev:n_dev + 64].eq(-5.0).all()
+                for n_host in (131071, 131072, 131073):
+                    d, m = dev.distances_host(allp[:n_host], True, True)
+                    assert_bits_equal(d, want_d[:n_host], "host n=%d" % n_host)
+                    assert np.array_equal(m, want_m[:n_host])
             # MRCA ids only through the tile-sorted kernel (they are complete after its key phase)
             out_m.fill_(-5)
             dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())
