@@ -55,6 +55,7 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
         return 1;
     }
     const bool canopy = prepare_canopy(parent.data(), dist.data(), T, max_canopy);
+    const bool lineage = canopy && prepare_lineage_sums(T, (int64_t)1 << 24);       // (in-order ids: always, unless too large)
     const int64_t n = T.n;
     std::uniform_int_distribution<int64_t> pick(0, n - 1);
     for (int k = 0; k < 20000; k++) {
@@ -71,6 +72,27 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
         if (c.mrca != w.mrca || std::memcmp(&c.dist, &w.dist, 4) != 0) {
             std::printf("mismatch leaves=%d skew=%g pair (%lld,%lld)\n", n_leaves, skew, (long long)a, (long long)b);
             return 3;
+        }
+        if (lineage) {      // the walk with a's side from the lineage sums, and the deep kernel's reads
+            LineageView lin;
+            lin.rec_p = T.rec_p.data();
+            lin.sums = T.lineage_sum.data();
+            lin.n_leaves = T.n_leaves;
+            lin.parity = T.parity_layout;
+            const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
+                                           T.tree_rmq.empty() ? nullptr : T.tree_rmq.data(), T.n, lin);
+            if (q.mrca != w.mrca || std::memcmp(&q.dist, &w.dist, 4) != 0) return 4;
+            if (A.portal != B.portal) {
+                uint32_t wpa, ya, wpb;
+                std::memcpy(&wpa, T.rec_p.data() + record_slot(a, T.parity_layout, T.n_leaves) * 8, 4);
+                std::memcpy(&ya, T.rec_p.data() + record_slot(a, T.parity_layout, T.n_leaves) * 8 + 4, 4);
+                std::memcpy(&wpb, T.rec_p.data() + record_slot(b, T.parity_layout, T.n_leaves) * 8, 4);
+                const uint64_t m64 = canopy_meet_ranks64(T.canopy_rmq64.data(), T.canopy_nodes, wpa & 0xFFFFu, wpb & 0xFFFFu);
+                const uint32_t dm = (uint32_t)(m64 >> 32);
+                const float d = ladder_sum_b<0>(T.ladder.data(), (wpb >> 16) - dm - B.nb,
+                                                T.lineage_sum[(size_t)(ya & 0x0FFFFFFFu) + ((wpa >> 16) - dm)], B.portal, B.D, B.nb);
+                if ((int32_t)(uint32_t)m64 != w.mrca || std::memcmp(&d, &w.dist, 4) != 0) return 5;
+            }
         }
     }
     return 0;
