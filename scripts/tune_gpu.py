@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--levels", type=int, default=20)
-    ap.add_argument("--tree", default="balanced", choices=["balanced", "ml", "nj", "random"])
+    ap.add_argument("--tree", default="balanced", choices=["balanced", "ml", "nj", "random", "caterpillar"])
     ap.add_argument("--pairs", type=int, default=100_000_000)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="name=v1,v2,...")
@@ -30,6 +30,9 @@ def main():
     dev = torch.device("cuda", 0)
     if args.tree == "balanced":
         parent, dist = synth.balanced_tree(args.levels)
+        leaf_ids = np.arange(0, len(parent), 2)
+    elif args.tree == "caterpillar":       # deep, small canopy: 2^levels leaves on one ladder
+        parent, dist = synth.caterpillar_tree(1 << args.levels)
         leaf_ids = np.arange(0, len(parent), 2)
     elif args.tree == "random":
         parent, dist = synth.random_binary_tree(1 << args.levels, seed=1)

@@ -1209,7 +1209,10 @@ static SortedShape sorted_shape(const st_tree *t)
         if ((m.rmq && !table) || (m.sums && !lineage)) continue;
         if ((forced == 1 || forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, m.rmq, m.sums) <= 160 * 1024)
             return {forced, m.rmq, m.sums};
-        if (image + sort_scratch_bytes(2, m.rmq, m.sums) <= 80 * 1024) return {2, m.rmq, m.sums};
+        // two workgroups per CU where that is possible -- except with lineage sums: that form of the
+        // kernel needs more than 64 VGPRs, so only one workgroup fits a CU anyway, and the larger
+        // tile wins (caterpillar of 2048 leaves: 1.35e10 pairs/s with 4096-pair tiles, 9.8e9 with 2048)
+        if (!m.sums && image + sort_scratch_bytes(2, m.rmq, m.sums) <= 80 * 1024) return {2, m.rmq, m.sums};
         // (measured on nj.tree, 9111 canopy nodes: lineage sums with 1024-pair tiles 1.37e10 pairs/s,
         // lock-step search with 2048-pair tiles 1.19e10, sparse table alone with 2048-pair tiles 1.03e10)
         for (const int q : {4, 2, 1}) {
