@@ -727,7 +727,9 @@ __host__ __device__ constexpr size_t sort_scratch_bytes(int q, bool rmq, bool su
     return (size_t)q * kCanopyBlock * (2 + (rmq ? 4 : 0) + (sums ? 8 : 0)) + (size_t)kSortBuckets * 4 + 64;
 }
 
-template <int CAP, int Q, typename Src>
+// SUMS: the lineage-sum mode (a separate instantiation: it needs about 120 VGPRs, the other
+// modes stay below 64, which is what lets two of their workgroups share a CU).
+template <int CAP, int Q, bool SUMS, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, int *__restrict__ out_m,
                                                                 Fault *fault, int key_shift)
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
     stage_ladder(P, lds_raw);
     unsigned char *scratch = lds_raw + ladder_image_bytes(P.canopy_nodes);
     const bool have_rmq = P.rmq != nullptr;
-    const bool have_sums = have_rmq && P.lineage != nullptr;
+    constexpr bool have_sums = SUMS;
     uint32_t *HIST = reinterpret_cast<uint32_t *>(scratch);          // [kSortBuckets] counts, then exclusive starts
     uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
     uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
         // node comes out of the sparse table right here), or -- ids not in order, no table -- the
         // depth of its deeper portal
         uint32_t key[Q], rank[Q];
-        if (have_sums) {
+        if constexpr (have_sums) {
             // Lineage-sum mode.  rec_p of either node = {rank of its portal | its depth << 16, offset
             // of its lineage sums | record chunks << 28}: the meeting node (depth << 32 | node id)
             // comes from the two ranks, a's whole side is one table read, and the sorted phase only
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
         __syncthreads();
         const uint32_t total = WSUM[4];
         // wave w: sorted groups w, 31 - w, 32 + w, 63 - w (short pairs with long pairs)
-        if (have_sums) {
+        if constexpr (have_sums) {
             // lineage-sum mode: per pair one global read is left (b's record), issued one
             // group ahead of the climb that uses it
             int jq[Q];
@@ -1272,7 +1274,10 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
                            (long long)n, out_d, out_m, fault, key_shift);
         return hipGetLastError();
     };
-    return q == 1 ? go(k_canopy_sorted<CAP, 1, Src>) : q == 2 ? go(k_canopy_sorted<CAP, 2, Src>) : go(k_canopy_sorted<CAP, 4, Src>);
+    if (shape.sums)
+        return q == 1 ? go(k_canopy_sorted<CAP, 1, true, Src>) : q == 2 ? go(k_canopy_sorted<CAP, 2, true, Src>)
+                                                                         : go(k_canopy_sorted<CAP, 4, true, Src>);
+    return q == 2 ? go(k_canopy_sorted<CAP, 2, false, Src>) : go(k_canopy_sorted<CAP, 4, false, Src>);
 }
 
 template <int CAP, typename Src>
