@@ -349,6 +349,85 @@ class ResultPool:
                 self.total -= cap
 
 
+class _LentBlock:
+    """An ordinary (pageable) block on loan to one numpy array; see RecyclePool."""
+
+    def __init__(self, pool, block, n, dtype):
+        self._pool, self._block = pool, block
+        self.__array_interface__ = {"data": (block.ctypes.data, False), "shape": (n,), "typestr": np.dtype(dtype).str, "version": 3}
+
+    def __del__(self):
+        try:
+            self._pool._give_back(self._block)
+        except Exception:     # interpreter shutdown
+            pass
+
+
+class RecyclePool:
+    """Recycled ordinary memory for LARGE result arrays (the default; the pinned ResultPool is the
+    opt-in alternative).
+
+    What a fresh numpy array costs beyond 32 MiB -- where glibc stops recycling freed blocks and
+    maps / unmaps every one -- is the kernel zeroing its pages on first touch and tearing them
+    down on release: for 5e7 pairs (600 MB of float64 + int32) three times as long as the
+    computation (``scripts/thp_probe.py``, ``profiles/host_path_r02.jsonl``: 1.2e9 pairs/s for
+    "call, drop the result" against 4.8e9 into arrays that are reused).  Result arrays of that
+    size are therefore handed out as views of blocks that come back here when the array and all
+    its views are gone, and go out again, resident, with the next call.  The memory is ordinary:
+    readable in ``fork()`` children, swappable, and returned to the system by ``trim()``.
+    ``SUCHTREE_AMD_RECYCLE_MB`` caps what the pool may hold (default 2048; 0 switches it off);
+    beyond the cap callers get plain ``np.empty`` arrays.
+    """
+
+    MIN_BYTES = 32 << 20
+
+    def __init__(self, budget_bytes=None):
+        if budget_bytes is None:
+            budget_bytes = int(os.environ.get("SUCHTREE_AMD_RECYCLE_MB", "2048")) << 20
+        self.budget = int(budget_bytes)
+        self.total = 0
+        self._free = {}
+        self._lock = threading.Lock()
+
+    def array(self, n, dtype):
+        """A 1-D array of ``n`` items in a recycled block, or None (too small, over budget)."""
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        if nbytes < self.MIN_BYTES or self.budget <= 0:
+            return None
+        cap = ResultPool._size_class(nbytes)
+        with self._lock:
+            stack = self._free.get(cap)
+            block = stack.pop() if stack else None
+            if block is None:
+                if self.total + cap > self.budget:
+                    return None
+                self.total += cap
+        if block is None:
+            block = np.empty(cap, dtype=np.uint8)
+        return np.asarray(_LentBlock(self, block, int(n), dtype))
+
+    def _give_back(self, block):
+        with self._lock:
+            self._free.setdefault(block.nbytes, []).append(block)
+
+    def trim(self):
+        """Release every block that is not on loan."""
+        with self._lock:
+            free, self._free = self._free, {}
+            for cap, blocks in free.items():
+                self.total -= cap * len(blocks)
+
+
+_recycle_pool = None
+
+
+def recycle_pool():
+    global _recycle_pool
+    if _recycle_pool is None:
+        _recycle_pool = RecyclePool()
+    return _recycle_pool
+
+
 _result_pool = None
 
 
@@ -446,10 +525,9 @@ class DeviceTree:
         if not want:
             return None
         if buf is None:
-            if self.pinned_results:
-                arr = result_pool().array(n, dtype)
-                if arr is not None:
-                    return arr
+            arr = (result_pool() if self.pinned_results else recycle_pool()).array(n, dtype)
+            if arr is not None:
+                return arr
             return np.empty(n, dtype=dtype)
         if buf.dtype != dtype or buf.shape != (n,) or not buf.flags.c_contiguous:
             raise ValueError("output buffer must be a contiguous %s array of shape (%d,)" % (np.dtype(dtype).name, n))

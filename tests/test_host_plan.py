@@ -113,3 +113,35 @@ def test_result_pool_lends_recycles_and_respects_its_budget(monkeypatch):
     assert fake.freed == [ptr] and pool.total == 0
     monkeypatch.setattr(pool, "_pid", -1)              # as seen from a forked child: hands out nothing
     assert pool.array(1_000_000, np.float64) is None
+
+
+def test_recycle_pool_of_ordinary_memory():
+    """_capi.RecyclePool (the default home of result arrays of 32 MiB and more): on loan while the
+    array or a view lives, handed out again afterwards (same memory), budget and trim."""
+    import gc
+
+    from suchtree_amd import _capi
+    P = _capi.RecyclePool(budget_bytes=300 << 20)
+    assert P.array(1000, np.float64) is None                       # small arrays: numpy's own business
+    a = P.array(5_000_000, np.float64)
+    assert a.shape == (5_000_000,) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+    ptr = a.ctypes.data
+    a[:] = 1.5
+    view = a[10:20]
+    del a
+    gc.collect()
+    assert not P._free                                             # the view keeps the block on loan
+    assert view[0] == 1.5
+    del view
+    gc.collect()
+    assert sum(len(v) for v in P._free.values()) == 1
+    b = P.array(4_500_000, np.float64)                             # same size class: the same block
+    assert b.ctypes.data == ptr
+    c = P.array(9_000_000, np.int32)
+    assert c is not None and c.ctypes.data != ptr and c.dtype == np.int32
+    assert P.array(40_000_000, np.float64) is None                 # over budget: caller falls back to np.empty
+    del b, c
+    gc.collect()
+    P.trim()
+    assert P.total == 0 and not P._free
+    assert _capi.RecyclePool(budget_bytes=0).array(50_000_000, np.float64) is None      # switched off
