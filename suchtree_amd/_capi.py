@@ -622,7 +622,8 @@ class DeviceTree:
     def quartets_host(self, quartets):
         """quartets: int64 (n,4) ndarray (any non-negative strides); returns int64 (n,4)."""
         n = int(quartets.shape[0])
-        out = np.empty((n, 4), dtype=np.int64)
+        flat = None if self.pinned_results else recycle_pool().array(4 * n, np.int64)      # (large results: recycled blocks)
+        out = flat.reshape(n, 4) if flat is not None else np.empty((n, 4), dtype=np.int64)
         if n == 0:
             return out
         if quartets.strides[0] % 8 or quartets.strides[1] % 8 or quartets.strides[0] < 0 or quartets.strides[1] < 0:
