@@ -13,7 +13,8 @@
 //           k_canopy_ilp     1-2 pairs per lane, predicated (the default)
 //           k_canopy_sorted  deep canopies: ladder form of the canopy (three edges per
 //                            16-byte LDS entry), pairs sorted by climb length within a
-//                            workgroup tile
+//                            workgroup tile; with in-order ids the meeting node comes from
+//                            a sparse table and a's side from per-node lineage sums
 //           k_canopy         scalar, branchy (records longer than 128 bytes)
 //
 // Every kernel is templated on a pair source (SrcContig / SrcContig32 / SrcStrided /
@@ -706,22 +707,29 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
     }
 }
 
-// Tile-sorted ladder form for deep canopies (the default there).  On trees like data/bigtrees/ml.tree
-// a pair's climb is anything from a few to several hundred LDS rounds, so in the kernels above
-// a wave is as slow as its longest lineage and keeps ~30 % of its lanes busy.  Here a workgroup
-// takes a tile of Q * 1024 pairs (Q = 2 with two workgroups per CU, 4 with one; 2 or 1 when the canopy image leaves no room for more), estimates each pair's work from the depths of its two portals
-// (one 4-byte read of each record), counting-sorts the tile by that key in LDS, and hands
-// every wave 64 pairs of similar length: waves, not lanes, differ in run time, and a wave's
+// Tile-sorted ladder form for deep canopies (the default there).  On trees like
+// data/bigtrees/ml.tree a pair's climb is anything from a few to several hundred LDS rounds, so
+// in the kernels above a wave is as slow as its longest lineage and keeps ~30 % of its lanes
+// busy.  Here a workgroup takes a tile of Q * 1024 pairs, computes a work estimate per pair (key
+// phase, input order), counting-sorts the tile by that key in LDS, and hands every wave 64 pairs
+// of similar length (sorted phase): waves, not lanes, differ in run time, and a wave's
 // instructions serve 64 active lanes.  Wave w processes sorted groups w, 31-w (, 32+w, 63-w):
-// short with long, so the waves of a workgroup finish together.  Results go straight to the pair's own
-// slot of the output (scattered within the tile's window, a few KiB).  The canopy sits in LDS
-// in its ladder form (tree_prep.h: three edges per 16-byte entry), so a climb of k edges is k/3
-// LDS reads; the meeting node is found first with integer work only (pair_math.h:
-// pair_ladder_split).  Not one float addition changes: same operands, same order.
+// short with long, so the waves of a workgroup finish together.  The canopy sits in LDS in its
+// ladder form (tree_prep.h: three edges per 16-byte entry), so a climb of k edges is k/3 LDS reads.
+// Three modes, by what the tree offers (sorted_shape):
+//   lock-step    any node numbering: the key is the depth of the deeper portal; the meeting node
+//                is searched on the ladder (pair_math.h: pair_ladder_split)
+//   sparse table in-order ids: the meeting node of every pair comes from canopy_pos / canopy_rmq
+//                in the key phase (exact key); both sides are then climbed with known counts
+//   lineage sums in-order ids + lineage table (SUMS): a's whole side is one table read in the key
+//                phase, the MRCA id leaves there too; the sorted phase climbs b's edges only and
+//                the distances leave together, coalesced (see below)
+// Not one float addition changes: same operands, same order.
 constexpr int kSortBuckets = 256;
-// LDS scratch of a tile of Q * 1024 pairs: per pair one uint16 (the sorted order) and -- when
-// the meeting nodes come from the sparse table -- one uint32 (the pair's meeting node), then
-// the bucket array and the scan carries
+// LDS scratch of a tile of Q * 1024 pairs: per pair one uint16 (the sorted order), with the
+// sparse table one uint32 (the pair's meeting node; b's edge count in lineage-sum mode), with
+// lineage sums two more words (a's side, later the distance; b's record slot), then the bucket
+// array and the scan carries
 __host__ __device__ constexpr size_t sort_scratch_bytes(int q, bool rmq, bool sums = false)
 {
     return (size_t)q * kCanopyBlock * (2 + (rmq ? 4 : 0) + (sums ? 8 : 0)) + (size_t)kSortBuckets * 4 + 64;
@@ -744,9 +752,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
     uint32_t *HIST = reinterpret_cast<uint32_t *>(scratch);          // [kSortBuckets] counts, then exclusive starts
     uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
     uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
-    uint32_t *MEET = reinterpret_cast<uint32_t *>(PERM + kSortTile); // [kSortTile] meeting node (depth << 16 | index), sparse-table mode
-    float *SIDE_A = reinterpret_cast<float *>(MEET + kSortTile);     // [kSortTile] a's side of the pair, lineage-sum mode
-    uint32_t *SLOT_B = reinterpret_cast<uint32_t *>(SIDE_A + kSortTile);   // [kSortTile] b's record slot, lineage-sum mode
+    uint32_t *MEET = reinterpret_cast<uint32_t *>(PERM + kSortTile); // [kSortTile] meeting node (depth << 16 | index), sparse-table mode; b's edge count, lineage-sum mode
+    float *SIDE_A = reinterpret_cast<float *>(MEET + kSortTile);     // [kSortTile] a's side of the pair, then its distance (lineage-sum mode)
+    uint32_t *SLOT_B = reinterpret_cast<uint32_t *>(SIDE_A + kSortTile);   // [kSortTile] b's record slot | chunks of its record that matter << 28 (lineage-sum mode)
 
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const int half = rec_bytes / 2;
