@@ -302,7 +302,9 @@ class ResultPool:
         self.budget = int(budget_bytes)
         self.total = 0
         self._free = {}
-        self._lock = threading.Lock()
+        # re-entrant: the garbage collector may run a lent block's __del__ (-> _give_back) on this
+        # very thread while it is inside array() / _give_back()
+        self._lock = threading.RLock()
         self._pid = os.getpid()
 
     @staticmethod
@@ -387,7 +389,9 @@ class RecyclePool:
         self.budget = int(budget_bytes)
         self.total = 0
         self._free = {}
-        self._lock = threading.Lock()
+        # re-entrant: the garbage collector may run a lent block's __del__ (-> _give_back) on this
+        # very thread while it is inside array() / _give_back()
+        self._lock = threading.RLock()
 
     def array(self, n, dtype):
         """A 1-D array of ``n`` items in a recycled block, or None (too small, over budget)."""
