@@ -352,6 +352,21 @@ def main():
                         "frac": rate / 1e9 / ceil,
                         "source": "requests: rocprofv3 TCC_EA0_RDREQ_sum in %s; ceiling: suchtree_amd/csrc/microbench.hip "
                                   "run in this process (random 32-byte reads, one per 64-byte sector)" % traffic_file}
+        if world == 1:
+            # MRCA ids alone (common_ancestors_bulk, quartets): on trees with in-order ids they come
+            # from a rank table and a sparse table over the canopy, without the distance kernels
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            chk = torch.empty(n, dtype=torch.int32, device=device)
+            tree.distances_device(pairs.data_ptr(), n, 0, chk.data_ptr(), stream=stream.cuda_stream)
+            ev0.record(stream)
+            for _ in range(5):
+                tree.distances_device(pairs.data_ptr(), n, 0, chk.data_ptr(), stream=stream.cuda_stream)
+            ev1.record(stream)
+            ev1.synchronize()
+            tree.fault_check(stream.cuda_stream)
+            line["mrca_ids_only"] = {"ids_per_s": 5.0 * n / (ev0.elapsed_time(ev1) * 1e-3),
+                                     "matches_the_fused_launch": bool(torch.equal(chk, out_m))}
+            del chk
         if world == 1 and not args.no_host_path:
             # end-to-end leg (SURVEY 8d asks for it next to the kernel-only figure; it is never
             # `value`): the same batch prefix from pageable host numpy arrays through the library's

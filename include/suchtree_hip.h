@@ -229,6 +229,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * form (default for deep canopies).
  * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
  * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
+ * "mrca_ranks": 1 (default) = MRCA-only requests on trees with in-order ids are answered from a
+ * per-node rank table and a sparse table over the canopy (no LDS, no understory records);
+ * 0 = they go through the distance kernels.
  * "lineage_sums": 1 (default) = on deep canopies with in-order ids the tile-sorted kernel reads
  * the first node's whole side of a pair from a table of per-node lineage sums (one 4-byte read;
  * table built when it stays below 1 GiB); 0 = it climbs that side through the canopy as well.

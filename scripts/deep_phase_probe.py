@@ -11,10 +11,17 @@ sys.path.insert(0, ROOT)
 from suchtree_amd import _capi   # noqa: E402
 
 n = 10_000_000
-for name in ("ml", "nj"):
-    z = np.load(os.path.join(ROOT, "tests", "golden", "%s_tree.npz" % name))
-    tree = _capi.DeviceTree(z["parent"], z["distance"])
-    pairs = torch.from_numpy(np.random.default_rng(2).choice(z["leaf_ids"].astype(np.int64), size=(n, 2))).cuda()
+from suchtree_amd import synth   # noqa: E402
+
+for name in ("ml", "nj", "balanced20"):
+    if name == "balanced20":
+        parent, dist = synth.balanced_tree(20)
+        leaf_ids = np.arange(0, len(parent), 2, dtype=np.int64)
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "%s_tree.npz" % name))
+        parent, dist, leaf_ids = z["parent"], z["distance"], z["leaf_ids"].astype(np.int64)
+    tree = _capi.DeviceTree(parent, dist)
+    pairs = torch.from_numpy(np.random.default_rng(2).choice(leaf_ids, size=(n, 2))).cuda()
     out_d = torch.empty(n, dtype=torch.float64, device="cuda")
     out_m = torch.empty(n, dtype=torch.int32, device="cuda")
     for label, pd, pm in (("both", out_d.data_ptr(), out_m.data_ptr()), ("mrca only", 0, out_m.data_ptr()), ("dist only", out_d.data_ptr(), 0)):

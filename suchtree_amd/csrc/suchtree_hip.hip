@@ -392,7 +392,8 @@ struct CanopyParams {
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
     const uint8_t *rec_p;          // [n_nodes * 8]            {portal rank | depth << 16, lineage offset | chunks << 28}; NULL without lineage sums
-    const uint64_t *rmq64;         // [levels * canopy_nodes] sparse table with node ids (tree_prep.h), lineage sums only
+    const uint64_t *rmq64;         // [levels * canopy_nodes] sparse table with node ids (tree_prep.h); in-order ids only
+    const uint32_t *rec_r;         // [n_nodes] portal rank | depth << 16 (MRCA-only queries); in-order ids only
     const float *lineage;          // lineage sums (tree_prep.h): a's whole side of a pair in one read
     long long n_nodes;
     long long n_leaves;
@@ -703,6 +704,35 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
                 if (valid[j]) store_result(out_d, out_m, idx[j], s[j], m[j]);
                 else store_result(out_d, out_m, idx[j], __builtin_nanf(""), -1);
             }
+        }
+    }
+}
+
+// MRCA ids only (common_ancestors_bulk, the six pairs of a quartet), trees with in-order ids: the
+// MRCA of two nodes is the shallowest node whose id lies between theirs, and unless both hang
+// below the same portal it is a canopy node -- two 4-byte reads (rank of either portal) and two
+// entries of the 64-bit sparse table (depth << 32 | node id).  No LDS, no understory records:
+// 4.8e10 ids/s on ml.tree where the canopy kernels' MRCA-only mode did 3.0e10.
+template <typename Src>
+__global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, long long n, int *__restrict__ out_m, Fault *fault)
+{
+    const bool parity = P.parity != 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long a, b;
+        src.load(i, a, b);
+        if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+            record_fault(fault, a, b, P.n_nodes);
+            out_m[i] = -1;
+            continue;
+        }
+        const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+        const uint32_t ra = P.rec_r[sa] & 0xFFFFu, rb = P.rec_r[sb] & 0xFFFFu;
+        if (ra != rb) {
+            out_m[i] = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
+        } else {      // shared portal: the MRCA is the portal or lies in the understory
+            const RecTables R{P.rec_a, P.rec_b, P.rec_i, P.rec_bytes / 2};
+            out_m[i] = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
         }
     }
 }
@@ -1130,6 +1160,7 @@ struct st_tree {
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
     uint8_t *d_rec_p = nullptr;       // lineage sums (deep canopies with a sparse table), else NULL
     uint64_t *d_rmq64 = nullptr;
+    uint32_t *d_rec_r = nullptr;      // MRCA-only queries (in-order ids), else NULL
     float *d_lineage = nullptr;
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the
@@ -1142,6 +1173,7 @@ struct st_tree {
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
+    int mrca_ranks = 1;       // tuning: 0 = MRCA-only requests go through the distance kernels
     int lineage_sums = 1;     // tuning: 0 = the tile-sorted kernel climbs a's canopy lineage even when the lineage-sum table exists
     LadderEntry *d_ladder = nullptr;
     uint16_t *d_cdepth = nullptr;
@@ -1264,7 +1296,7 @@ static hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, 
     const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q, shape.rmq, shape.sums);
     CanopyParams Pk = P;
     if (!shape.rmq) { Pk.cpos = nullptr; Pk.rmq = nullptr; }
-    if (!shape.sums) { Pk.rec_p = nullptr; Pk.lineage = nullptr; Pk.rmq64 = nullptr; }
+    if (!shape.sums) { Pk.rec_p = nullptr; Pk.lineage = nullptr; }
     const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t tile = (int64_t)q * kCanopyBlock;
     int64_t blocks = (n + tile - 1) / tile;
@@ -1324,12 +1356,18 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.rec_i = t->d_rec_i;
     P.rec_p = t->d_rec_p;
     P.rmq64 = t->d_rmq64;
+    P.rec_r = t->d_rec_r;
     P.lineage = t->d_lineage;
     P.n_nodes = t->n_nodes;
     P.n_leaves = t->n_leaves;
     P.canopy_nodes = t->canopy_nodes;
     P.rec_bytes = t->rec_bytes;
     P.parity = t->parity;
+    if (!out_d.any() && out_m && P.rec_r && P.rmq64 && t->mrca_ranks) {
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)t->n_cu * 8));
+        hipLaunchKernelGGL(k_mrca_ranks<Src>, dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault);
+        return hipGetLastError();
+    }
     // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
     // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
     if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 &&
@@ -1872,6 +1910,7 @@ static int build_tables(const int32_t *parent, const float *distance, int64_t n_
             }
         }
     }
+    if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
     if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
         return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
     return ST_OK;
@@ -1926,9 +1965,12 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
         if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
-        if (rc == ST_OK && t->d_rmq && !T.lineage_sum.empty()) {
-            rc = upload(&t->d_rec_p, T.rec_p, &bytes);
+        if (rc == ST_OK && !T.rec_r.empty()) {
+            rc = upload(&t->d_rec_r, T.rec_r, &bytes);
             if (rc == ST_OK) rc = upload(&t->d_rmq64, T.canopy_rmq64, &bytes);
+        }
+        if (rc == ST_OK && t->d_rmq && t->d_rmq64 && !T.lineage_sum.empty()) {
+            rc = upload(&t->d_rec_p, T.rec_p, &bytes);
             if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
         }
     }
@@ -2091,6 +2133,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_rec_i);
         (void)hipFree(t->d_rec_p);
         (void)hipFree(t->d_rmq64);
+        (void)hipFree(t->d_rec_r);
         (void)hipFree(t->d_lineage);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->q_tmp);
@@ -2144,6 +2187,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "tile_sort") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tile_sort must be 0 or 1");
         t->tile_sort = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "mrca_ranks") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "mrca_ranks must be 0 or 1");
+        t->mrca_ranks = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "lineage_sums") == 0) {

@@ -276,22 +276,41 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     return true;
 }
 
+static void build_rmq64(TreeTables &T)
+{
+    T.canopy_rmq64.resize(T.canopy_rmq.size());
+    for (size_t i = 0; i < T.canopy_rmq.size(); i++) {
+        const uint32_t e = T.canopy_rmq[i];
+        T.canopy_rmq64[i] = ((uint64_t)(e >> 16) << 32) | (uint32_t)T.canopy_id[(size_t)(e & 0xFFFFu)];
+    }
+}
+
+bool prepare_rank_table(TreeTables &T)
+{
+    T.rec_r.clear();
+    if (!T.has_canopy || !T.inorder_ids || T.canopy_rmq.empty() || T.tree_depth > 65535) return false;
+    build_rmq64(T);
+    T.rec_r.assign((size_t)T.n, 0u);
+    for (int64_t x = 0; x < T.n; x++) {
+        const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
+        uint32_t w0;
+        std::memcpy(&w0, T.rec_a.data() + slot * 8, 4);
+        T.rec_r[slot] = (uint32_t)T.canopy_pos[(size_t)(w0 & 0xFFFFu)] | ((uint32_t)T.depth[(size_t)x] << 16);
+    }
+    return true;
+}
+
 bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
 {
     T.lineage_sum.clear();
     T.rec_p.clear();
-    T.canopy_rmq64.clear();
     if (!T.has_canopy || !T.inorder_ids || T.canopy_rmq.empty()) return false;
     const int64_t n = T.n;
     int64_t entries = 0;
     for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
     // (offsets share their word with a 4-bit chunk count; slots are kept in 28 bits by the kernel)
     if (entries > max_entries || entries >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28) || T.tree_depth > 65535) return false;
-    T.canopy_rmq64.resize(T.canopy_rmq.size());
-    for (size_t i = 0; i < T.canopy_rmq.size(); i++) {
-        const uint32_t e = T.canopy_rmq[i];
-        T.canopy_rmq64[i] = ((uint64_t)(e >> 16) << 32) | (uint32_t)T.canopy_id[(size_t)(e & 0xFFFFu)];
-    }
+    build_rmq64(T);
     T.lineage_sum.resize((size_t)entries);
     T.rec_p.assign((size_t)n * 8, 0);
     int64_t off = 0;

@@ -135,6 +135,11 @@ struct TreeTables {
     std::vector<float> lineage_sum;     // [sum over nodes of depth + 1] or empty
     std::vector<uint8_t> rec_p;         // [n * 8], slot order, or empty
     std::vector<uint64_t> canopy_rmq64; // [rmq_levels * canopy_nodes] or empty
+    // rec_r[slot] = rank of x's portal | depth(x) << 16 (the first word of rec_p, on its own: 4
+    // bytes per node).  With canopy_rmq64 it answers MRCA-only queries without touching the
+    // understory records or LDS: two 4-byte reads and two table entries per pair
+    // (prepare_rank_table; in-order ids).
+    std::vector<uint32_t> rec_r;        // [n], slot order, or empty
 };
 
 // Record slot of node id x.  With the parity layout leaf records come first
@@ -147,6 +152,9 @@ ST_HD int64_t record_slot(int64_t x, bool parity, int64_t n_leaves) {
 // set when it is not a single rooted tree.
 bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
                    TreeTables &T, std::string &err);
+
+// rec_r and canopy_rmq64 (see TreeTables) for trees with a canopy and in-order ids; false otherwise.
+bool prepare_rank_table(TreeTables &T);
 
 // Lineage sums of every node (see TreeTables), for trees with a canopy and a sparse table and
 // at most max_entries table entries; returns false (tables left empty) otherwise.

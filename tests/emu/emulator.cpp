@@ -33,7 +33,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     TreeTables T;
     if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
     bool canopy = false;
-    bool lineage = false;
+    bool lineage = false, ranks = false;
     if (strategy == 1) {   // the walk family uses the lineage sums of trees that have them
         TreeTables C = T;
         if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27)) {
@@ -45,6 +45,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
         canopy = prepare_canopy(parent, distance, T);
         if (!canopy) { g_err = "canopy not admitted"; return 2; }
         lineage = prepare_lineage_sums(T, (int64_t)1 << 27);   // (in-order ids only)
+        ranks = prepare_rank_table(T);                         // (in-order ids only)
     }
     if (info) {
         info->n_leaves = T.n_leaves;
@@ -100,6 +101,19 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
             if (wa != (A.portal | (A.nb << 16)) || std::memcmp(&pbot_a, &A.pbot, 4) != 0) {
                 g_err = "rec_a disagrees with rec_b / rec_i";
                 return 3;
+            }
+            if (ranks && A.portal != B.portal) {     // the MRCA-only kernel's form: two rank reads, two table entries
+                const uint64_t m64 = canopy_meet_ranks64(T.canopy_rmq64.data(), T.canopy_nodes, T.rec_r[(size_t)sa] & 0xFFFFu,
+                                                         T.rec_r[(size_t)sb] & 0xFFFFu);
+                const PairResult ref = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), wa & 0xFFFFu, pbot_a, B.portal, B.D, B.nb);
+                if ((int32_t)(uint32_t)m64 != ref.mrca || (T.rec_r[(size_t)sa] >> 16) != (uint32_t)T.depth[(size_t)a]) {
+                    g_err = "rank-table MRCA disagrees with the canopy climb";
+                    return 10;
+                }
+            }
+            if (ranks && A.portal == B.portal && (T.rec_r[(size_t)sa] & 0xFFFFu) != (T.rec_r[(size_t)sb] & 0xFFFFu)) {
+                g_err = "rank table: equal portals, different ranks";
+                return 11;
             }
             if (A.portal != B.portal) {
                 r = pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), wa & 0xFFFFu, pbot_a,

@@ -445,6 +445,43 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
         dev.close()
 
 
+def test_mrca_only_requests_from_the_rank_table(ml_arrays):
+    """MRCA ids without distances on trees with in-order ids: k_mrca_ranks (rank of either portal
+    + sparse table; shared-portal pairs through the understory records).  Shallow and deep tree,
+    internal nodes, near pairs, (x, x), ancestor pairs, out-of-range ids; the option off as well."""
+    import torch
+    rng = np.random.default_rng(909)
+    for parent, dist in (synth.balanced_tree(16), synth.random_binary_tree(40000, seed=5), (ml_arrays[0], ml_arrays[1])):
+        n = len(parent)
+        O = OracleTree(parent, dist)
+        dev = _capi.DeviceTree(parent, dist)
+        pairs = rng.integers(0, n, (150_000, 2))
+        a = rng.integers(0, n - 9, 50_000)
+        near = np.stack([a, a + rng.integers(0, 9, a.size)], 1)
+        up = rng.integers(0, n, 10_000)
+        anc = up.copy()
+        for _ in range(5):
+            anc = np.where(parent[anc] >= 0, parent[anc], anc)
+        allp = np.concatenate([pairs, near, np.stack([up, anc], 1), np.stack([anc, up], 1), np.stack([up, up], 1)]).astype(np.int64)
+        want = O.mrca_bulk(allp)
+        t = torch.from_numpy(allp).cuda()
+        for on in (1, 0):
+            dev.set_option("mrca_ranks", on)
+            out_m = torch.full((len(allp) + 8,), -7, dtype=torch.int32, device="cuda")
+            dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())
+            dev.fault_check()
+            assert np.array_equal(out_m[:len(allp)].cpu().numpy(), want), on
+            assert out_m[len(allp):].eq(-7).all()
+            m = dev.distances_host(allp, False, True)[1]
+            assert np.array_equal(m, want), on
+            bad = allp[:30_000].copy()
+            bad[12_345, 1] = -4
+            with pytest.raises(_capi.InvalidNodeError) as err:
+                dev.distances_host(bad, False, True)
+            assert err.value.node_id == -4
+        dev.close()
+
+
 def test_general_trees_through_the_c_abi():
     """Arbitrary arity and arbitrary node numbering (not what the facade produces, but what the
     C ABI accepts): records in identity order, checked against the plain-Python restatement."""
