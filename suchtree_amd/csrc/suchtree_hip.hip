@@ -2520,54 +2520,87 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     ST_DEVICE(t->device);
     std::lock_guard<std::mutex> lock(t->dp->m);
     HostPipe &pipe = t->dp->pipe;
-    // (n,4) int64 in and out are each the size of two pair rows: reuse the pipe's slots,
-    // input through slot 0, output through slot 1
-    const int64_t chunk = std::min<int64_t>(n, kHostChunk / 2);
+    // (n,4) int64 in and out are each the size of two pair rows.  Every slot of the pipe carries
+    // one chunk: its pinned buffer holds the chunk's quartets (first half) and, later, its
+    // topologies (second half, written by the kernel); while chunk c is on the GPU the host
+    // unpacks chunk c-2 and packs chunk c+1.
+    const int64_t chunk = std::min<int64_t>(n, kHostChunk / 8);
     {
-        hipError_t e = pipe.ensure(std::max<int64_t>(2 * chunk, 1024));
+        hipError_t e = pipe.ensure(std::max<int64_t>(4 * chunk, 1024));
         if (e == hipSuccess) e = pipe.ensure_device_in();
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
     }
-    PipeSlot &in = pipe.slot[0], &out = pipe.slot[1];
-    if (begin_host_faults(t, in.stream) != ST_OK) return ST_ERR_HIP;
+    if (begin_host_faults(t, pipe.slot[0].stream) != ST_OK) return ST_ERR_HIP;
     const WalkParams P = walk_params(t);
-    for (int64_t off = 0; off < n; off += chunk) {
-        const int64_t m = std::min(chunk, n - off);
-        int64_t *h = static_cast<int64_t *>(in.h_in);
-        const int64_t *src = quartets + off * stride0;
-        pipe.pool.parallel_for(m, [=](int64_t b, int64_t e) {
-            for (int64_t k = b; k < e; k++)
-                for (int c = 0; c < 4; c++) h[4 * k + c] = src[k * stride0 + c * stride1];
-        });
-        ST_HIP(hipMemcpyAsync(in.d_in, in.h_in, (size_t)m * 32, hipMemcpyHostToDevice, in.stream));
-        int64_t blocks = std::min<int64_t>((m + 255) / 256, (int64_t)t->n_cu * 16);
-        if (t->strategy == ST_STRATEGY_CANOPY && 6 * m >= canopy_min_pairs(t)) {
-            // six MRCA ids per quartet out of the canopy kernels, then the pick
-            if (t->q_tmp_cap < m) {
-                (void)hipFree(t->q_tmp);
-                t->q_tmp = nullptr;
-                t->q_tmp_cap = 0;
-                ST_HIP(hipMalloc(&t->q_tmp, (size_t)chunk * 24));
-                t->q_tmp_cap = chunk;
-            }
-            const int rc = enqueue_src(t, SrcQuartet{static_cast<const long long *>(in.d_in)}, 6 * m,
-                                       DistSink{nullptr, nullptr}, static_cast<int32_t *>(t->q_tmp),
-                                       t->d_fault_host, in.stream);
-            if (rc != ST_OK) return rc;
-            hipLaunchKernelGGL(k_quartet_pick, dim3((unsigned)blocks), dim3(256), 0, in.stream,
-                               static_cast<const long long *>(in.d_in), static_cast<const int *>(t->q_tmp),
-                               (long long)m, static_cast<long long *>(out.h_in));
-        } else {
-            hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, in.stream, P,
-                               static_cast<const long long *>(in.d_in), (long long)m, 4LL, 1LL,
-                               static_cast<long long *>(out.h_in), t->d_fault_host);
+    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && 6 * chunk >= canopy_min_pairs(t);
+    if (canopy && t->q_tmp_cap < kPipeSlots * chunk) {      // six MRCA ids per quartet, per slot
+        (void)hipFree(t->q_tmp);
+        t->q_tmp = nullptr;
+        t->q_tmp_cap = 0;
+        ST_HIP(hipMalloc(&t->q_tmp, (size_t)kPipeSlots * (size_t)chunk * 24));
+        t->q_tmp_cap = kPipeSlots * chunk;
+    }
+    auto out_of = [&](PipeSlot &s) { return reinterpret_cast<int64_t *>(static_cast<char *>(s.h_in) + (size_t)chunk * 32); };
+    auto drain = [&](PipeSlot &s) -> hipError_t {
+        if (!s.busy) return hipSuccess;
+        s.busy = false;
+        const hipError_t e = hipEventSynchronize(s.done);
+        if (e != hipSuccess) return e;
+        pipe.pool.copy(out_topologies + s.off * 4, out_of(s), s.m * 32);     // topologies were written straight into pinned memory
+        return hipSuccess;
+    };
+    auto bail = [&](int code, const std::string &msg) {
+        for (auto &s : pipe.slot) {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            s.busy = false;
         }
-        ST_HIP(hipGetLastError());
-        ST_HIP(hipStreamSynchronize(in.stream));    // topologies were written straight into pinned out.h_in
-        pipe.pool.copy(out_topologies + off * 4, out.h_in, m * 32);
+        return fail(code, msg);
+    };
+    int64_t k = 0;
+    for (int64_t off = 0; off < n; off += chunk, k++) {
+        const int64_t m = std::min(chunk, n - off);
+        const int slot_index = (int)(k % kPipeSlots);
+        PipeSlot &s = pipe.slot[slot_index];
+        hipError_t e = drain(s);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
+        int64_t *h = static_cast<int64_t *>(s.h_in);
+        const int64_t *src = quartets + off * stride0;
+        pipe.pool.parallel_for(m, [=](int64_t b, int64_t e2) {
+            for (int64_t q = b; q < e2; q++)
+                for (int c = 0; c < 4; c++) h[4 * q + c] = src[q * stride0 + c * stride1];
+        });
+        e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * 32, hipMemcpyHostToDevice, s.stream);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((m + 255) / 256, (int64_t)t->n_cu * 16));
+        if (canopy && 6 * m >= canopy_min_pairs(t)) {
+            // six MRCA ids per quartet out of the canopy / rank-table kernels, then the pick
+            int32_t *tmp = static_cast<int32_t *>(t->q_tmp) + (size_t)slot_index * (size_t)chunk * 6;
+            const int rc = enqueue_src(t, SrcQuartet{static_cast<const long long *>(s.d_in)}, 6 * m,
+                                       DistSink{nullptr, nullptr}, tmp, t->d_fault_host, s.stream);
+            if (rc != ST_OK) return bail(rc, g_last_error);
+            hipLaunchKernelGGL(k_quartet_pick, dim3((unsigned)blocks), dim3(256), 0, s.stream,
+                               static_cast<const long long *>(s.d_in), static_cast<const int *>(tmp),
+                               (long long)m, reinterpret_cast<long long *>(out_of(s)));
+        } else {
+            hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, s.stream, P,
+                               static_cast<const long long *>(s.d_in), (long long)m, 4LL, 1LL,
+                               reinterpret_cast<long long *>(out_of(s)), t->d_fault_host);
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
+        s.busy = true;
+        s.off = off;
+        s.m = m;
+        e = drain(pipe.slot[(k + 1) % kPipeSlots]);      // the oldest chunk, while the newer ones are in flight
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
+    }
+    for (int j = 0; j < kPipeSlots; j++) {
+        const hipError_t e = drain(pipe.slot[(k + j) % kPipeSlots]);
+        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
     }
     Fault f;
-    const int rc = end_host_faults(t, in.stream, f);
+    const int rc = end_host_faults(t, pipe.slot[0].stream, f);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
 }

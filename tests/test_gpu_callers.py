@@ -224,6 +224,21 @@ def test_quartet_topologies(ml_arrays):
     qi = rng.integers(0, len(parent), (20_000, 4))             # internal nodes, repeated ids
     assert np.array_equal(T.quartet_topologies_bulk(qi), O.quartets(qi))
     assert np.array_equal(T.quartet_topologies_bulk(np.asfortranarray(q[:5000])), O.quartets(q[:5000]))
+    # several chunks through the three slots of the host pipe (524,288 quartets each), an id out of
+    # range in a late chunk, and MRCA ids from the rank-table kernel or from the distance kernels
+    big = rng.choice(leaf_ids, size=(1_700_001, 4))
+    for ranks in (1, 0):
+        T._device_tree().set_option("mrca_ranks", ranks)
+        got_big = T.quartet_topologies_bulk(big)
+        for lo in (0, 524_000, 1_048_500, 1_690_000):
+            assert np.array_equal(got_big[lo:lo + 10_001], O.quartets(big[lo:lo + 10_001])), (ranks, lo)
+    assert np.array_equal(np.sort(got_big, axis=1), np.sort(big, axis=1))
+    bad = big.copy()
+    bad[1_600_000, 2] = len(parent) + 11
+    with pytest.raises(InvalidNodeError) as err:
+        T.quartet_topologies_bulk(bad)
+    assert err.value.node_id == len(parent) + 11
+    assert np.array_equal(T.quartet_topologies_bulk(q), got)          # the pipe is clean after the error
     with pytest.raises(ValueError, match=r"Expected \(n, 4\) array"):
         T.quartet_topologies_bulk(np.zeros((3, 3), dtype=np.int64))
     with pytest.raises(InvalidNodeError):
