@@ -1281,6 +1281,11 @@ static int64_t canopy_min_pairs(const st_tree *t)
     return t->tile_sort && t->d_lineage && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
 }
 
+static bool mrca_ranks_ready(const st_tree *t)
+{
+    return t->strategy == ST_STRATEGY_CANOPY && t->mrca_ranks && t->d_rec_r && t->d_rmq64;
+}
+
 static bool wants_device_stage(const st_tree *t, int64_t m)
 {
     if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
@@ -1423,8 +1428,12 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, in
     // of the same climb, and that is ~7x faster than walking the global table
     // (allow_sorted = false: pairs and results are in pinned host memory, which the tile-sorted
     // kernel must not work on -- it reads every pair twice and scatters its stores)
-    const bool canopy = t->strategy == ST_STRATEGY_CANOPY && n >= canopy_min_pairs(t) &&
-                        (allow_sorted || !(t->tile_sort && sorted_q(t) > 0));
+    // MRCA ids only, rank table available: k_mrca_ranks whatever the tree's depth (it reads every
+    // pair once and stores coalesced, so it may also work on pinned host memory)
+    const bool ranks_only = !d_out.any() && d_mrca && mrca_ranks_ready(t) && n >= kCanopyMinPairs;
+    const bool canopy = ranks_only ||
+                        (t->strategy == ST_STRATEGY_CANOPY && n >= canopy_min_pairs(t) &&
+                         (allow_sorted || !(t->tile_sort && sorted_q(t) > 0)));
     const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, fault, stream)
                                 : launch_walk(t, src, n, d_out, d_mrca, fault, stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1543,8 +1552,10 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
         ST_HIP(hipHostMalloc(&t->mb_host, bytes, hipHostMallocMapped));
         ST_HIP(hipHostGetDevicePointer(&t->mb_dev, t->mb_host, 0));
         ST_HIP(hipMalloc(reinterpret_cast<void **>(&t->d_fault_mb), sizeof(Fault)));      // [0]: block counter of the mailbox kernel
-        ST_HIP(hipMemset(t->d_fault_mb, 0, sizeof(Fault)));
         ST_HIP(hipStreamCreateWithFlags(&t->mb_stream, hipStreamNonBlocking));
+        // cleared ON the mailbox stream: a hipMemset on the null stream is not ordered before
+        // kernels of a non-blocking stream, and recycled device memory is not zero
+        ST_HIP(hipMemsetAsync(t->d_fault_mb, 0, sizeof(Fault), t->mb_stream));
         *reinterpret_cast<volatile unsigned *>(static_cast<char *>(t->mb_host) + (size_t)kMailboxPairs * 28) = 0;
     }
     int64_t *h_pairs = static_cast<int64_t *>(t->mb_host);
@@ -1675,7 +1686,7 @@ template <typename MakeSrc>
 static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_words_per_pair, const HostOut &out,
                         MakeSrc make_src)
 {
-    if (!wants_device_stage(r, m)) {
+    if (!wants_device_stage(r, m) || (!out.dist && mrca_ranks_ready(r))) {
         DistSink sink{nullptr, nullptr};
         if (out.dist) {
             if (out.direct_d) sink.d64 = out.dist + off;
