@@ -56,6 +56,7 @@ def main():
                     if k == 0:
                         dev.set_option("tile_sort", int(rng.integers(0, 2)))
                         dev.set_option("lineage_sums", int(rng.integers(0, 2)))
+                    dev.set_option("mrca_ranks", int(rng.integers(0, 2)))
                 if rng.random() < 0.2:
                     view = np.ascontiguousarray(view).astype(np.int32)      # the int32 entry point
                 d, m = dev.distances_host(view, want_d, want_m)
@@ -83,6 +84,14 @@ def main():
                     gp = np.stack([ids[np.minimum(r, c)], ids[np.maximum(r, c)]], 1)
                     if not np.array_equal(gd.view(np.int64), O.distances(gp).view(np.int64)):
                         errors.append("grid mismatch tree %d m %d" % (k, mm))
+                if rng.random() < 0.1:
+                    # quartet topologies (six MRCA ids each), one chunk to several
+                    nq = int(10 ** rng.uniform(0, 6.2))
+                    quartets = rng.integers(0, n_nodes, (nq, 4))
+                    got = dev.quartets_host(quartets)
+                    lo = int(rng.integers(0, max(1, nq - 3000)))
+                    if not np.array_equal(got[lo:lo + 3000], O.quartets(quartets[lo:lo + 3000])):
+                        errors.append("quartet mismatch tree %d n %d at %d" % (k, nq, lo))
                 if n > 10 and rng.random() < 0.1:
                     bad = pairs.copy()
                     bad[int(rng.integers(0, n)), int(rng.integers(0, 2))] = n_nodes + 3
