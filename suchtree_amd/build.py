@@ -19,6 +19,8 @@ MICRO_LIB = os.path.join(HERE, "libst_microbench.so")      # measurement helpers
 MICRO_SRC = os.path.join(CSRC, "microbench.hip")
 HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
            os.path.join(CSRC, "host_pipe.h"), os.path.join(CSRC, "host_copy.h"),
+           os.path.join(CSRC, "device_common.h"), os.path.join(CSRC, "kernels_walk.h"),
+           os.path.join(CSRC, "kernels_canopy.h"), os.path.join(CSRC, "kernels_misc.h"),
            os.path.join(HERE, "..", "include", "suchtree_hip.h")]
 
 FLAGS = [

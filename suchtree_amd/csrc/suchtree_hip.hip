@@ -21,6 +21,10 @@
 // SrcTriangle / SrcGrid / SrcQuartet): an explicit (n,2) array, or pairs derived from their
 // index (all-pairs triangle, rows x columns grid, the six pairs of a quartet).
 //
+// The kernels live in headers included below, in this order: device_common.h (fault word, pair
+// sources, result sinks), kernels_walk.h, kernels_canopy.h, kernels_misc.h; this file holds the
+// error plumbing, the copy kernels of the host pipe and everything host-side.
+//
 // Host side of the C ABI: tree upload to one or several GPUs (tree_prep.cpp builds the
 // tables), the zero-copy host path (host_pipe.h, host_copy.h: kernels read and write pinned
 // host memory), the small-batch mailbox, fault read-back, k-nearest selection, graph matrices.
@@ -97,1012 +101,13 @@ private:
     if (device_scope_.error() != hipSuccess)                                               \
         return fail(ST_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(device_scope_.error()))
 
-// --------------------------------------------------------------------------
-// device-side helpers
-// --------------------------------------------------------------------------
-struct Fault {
-    long long max_bad;   // largest offending id seen  (init INT64_MIN)
-    long long min_bad;   // smallest offending id seen (init INT64_MAX)
-};
-
-__device__ __forceinline__ void record_fault(Fault *f, long long a, long long b, long long n_nodes)
-{
-    if (a < 0 || a >= n_nodes) { atomicMax(&f->max_bad, a); atomicMin(&f->min_bad, a); }
-    if (b < 0 || b >= n_nodes) { atomicMax(&f->max_bad, b); atomicMin(&f->min_bad, b); }
-}
-
-// ---- pair sources: where pair number i of a launch comes from ----------------
-// C-order int64 (n,2): one 16-byte load per lane, fully coalesced.
-struct SrcContig {
-    const long long *pairs;
-    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
-    {
-        const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];
-        a = v.x;
-        b = v.y;
-    }
-};
-
-// C-order int32 (n,2): what the host path ships over PCIe (node ids always fit in 31 bits;
-// the packing step clamps anything wider so that it still fails the range check).
-struct SrcContig32 {
-    const int *pairs;
-    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
-    {
-        const int2 v = reinterpret_cast<const int2 *>(pairs)[i];
-        a = v.x;
-        b = v.y;
-    }
-};
-
-// Any other (n,2) view: element strides s0 (rows) and s1 (columns).
-struct SrcStrided {
-    const long long *pairs;
-    long long s0, s1;
-    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
-    {
-        a = pairs[i * s0];
-        b = pairs[i * s0 + s1];
-    }
-};
-
-// All-pairs generator: pair k = (ids[j], ids[i]) with k = i(i-1)/2 + j, 0 <= j < i,
-// the enumeration of SuchLinkedTrees.linked_distances (MuchTree.pyx:2918-2925) and, up to
-// order, of pairwise_distances (:1111-1114).  Nothing is read but the id list: within a
-// wave b = ids[i] is (nearly) uniform and a = ids[j] walks the list, so the record reads
-// of consecutive lanes fall on consecutive sectors.
-struct SrcTriangle {
-    const long long *ids;
-    long long stride;   // element stride of ids
-    long long k0;       // first pair index of this launch
-    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
-    {
-        const long long k = k0 + i;
-        long long row = (long long)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);
-        if (row * (row - 1) / 2 > k) row--;
-        if ((row + 1) * row / 2 <= k) row++;
-        const long long col = k - row * (row - 1) / 2;
-        a = ids[col * stride];
-        b = ids[row * stride];
-    }
-};
-
-// Grid generator: element e = e0 + i of an n_rows x n_cols grid (C order) is the pair
-// (rows[r], cols[c]), r = e / n_cols, c = e % n_cols.  `symmetric` (rows and cols are the same
-// id list): below the diagonal the pair is taken in the order of its mirror image above it,
-// (ids[c], ids[r]) for c < r, so the square is exactly the mirrored upper triangle that
-// pairwise_distances builds (MuchTree.pyx:1106-1124: d(ids[i], ids[j]) for i < j, stored at
-// [i,j] and [j,i]); the diagonal comes out as d(x,x) = 0.  Consecutive lanes share one endpoint
-// and walk the id list with the other, so record reads coalesce as in the triangle.
-struct SrcGrid {
-    const long long *rows, *cols;
-    long long n_cols, e0;
-    int symmetric;
-    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
-    {
-        const long long e = e0 + i;
-        const long long r = e / n_cols, c = e - r * n_cols;
-        a = rows[r];
-        b = cols[c];
-        if (symmetric && c < r) { const long long t = a; a = b; b = t; }
-    }
-};
-
-// Where distances go.  The C ABI's contract is float64 (what the reference returns); the
-// values are float32 sums, so the host path ships them over PCIe as float32 and widens them
-// on the host (half the D2H bytes, bit-identical result).
-struct DistSink {
-    double *d64;
-    float *f32;
-    __host__ __device__ bool any() const { return d64 != nullptr || f32 != nullptr; }
-};
-
-// The six pairs of a quartet (a,b,c,d), in the reference's order ab ac ad bc bd cd
-// (MuchTree.pyx:1353-1358): pair i is combination i % 6 of quartet i / 6.  Lets the canopy
-// kernels produce the six MRCA ids of every quartet without a pair array.
-struct SrcQuartet {
-    const long long *q;   // C-order int64 (n,4)
-    __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
-    {
-        const long long quartet = i / 6;
-        const int combo = (int)(i - quartet * 6);
-        const int ia = (0x940 >> (2 * combo)) & 3;    // 0 0 0 1 1 2
-        const int ib = (0xFB9 >> (2 * combo)) & 3;    // 1 2 3 2 3 3
-        a = q[quartet * 4 + ia];
-        b = q[quartet * 4 + ib];
-    }
-};
-
-__device__ __forceinline__ void store_result(const DistSink &out_d, int *__restrict__ out_m,
-                                             long long i, float d, int m)
-{
-    if (out_d.d64) out_d.d64[i] = (double)d;
-    else if (out_d.f32) out_d.f32[i] = d;
-    if (out_m) out_m[i] = m;
-}
-
-// --------------------------------------------------------------------------
-// walk kernel
-// --------------------------------------------------------------------------
-struct WalkParams {
-    const Node8 *nodes;
-    const int32_t *depth;
-    const Stride3 *stride;
-    const uint64_t *rmq;     // whole-tree sparse table for the meeting node, or NULL
-    long long n_nodes;
-    LineageView lineage;     // a's side in one read (deep trees with lineage sums), else empty
-};
-
-template <typename Src>
-__global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n,
-                                              DistSink out_d, int *__restrict__ out_m,
-                                              Fault *fault)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-            (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-            record_fault(fault, a, b, P.n_nodes);
-            store_result(out_d, out_m, i, __builtin_nanf(""), -1);
-            continue;
-        }
-        if (out_d.any()) {
-            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, P.rmq, P.n_nodes, P.lineage);
-            store_result(out_d, out_m, i, r.dist, r.mrca);
-        } else {
-            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, nullptr, P.rmq, P.n_nodes);
-        }
-    }
-}
-
-// The mailbox form of k_walk (small host batches, one lane per pair, no grid stride): pairs and
-// results live in pinned host memory, and so does a completion word -- the last workgroup to
-// finish publishes the call's sequence number there (system-scope release after every block's
-// system-scope fence), so the host learns of completion by polling its own memory instead of
-// paying a stream synchronisation (the driver's wake-up costs as much as the whole kernel).
-__global__ __launch_bounds__(64) void k_walk_mailbox(WalkParams P, const long long *__restrict__ pairs, int n,
-                                                     double *__restrict__ out_d, int *__restrict__ out_m,
-                                                     unsigned *block_counter, unsigned *done_word, unsigned seq)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const longlong2 v = reinterpret_cast<const longlong2 *>(pairs)[i];   // (ids were range-checked on the host)
-        if (out_d) {
-            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)v.x, (int32_t)v.y, P.rmq, P.n_nodes, P.lineage);
-            out_d[i] = (double)r.dist;
-            if (out_m) out_m[i] = r.mrca;
-        } else {
-            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)v.x, (int32_t)v.y, nullptr, P.rmq, P.n_nodes);
-        }
-    }
-    __threadfence_system();            // this lane's results are visible to the host ...
-    __syncthreads();                   // ... and so are the whole block's
-    if (threadIdx.x == 0) {
-        const unsigned done = atomicAdd(block_counter, 1u);
-        if (done == gridDim.x - 1) {   // last block of the launch
-            *block_counter = 0;        // (launches on the mailbox stream are serial)
-            __threadfence_system();
-            __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-// Quartet topologies (MuchTree.pyx:1331-1376): six MRCAs per quartet (ab ac ad bc bd cd),
-// the first MRCA id that occurs exactly once names the sister pair; the row is re-ordered
-// by the matching line of the table I = {0123, 0213, 0312, 1203, 1302, 2301}.  If no id is
-// unique the reference's loop leaves j = 5, reproduced here.  Integer work only.
-__global__ __launch_bounds__(256) void k_quartets(WalkParams P, const long long *__restrict__ q,
-                                                  long long n, long long s0, long long s1,
-                                                  long long *__restrict__ out, Fault *fault)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long id[4];
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            id[k] = q[i * s0 + k * s1];
-            ok &= (unsigned long long)id[k] < (unsigned long long)P.n_nodes;
-        }
-        if (!ok) {
-            record_fault(fault, id[0], id[1], P.n_nodes);
-            record_fault(fault, id[2], id[3], P.n_nodes);
-#pragma unroll
-            for (int k = 0; k < 4; k++) out[i * 4 + k] = -1;
-            continue;
-        }
-        const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
-        int M[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++)
-            M[j] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)id[pa[j]], (int32_t)id[pb[j]], nullptr, P.rmq, P.n_nodes);
-        int pick = 5;
-#pragma unroll
-        for (int j = 5; j >= 0; j--) {
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) c += M[j] == M[k];
-            if (c == 1) pick = j;
-        }
-        // I[pick] = {pa, pb, the other two in increasing order}
-        const int a = pa[pick], b = pb[pick];
-        int rest[2], r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (k != a && k != b) { if (r < 2) rest[r] = k; r++; }
-        out[i * 4 + 0] = id[a];
-        out[i * 4 + 1] = id[b];
-        out[i * 4 + 2] = id[rest[0]];
-        out[i * 4 + 3] = id[rest[1]];
-    }
-}
-
-// Second half of the quartet path when the MRCA ids came from a canopy launch over
-// SrcQuartet: M[6*i .. 6*i+5] are the ids of quartet i (-1 where an id was out of range).
-__global__ __launch_bounds__(256) void k_quartet_pick(const long long *__restrict__ q, const int *__restrict__ M,
-                                                      long long n, long long *__restrict__ out)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        int m[6];
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 6; j++) { m[j] = M[i * 6 + j]; bad |= m[j] < 0; }
-        long long id[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) id[k] = q[i * 4 + k];
-        if (bad) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) out[i * 4 + k] = -1;
-            continue;
-        }
-        int pick = 5;
-#pragma unroll
-        for (int j = 5; j >= 0; j--) {
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) c += m[j] == m[k];
-            if (c == 1) pick = j;
-        }
-        const int a = (0x940 >> (2 * pick)) & 3, b = (0xFB9 >> (2 * pick)) & 3;
-        int rest[2], r = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (k != a && k != b) { if (r < 2) rest[r] = k; r++; }
-        out[i * 4 + 0] = id[a];
-        out[i * 4 + 1] = id[b];
-        out[i * 4 + 2] = id[rest[0]];
-        out[i * 4 + 3] = id[rest[1]];
-    }
-}
-
-// --------------------------------------------------------------------------
-// canopy kernels
-// --------------------------------------------------------------------------
-struct CanopyParams {
-    const CanopyEntry *canopy;     // [canopy_nodes] global copy, staged to LDS
-    const int32_t *canopy_id;      // [canopy_nodes]
-    const LadderEntry *ladder;     // [canopy_nodes] ladder form (deep canopies), staged to LDS instead of `canopy`
-    const uint16_t *cdepth;        // [canopy_nodes (padded to 8)] canopy depths
-    const uint16_t *cpos;          // [canopy_nodes] rank by node id; NULL unless ids are in-order positions
-    const uint32_t *rmq;           // [levels * canopy_nodes] sparse table of shallowest nodes (tree_prep.h)
-    const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
-    const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
-    const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
-    const uint8_t *rec_p;          // [n_nodes * 8]            {portal rank | depth << 16, lineage offset | chunks << 28}; NULL without lineage sums
-    const uint64_t *rmq64;         // [levels * canopy_nodes] sparse table with node ids (tree_prep.h); in-order ids only
-    const uint32_t *rec_r;         // [n_nodes] portal rank | depth << 16 (MRCA-only queries); in-order ids only
-    const float *lineage;          // lineage sums (tree_prep.h): a's whole side of a pair in one read
-    long long n_nodes;
-    long long n_leaves;
-    int32_t canopy_nodes;
-    int32_t rec_bytes;
-    int32_t parity;                // 1: leaf records first (leaves are the even ids)
-};
-
-constexpr int kCanopyBlock = 1024;
-
-// stage the canopy image into LDS: 16 bytes (two entries) per lane per step, coalesced
-__device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned char *lds_raw)
-{
-    const int n16 = (P.canopy_nodes + 1) / 2;
-    const uint4 *src = reinterpret_cast<const uint4 *>(P.canopy);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-    for (int k = threadIdx.x; k < n16; k += blockDim.x) dst[k] = src[k];
-    __syncthreads();
-}
-
-// One pair, scalar: the record loads and the climb, for a valid pair with record slots sa / sb.
-// CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 is the generic form for records
-// longer than CAP allows in registers, which reads b's chain through a pointer.  LADDER: `image`
-// is the ladder form of the canopy (tree_prep.h), else the plain 8-byte entries.
-// The record reads of one pair: word0 + pbot of a (8 bytes of rec_a), word0 + chain of b (rec_b).
-template <int CAP>
-struct PairRecs {
-    uint32_t wa, wb;
-    float pbot_a;
-    float Db[CAP > 0 ? CAP : 1];
-    const uint8_t *rb;
-    __device__ __forceinline__ const float *chain() const { return CAP > 0 ? Db : reinterpret_cast<const float *>(rb + 4); }
-};
-
-// b's record (L.rb set): word0 + chain
-template <int CAP>
-__device__ __forceinline__ void load_rec_b(PairRecs<CAP> &L)
-{
-    if (CAP == 1) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(L.rb);
-        L.wb = v.x;
-        L.Db[0] = __uint_as_float(v.y);
-    } else if (CAP > 1) {
-        uint32_t w[CAP + 1];
-#pragma unroll
-        for (int q = 0; q < (CAP + 1) / 4; q++) {
-            const uint4 v = reinterpret_cast<const uint4 *>(L.rb)[q];
-            w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-        }
-        L.wb = w[0];
-#pragma unroll
-        for (int q = 0; q < CAP; q++) L.Db[q] = __uint_as_float(w[q + 1]);
-    } else {
-        L.wb = *reinterpret_cast<const uint32_t *>(L.rb);
-        L.Db[0] = 0.0f;
-    }
-}
-
-// b's record (L.rb set), only its first `chunks` 16-byte chunks (the rest of the chain slots are
-// never added: zero).  A lane that does not load a chunk does not cost a cache lookup.
-template <int CAP>
-__device__ __forceinline__ void load_rec_b_chunks(PairRecs<CAP> &L, uint32_t chunks)
-{
-    static_assert(CAP == 0 || CAP == 1 || (CAP + 1) % 4 == 0, "record layout");
-    if (CAP <= 1) {
-        load_rec_b<CAP>(L);
-    } else {
-        uint32_t w[CAP + 1];
-#pragma unroll
-        for (int q = 0; q < (CAP + 1) / 4; q++) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((uint32_t)q < chunks) v = reinterpret_cast<const uint4 *>(L.rb)[q];
-            w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-        }
-        L.wb = w[0];
-#pragma unroll
-        for (int q = 0; q < CAP; q++) L.Db[q] = __uint_as_float(w[q + 1]);
-    }
-}
-
-template <int CAP>
-__device__ __forceinline__ void load_pair_recs(const CanopyParams &P, long long sa, long long sb, int rec_bytes, PairRecs<CAP> &L)
-{
-    L.rb = P.rec_b + sb * (rec_bytes / 2);
-    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-    L.wa = va.x;
-    L.pbot_a = __uint_as_float(va.y);
-    load_rec_b<CAP>(L);
-}
-
-// One pair, scalar, after its record reads: the climb, for a valid pair with record slots sa / sb.
-// CAP = chain slots per record (rec_bytes = 8*(CAP+1)); CAP == 0 is the generic form for records
-// longer than CAP allows in registers, which reads b's chain through a pointer.  LADDER: `image`
-// is the ladder form of the canopy (tree_prep.h), else the plain 8-byte entries.
-template <int CAP, bool LADDER>
-__device__ __forceinline__ PairResult canopy_pair_finish(const CanopyParams &P, const unsigned char *image,
-                                                         const PairRecs<CAP> &L, long long sa, long long sb,
-                                                         int rec_bytes, uint32_t meet)
-{
-    const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
-    if (pa != pb) {
-        if (LADDER) {
-            const LadderEntry *lad = reinterpret_cast<const LadderEntry *>(image);
-            if (meet != 0xFFFFFFFFu)      // meeting node known from the sparse table: only the sums remain
-                return pair_ladder_sums<CAP>(lad, P.canopy_id, meet, pa, P.cdepth[pa], L.pbot_a, pb, P.cdepth[pb], L.chain(), L.wb >> 16);
-            return pair_ladder_split<CAP>(lad, P.cdepth, P.canopy_id, pa, L.pbot_a, pb, L.chain(), L.wb >> 16);
-        }
-        return pair_canopy_split<CAP>(reinterpret_cast<const CanopyEntry *>(image), P.canopy_id, pa, L.pbot_a, pb,
-                                      L.chain(), L.wb >> 16);
-    }
-    const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
-    return pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
-}
-
-template <int CAP, bool LADDER>
-__device__ __forceinline__ PairResult canopy_pair_scalar(const CanopyParams &P, const unsigned char *image,
-                                                         long long sa, long long sb, int rec_bytes,
-                                                         uint32_t meet = 0xFFFFFFFFu)
-{
-    PairRecs<CAP> L;
-    load_pair_recs<CAP>(P, sa, sb, rec_bytes, L);
-    return canopy_pair_finish<CAP, LADDER>(P, image, L, sa, sb, rec_bytes, meet);
-}
-
-// LDS image of the ladder form: canopy_nodes 16-byte entries (the depths stay in global
-// memory: they are read twice per pair, from a table of a few KiB)
-__host__ __device__ inline size_t ladder_image_bytes(int canopy_nodes)
-{
-    return (size_t)canopy_nodes * 16;
-}
-
-__device__ __forceinline__ void stage_ladder(const CanopyParams &P, unsigned char *lds_raw)
-{
-    uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-    const uint4 *src_e = reinterpret_cast<const uint4 *>(P.ladder);
-    for (int k = threadIdx.x; k < P.canopy_nodes; k += blockDim.x) dst[k] = src_e[k];
-    __syncthreads();
-}
-
-// Scalar, branchy kernel (one pair per lane, input order): records longer than 128 bytes and
-// the pairs_per_lane = 0 setting.  (Over the ladder image it measured no faster than the
-// predicated kernel on 2^17-leaf trees -- those are bound by record fetches too -- so the
-// ladder is only used by the tile-sorted kernel.)
-template <int CAP, typename Src>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src, long long n,
-                                                         DistSink out_d,
-                                                         int *__restrict__ out_m, Fault *fault)
-{
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    stage_canopy(P, lds_raw);
-
-    const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-            (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-            record_fault(fault, a, b, P.n_nodes);
-            store_result(out_d, out_m, i, __builtin_nanf(""), -1);
-            continue;
-        }
-        const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
-        const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
-        const PairResult r = canopy_pair_scalar<CAP, false>(P, lds_raw, sa, sb, rec_bytes);
-        store_result(out_d, out_m, i, r.dist, r.mrca);
-    }
-}
-
-// Same computation with PPL pairs in flight per lane.  Every lane carries PPL independent
-// pairs: their pair and record loads are issued together and their canopy climbs advance in
-// the same loop iteration as independent ds_read_b64 (low word = dist bits, high word =
-// parent index).  All updates are predicated selects (a finished climb keeps re-reading its
-// meeting node), so the PPL chains never serialise behind a branch.
-template <int CAP, int PPL, typename Src>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
-                                                             DistSink out_d,
-                                                             int *__restrict__ out_m, Fault *fault)
-{
-    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
-    stage_canopy(P, lds_raw);
-
-    constexpr int rec_bytes = 8 * (CAP + 1);
-    const bool parity = P.parity != 0;
-    const long long tile = (long long)blockDim.x * PPL;
-    for (long long base = (long long)blockIdx.x * tile; base < n; base += (long long)gridDim.x * tile) {
-        long long idx[PPL], sa[PPL], sb[PPL], ida[PPL], idb[PPL];
-        bool live[PPL], valid[PPL];
-        // all PPL pair loads are issued before anything looks at them
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            const long long i = base + (long long)j * blockDim.x + threadIdx.x;
-            live[j] = i < n;
-            idx[j] = live[j] ? i : n - 1;
-            src.load(idx[j], ida[j], idb[j]);
-        }
-        bool any_bad = false;
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            valid[j] = (unsigned long long)ida[j] < (unsigned long long)P.n_nodes &&
-                       (unsigned long long)idb[j] < (unsigned long long)P.n_nodes;
-            any_bad |= !valid[j] && live[j];
-            const long long a = valid[j] ? ida[j] : 0, b = valid[j] ? idb[j] : 0;
-            sa[j] = record_slot(a, parity, P.n_leaves);
-            sb[j] = record_slot(b, parity, P.n_leaves);
-        }
-        if (any_bad) {
-#pragma unroll
-            for (int j = 0; j < PPL; j++)
-                if (!valid[j] && live[j]) record_fault(fault, ida[j], idb[j], P.n_nodes);
-        }
-        uint32_t u[PPL], v[PPL], pa[PPL], pb[PPL], nb[PPL];
-        float s[PPL], Db[PPL][CAP];
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            const uint8_t *rb = P.rec_b + sb[j] * (rec_bytes / 2);
-            const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa[j]];
-            const uint32_t wa = va.x;
-            s[j] = __uint_as_float(va.y);
-            uint32_t wb;
-            if (CAP == 1) {
-                const uint2 q = *reinterpret_cast<const uint2 *>(rb);
-                wb = q.x;
-                Db[j][0] = __uint_as_float(q.y);
-            } else {
-                uint32_t w[CAP + 1];
-#pragma unroll
-                for (int q = 0; q < (CAP + 1) / 4; q++) {
-                    const uint4 x = reinterpret_cast<const uint4 *>(rb)[q];
-                    w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
-                }
-                wb = w[0];
-#pragma unroll
-                for (int q = 0; q < CAP; q++) Db[j][q] = __uint_as_float(w[q + 1]);
-            }
-            u[j] = wa & 0xFFFFu;
-            v[j] = wb & 0xFFFFu;
-            pa[j] = u[j];
-            pb[j] = v[j];
-            nb[j] = wb >> 16;
-        }
-
-        // climb 1: find the meeting node; the a-side sum rides along
-        bool go = false;
-#pragma unroll
-        for (int j = 0; j < PPL; j++) go |= u[j] != v[j];
-        while (go) {
-            go = false;
-#pragma unroll
-            for (int j = 0; j < PPL; j++) {
-                // depth cut inside the canopy: both entries are read every round, the deeper
-                // side moves (both on a tie), so the climb takes max(ka,kb) rounds, not ka+kb
-                const unsigned long long eu = can[u[j]], ev = can[v[j]];
-                const uint32_t lu = (uint32_t)(eu >> 32), lv = (uint32_t)(ev >> 32);
-                const bool act = u[j] != v[j];
-                const bool mu = act && (lu >> 16) >= (lv >> 16);
-                const bool mv = act && (lv >> 16) >= (lu >> 16);
-                const float s_next = s[j] + __uint_as_float((uint32_t)eu);
-                s[j] = mu ? s_next : s[j];
-                u[j] = mu ? (lu & kCanopyParentMask) : u[j];
-                v[j] = mv ? (lv & kCanopyParentMask) : v[j];
-                go |= u[j] != v[j];
-            }
-        }
-        // b's understory, then climb 2 over b's canopy lineage
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-#pragma unroll
-            for (int q = 0; q < CAP; q++) {
-                const float s_next = s[j] + Db[j][q];
-                s[j] = (uint32_t)q < nb[j] ? s_next : s[j];
-            }
-            v[j] = pb[j];
-        }
-        go = false;
-#pragma unroll
-        for (int j = 0; j < PPL; j++) go |= v[j] != u[j];
-        while (go) {
-            go = false;
-#pragma unroll
-            for (int j = 0; j < PPL; j++) {
-                const bool act = v[j] != u[j];
-                const unsigned long long e = can[v[j]];
-                const float s_next = s[j] + __uint_as_float((uint32_t)e);
-                s[j] = act ? s_next : s[j];
-                v[j] = act ? ((uint32_t)(e >> 32) & kCanopyParentMask) : v[j];
-                go |= v[j] != u[j];
-            }
-        }
-        int m[PPL];
-#pragma unroll
-        for (int j = 0; j < PPL; j++) m[j] = P.canopy_id[u[j]];
-        // shared portal (rare for random pairs): the MRCA is the portal or below it
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            if (pa[j] == pb[j]) {
-                const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
-                const PairResult r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
-                s[j] = r.dist;
-                m[j] = r.mrca;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            if (live[j]) {
-                if (valid[j]) store_result(out_d, out_m, idx[j], s[j], m[j]);
-                else store_result(out_d, out_m, idx[j], __builtin_nanf(""), -1);
-            }
-        }
-    }
-}
-
-// MRCA ids only (common_ancestors_bulk, the six pairs of a quartet), trees with in-order ids: the
-// MRCA of two nodes is the shallowest node whose id lies between theirs, and unless both hang
-// below the same portal it is a canopy node -- two 4-byte reads (rank of either portal) and two
-// entries of the 64-bit sparse table (depth << 32 | node id).  No LDS, no understory records:
-// 4.8e10 ids/s on ml.tree where the canopy kernels' MRCA-only mode did 3.0e10.
-template <typename Src>
-__global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, long long n, int *__restrict__ out_m, Fault *fault)
-{
-    const bool parity = P.parity != 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-            record_fault(fault, a, b, P.n_nodes);
-            out_m[i] = -1;
-            continue;
-        }
-        const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-        const uint32_t ra = P.rec_r[sa] & 0xFFFFu, rb = P.rec_r[sb] & 0xFFFFu;
-        if (ra != rb) {
-            out_m[i] = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
-        } else {      // shared portal: the MRCA is the portal or lies in the understory
-            const RecTables R{P.rec_a, P.rec_b, P.rec_i, P.rec_bytes / 2};
-            out_m[i] = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
-        }
-    }
-}
-
-// Tile-sorted ladder form for deep canopies (the default there).  On trees like
-// data/bigtrees/ml.tree a pair's climb is anything from a few to several hundred LDS rounds, so
-// in the kernels above a wave is as slow as its longest lineage and keeps ~30 % of its lanes
-// busy.  Here a workgroup takes a tile of Q * 1024 pairs, computes a work estimate per pair (key
-// phase, input order), counting-sorts the tile by that key in LDS, and hands every wave 64 pairs
-// of similar length (sorted phase): waves, not lanes, differ in run time, and a wave's
-// instructions serve 64 active lanes.  Wave w processes sorted groups w, 31-w (, 32+w, 63-w):
-// short with long, so the waves of a workgroup finish together.  The canopy sits in LDS in its
-// ladder form (tree_prep.h: three edges per 16-byte entry), so a climb of k edges is k/3 LDS reads.
-// Three modes, by what the tree offers (sorted_shape):
-//   lock-step    any node numbering: the key is the depth of the deeper portal; the meeting node
-//                is searched on the ladder (pair_math.h: pair_ladder_split)
-//   sparse table in-order ids: the meeting node of every pair comes from canopy_pos / canopy_rmq
-//                in the key phase (exact key); both sides are then climbed with known counts
-//   lineage sums in-order ids + lineage table (SUMS): a's whole side is one table read in the key
-//                phase, the MRCA id leaves there too; the sorted phase climbs b's edges only and
-//                the distances leave together, coalesced (see below)
-// Not one float addition changes: same operands, same order.
-constexpr int kSortBuckets = 256;
-// LDS scratch of a tile of Q * 1024 pairs: per pair one uint16 (the sorted order), with the
-// sparse table one uint32 (the pair's meeting node; b's edge count in lineage-sum mode), with
-// lineage sums two more words (a's side, later the distance; b's record slot), then the bucket
-// array and the scan carries
-__host__ __device__ constexpr size_t sort_scratch_bytes(int q, bool rmq, bool sums = false)
-{
-    return (size_t)q * kCanopyBlock * (2 + (rmq ? 4 : 0) + (sums ? 8 : 0)) + (size_t)kSortBuckets * 4 + 64;
-}
-
-// SUMS: the lineage-sum mode (a separate instantiation: it needs about 120 VGPRs, the other
-// modes stay below 64, which is what lets two of their workgroups share a CU).
-template <int CAP, int Q, bool SUMS, typename Src>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, Src src, long long n,
-                                                                DistSink out_d, int *__restrict__ out_m,
-                                                                Fault *fault, int key_shift)
-{
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const uint16_t *cdep = P.cdepth;
-    constexpr int kSortTile = Q * kCanopyBlock;
-    stage_ladder(P, lds_raw);
-    unsigned char *scratch = lds_raw + ladder_image_bytes(P.canopy_nodes);
-    const bool have_rmq = P.rmq != nullptr;
-    constexpr bool have_sums = SUMS;
-    uint32_t *HIST = reinterpret_cast<uint32_t *>(scratch);          // [kSortBuckets] counts, then exclusive starts
-    uint32_t *WSUM = HIST + kSortBuckets;                            // [4] scan carries, [4] = pairs to process
-    uint16_t *PERM = reinterpret_cast<uint16_t *>(WSUM + 16);        // [kSortTile] sorted position -> pair of the tile
-    uint32_t *MEET = reinterpret_cast<uint32_t *>(PERM + kSortTile); // [kSortTile] meeting node (depth << 16 | index), sparse-table mode; b's edge count, lineage-sum mode
-    float *SIDE_A = reinterpret_cast<float *>(MEET + kSortTile);     // [kSortTile] a's side of the pair, then its distance (lineage-sum mode)
-    uint32_t *SLOT_B = reinterpret_cast<uint32_t *>(SIDE_A + kSortTile);   // [kSortTile] b's record slot | chunks of its record that matter << 28 (lineage-sum mode)
-
-    const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
-    const int half = rec_bytes / 2;
-    const bool parity = P.parity != 0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long long base = (long long)blockIdx.x * kSortTile; base < n; base += (long long)gridDim.x * kSortTile) {
-        if (threadIdx.x < kSortBuckets) HIST[threadIdx.x] = 0;
-        __syncthreads();
-        // keys, in units of 2^key_shift levels: the canopy edges the pair will climb (its meeting
-        // node comes out of the sparse table right here), or -- ids not in order, no table -- the
-        // depth of its deeper portal
-        uint32_t key[Q], rank[Q];
-        if constexpr (have_sums) {
-            // Lineage-sum mode.  rec_p of either node = {rank of its portal | its depth << 16, offset
-            // of its lineage sums | record chunks << 28}: the meeting node (depth << 32 | node id)
-            // comes from the two ranks, a's whole side is one table read, and the sorted phase only
-            // climbs b's edges.  The gathers of the lane's Q pairs are issued level by level --
-            // pairs, records, sparse table, lineage sums -- without branches in between, so that
-            // all Q chains are in flight together (written pair by pair, each chain waited for the
-            // one before).  What the sorted phase needs besides b's record stays in LDS: b's edges
-            // below the meeting node, a's side, b's slot.
-            long long a_[Q], b_[Q];
-            bool in_[Q], valid_[Q];
-            uint2 va_[Q], vb_[Q];
-            uint64_t e1_[Q], e2_[Q];
-            float side_[Q];
-            const bool want_d = out_d.any();
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const long long i = base + (int)threadIdx.x + q * kCanopyBlock;
-                in_[q] = i < n;
-                a_[q] = 0;
-                b_[q] = 0;
-                if (in_[q]) src.load(i, a_[q], b_[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                valid_[q] = (unsigned long long)a_[q] < (unsigned long long)P.n_nodes &&
-                            (unsigned long long)b_[q] < (unsigned long long)P.n_nodes;
-                const long long sa = record_slot(valid_[q] ? a_[q] : 0, parity, P.n_leaves);
-                const long long sb = record_slot(valid_[q] ? b_[q] : 0, parity, P.n_leaves);
-                va_[q] = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
-                vb_[q] = reinterpret_cast<const uint2 *>(P.rec_p)[sb];
-            }
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const uint32_t ra = va_[q].x & 0xFFFFu, rb = vb_[q].x & 0xFFFFu;
-                const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
-                const uint32_t len = r - l + 1;
-                const uint32_t k = 31u - (uint32_t)__clz((int)len);      // floor(log2(len))
-                e1_[q] = P.rmq64[(size_t)k * (size_t)P.canopy_nodes + l];
-                e2_[q] = P.rmq64[(size_t)k * (size_t)P.canopy_nodes + (r + 1 - (1u << k))];
-            }
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                e1_[q] = (e2_[q] >> 32) < (e1_[q] >> 32) ? e2_[q] : e1_[q];     // the meeting node
-                side_[q] = 0.0f;
-                if (want_d)
-                    side_[q] = P.lineage[(size_t)(va_[q].y & 0x0FFFFFFFu) + ((va_[q].x >> 16) - (uint32_t)(e1_[q] >> 32))];
-            }
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const int j = (int)threadIdx.x + q * kCanopyBlock;
-                const long long i = base + j;
-                key[q] = 0xFFFFFFFFu;
-                rank[q] = 0;
-                if (!in_[q]) continue;
-                if (!valid_[q]) {
-                    record_fault(fault, a_[q], b_[q], P.n_nodes);
-                    SIDE_A[j] = __builtin_nanf("");      // (the distances of the tile leave LDS together, below)
-                    if (out_m) out_m[i] = -1;
-                    continue;
-                }
-                uint32_t k = 0;
-                if ((va_[q].x & 0xFFFFu) == (vb_[q].x & 0xFFFFu)) {     // shared portal: left to the general form
-                    MEET[j] = 0xFFFFFFFFu;
-                } else {
-                    // the MRCA id is known here and leaves at once, coalesced
-                    if (out_m) out_m[i] = (int)(uint32_t)e1_[q];
-                    if (!want_d) continue;      // MRCA ids only: this pair is done
-                    const uint32_t kb = (vb_[q].x >> 16) - (uint32_t)(e1_[q] >> 32);
-                    MEET[j] = kb;
-                    SIDE_A[j] = side_[q];
-                    SLOT_B[j] = (uint32_t)record_slot(b_[q], parity, P.n_leaves) | (vb_[q].y & 0xF0000000u);   // (+ how many 16-byte chunks of b's record matter)
-                    k = kb >> key_shift;
-                }
-                key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
-                rank[q] = atomicAdd(&HIST[key[q]], 1u);
-            }
-        } else {
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int j = (int)threadIdx.x + q * kCanopyBlock;
-            const long long i = base + j;
-            key[q] = 0xFFFFFFFFu;
-            rank[q] = 0;
-            if (i < n) {
-                long long a, b;
-                src.load(i, a, b);
-                if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-                    (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-                    record_fault(fault, a, b, P.n_nodes);
-                    store_result(out_d, out_m, i, __builtin_nanf(""), -1);
-                } else {
-                    const long long sa = record_slot(a, parity, P.n_leaves);
-                    const long long sb = record_slot(b, parity, P.n_leaves);
-                    uint32_t k;
-                    const uint32_t pa = *reinterpret_cast<const uint32_t *>(P.rec_a + sa * 8) & 0xFFFFu;
-                    const uint32_t pb = *reinterpret_cast<const uint32_t *>(P.rec_b + sb * half) & 0xFFFFu;
-                    const uint32_t da = cdep[pa], db = cdep[pb];
-                    if (have_rmq) {
-                        const uint32_t meet = canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb);
-                        MEET[j] = meet;
-                        k = (da + db - 2 * (meet >> 16)) >> key_shift;
-                    } else {
-                        k = (2 * (da > db ? da : db)) >> key_shift;
-                    }
-                    key[q] = k < (uint32_t)kSortBuckets - 1 ? k : (uint32_t)kSortBuckets - 1;
-                    rank[q] = atomicAdd(&HIST[key[q]], 1u);
-                }
-            }
-        }
-        }
-        __syncthreads();
-        // exclusive scan of the 256 bucket counts (4 waves of 64)
-        uint32_t cnt = 0, incl = 0;
-        if (threadIdx.x < kSortBuckets) {
-            cnt = HIST[threadIdx.x];
-            incl = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off);
-                if (lane >= off) incl += up;
-            }
-            if (lane == 63) WSUM[wave] = incl;
-        }
-        __syncthreads();
-        if (threadIdx.x < kSortBuckets) {
-            uint32_t carry = 0;
-            for (int w = 0; w < wave; w++) carry += WSUM[w];
-            HIST[threadIdx.x] = carry + incl - cnt;
-            if (threadIdx.x == kSortBuckets - 1) WSUM[4] = carry + incl;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-            if (key[q] != 0xFFFFFFFFu) PERM[HIST[key[q]] + rank[q]] = (uint16_t)((int)threadIdx.x + q * kCanopyBlock);
-        __syncthreads();
-        const uint32_t total = WSUM[4];
-        // wave w: sorted groups w, 31 - w, 32 + w, 63 - w (short pairs with long pairs)
-        if constexpr (have_sums) {
-            // lineage-sum mode: per pair one global read is left (b's record), issued one
-            // group ahead of the climb that uses it
-            int jq[Q];
-            bool ok[Q];
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
-                ok[q] = pos < total;
-                jq[q] = ok[q] ? (int)PERM[pos] : 0;
-            }
-            PairRecs<CAP> cur, nxt;
-            auto fetch = [&](PairRecs<CAP> &L, int q) {
-                const uint32_t w = ok[q] && MEET[jq[q]] != 0xFFFFFFFFu ? SLOT_B[jq[q]] : 0u;
-                L.rb = P.rec_b + (long long)(w & 0x0FFFFFFFu) * half;
-                if (ok[q] && MEET[jq[q]] != 0xFFFFFFFFu) load_rec_b_chunks<CAP>(L, (w >> 28) + 1);
-            };
-            fetch(cur, 0);
-#pragma unroll
-            for (int q = 0; q < Q; q++) {
-                if (q + 1 < Q) fetch(nxt, q + 1);
-                if (ok[q]) {
-                    const int j = jq[q];
-                    const uint32_t kb = MEET[j];
-                    float dist;
-                    if (kb != 0xFFFFFFFFu) {
-                        dist = ladder_sum_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), kb - (cur.wb >> 16), SIDE_A[j],
-                                                 cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
-                    } else {     // shared portal
-                        long long a, b;
-                        src.load(base + j, a, b);
-                        const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
-                                                                           record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
-                        dist = r.dist;
-                        if (out_m) out_m[base + j] = r.mrca;
-                    }
-                    SIDE_A[j] = dist;      // the pair's scratch word has served: its distance waits there
-                }
-                if (q + 1 < Q) cur = nxt;
-            }
-            // distances leave in input order, coalesced (scattered stores straight from the sorted
-            // phase cost a cache lookup per lane and wrote every output line several times)
-            __syncthreads();
-            if (out_d.any()) {
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    const int j = (int)threadIdx.x + q * kCanopyBlock;
-                    if (base + j < n) store_result(out_d, nullptr, base + j, SIDE_A[j], 0);
-                }
-            }
-        } else {
-#pragma unroll 1
-            for (int q = 0; q < Q; q++) {
-                const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
-                if (pos >= total) continue;
-                const int j = PERM[pos];
-                long long a, b;
-                src.load(base + j, a, b);     // (the tile was read a moment ago: an L2 hit; validated then)
-                const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-                const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes, have_rmq ? MEET[j] : 0xFFFFFFFFu);
-                store_result(out_d, out_m, base + j, r.dist, r.mrca);
-            }
-        }
-        __syncthreads();     // the next tile overwrites PERM and MEET
-    }
-}
-
-// ---- k nearest candidates per query row (nearest_neighbors, MuchTree.pyx:1032-1082) ----------
-// dist[row * n_c + c] are the float32 distances query(row) -> cands[c].  One workgroup per row
-// selects the k smallest in k rounds: round r finds the smallest key greater than the one
-// chosen in round r-1, key = (order-preserving image of the float) << 32 | candidate index, so
-// ties resolve to the lower candidate index (the reference's argsort leaves tie order
-// unspecified).  O(k * n_c) per row, for small k; the facade sorts on the host beyond kKnnMaxK.
-constexpr int kKnnMaxK = 256;
-
-__device__ __forceinline__ unsigned long long knn_key(float d, unsigned idx)
-{
-    unsigned u = __float_as_uint(d);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)u << 32) | idx;
-}
-
-__global__ __launch_bounds__(256) void k_knn_select(const float *__restrict__ dist, long long n_c,
-                                                    const long long *__restrict__ queries,
-                                                    const long long *__restrict__ cands, int skip_self, int k,
-                                                    long long *__restrict__ out_index, double *__restrict__ out_dist)
-{
-    __shared__ unsigned long long wave_min[4];
-    __shared__ unsigned long long chosen;
-    const long long row = blockIdx.x;
-    const float *d = dist + row * n_c;
-    const long long q = queries[row];
-    unsigned long long prev = 0;
-    bool first = true;
-    for (int r = 0; r < k; r++) {
-        unsigned long long best = ~0ull;
-        for (long long c = threadIdx.x; c < n_c; c += blockDim.x) {
-            if (skip_self && cands[c] == q) continue;
-            const unsigned long long key = knn_key(d[c], (unsigned)c);
-            if ((first || key > prev) && key < best) best = key;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long other = __shfl_xor(best, off);
-            best = other < best ? other : best;
-        }
-        if ((threadIdx.x & 63) == 0) wave_min[threadIdx.x >> 6] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long m = wave_min[0];
-            for (int w = 1; w < 4; w++) m = wave_min[w] < m ? wave_min[w] : m;
-            chosen = m;
-            const long long c = (long long)(m & 0xFFFFFFFFull);
-            const bool found = m != ~0ull;
-            out_index[row * k + r] = found ? c : -1;
-            out_dist[row * k + r] = found ? (double)d[c] : __builtin_nan("");
-        }
-        __syncthreads();
-        prev = chosen;
-        first = false;
-        if (prev == ~0ull) {     // fewer than k candidates: the remaining slots stay -1 / NaN
-            for (int rr = r + 1 + (int)threadIdx.x; rr < k; rr += blockDim.x) {
-                out_index[row * k + rr] = -1;
-                out_dist[row * k + rr] = __builtin_nan("");
-            }
-            break;
-        }
-        __syncthreads();
-    }
-}
-
-// ---- dense graph matrices of SuchLinkedTrees (adjacency / Laplacian, MuchTree.pyx:3081-3145)
-// A[u][v] = A[v][u] = w for every edge; L = diag(column sums of A) - A.  The column sums run
-// over the rows in increasing order, like numpy's sum(axis=0), so L is bit-identical to the
-// host formula.
-__global__ void k_graph_scatter(double *__restrict__ A, long long n, long long n_edges,
-                                const int *__restrict__ u, const int *__restrict__ v,
-                                const double *__restrict__ w)
-{
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
-         e += (long long)gridDim.x * blockDim.x) {
-        A[(long long)u[e] * n + v[e]] = w[e];
-        A[(long long)v[e] * n + u[e]] = w[e];
-    }
-}
-
-__global__ void k_graph_degree(const double *__restrict__ A, long long n, double *__restrict__ deg)
-{
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += (long long)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (long long i = 0; i < n; i++) s += A[i * n + j];   // lanes read consecutive columns: coalesced
-        deg[j] = s;
-    }
-}
-
-__global__ void k_graph_laplacian(const double *__restrict__ A, const double *__restrict__ deg, long long n,
-                                  double *__restrict__ L)
-{
-    const long long total = n * n;
-    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total;
-         k += (long long)gridDim.x * blockDim.x) {
-        const long long i = k / n, j = k - i * n;
-        L[k] = (i == j ? deg[j] : 0.0) - A[k];
-    }
-}
-
 }  // namespace st
+
+#include "device_common.h"
+#include "kernels_walk.h"
+#include "kernels_canopy.h"
+#include "kernels_misc.h"
+
 
 // --------------------------------------------------------------------------
 // host side: the tree handle
