@@ -21,6 +21,8 @@ HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
            os.path.join(CSRC, "host_pipe.h"), os.path.join(CSRC, "host_copy.h"),
            os.path.join(CSRC, "device_common.h"), os.path.join(CSRC, "kernels_walk.h"),
            os.path.join(CSRC, "kernels_canopy.h"), os.path.join(CSRC, "kernels_misc.h"),
+           os.path.join(CSRC, "host_tree.h"), os.path.join(CSRC, "host_launch.h"),
+           os.path.join(CSRC, "host_path.h"), os.path.join(CSRC, "host_upload.h"),
            os.path.join(HERE, "..", "include", "suchtree_hip.h")]
 
 FLAGS = [

@@ -1,0 +1,133 @@
+// host_upload.h -- part of libsuchtree_hip.so's single translation unit (included by suchtree_hip.hip after
+// the kernels, in this order: host_tree.h, host_launch.h, host_path.h, host_upload.h).
+// Table construction (tree_prep.cpp) and upload of a tree to one device.
+#pragma once
+
+// Tables are built once on the host, then uploaded to every device of the handle.
+struct BuiltTables {
+    TreeTables T;
+    bool canopy_ok = false;
+    bool deep = false;
+};
+
+static int build_tables(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
+{
+    std::string err;
+    if (!prepare_basic(parent, distance, n_nodes, B.T, err)) return fail(ST_ERR_TREE, err);
+    int max_canopy = 0;
+    if (const char *env = std::getenv("SUCHTREE_AMD_CANOPY_NODES")) max_canopy = std::atoi(env);   // tuning experiments
+    if (strategy != ST_STRATEGY_WALK) {
+        B.canopy_ok = prepare_canopy(parent, distance, B.T, max_canopy);
+        // Deep canopies (real, unbalanced phylogenies: hundreds of levels) spend their time in
+        // the LDS climb, not in memory.  There a canopy image small enough for two workgroups
+        // per CU, a longer understory (more of each lineage pre-summed in its record) and the
+        // branchy scalar kernel (finished lanes stop issuing LDS reads) measured 13-30 % faster.
+        if (B.canopy_ok && max_canopy == 0) {
+            int cdepth = 0;
+            for (const CanopyEntry &e : B.T.canopy) cdepth = std::max<int>(cdepth, (int)(e.link >> 16));
+            if (cdepth > kDeepCanopyDepth) {
+                B.deep = true;
+                int deep_nodes = kDeepCanopyNodes;
+                if (const char *env = std::getenv("SUCHTREE_AMD_DEEP_NODES")) deep_nodes = std::atoi(env);   // tuning experiments
+                if (B.T.canopy_nodes > deep_nodes) {
+                    TreeTables T2 = B.T;
+                    if (prepare_canopy(parent, distance, T2, deep_nodes)) B.T = std::move(T2);
+                }
+                // a's side of every pair from one read (tree_prep.h: lineage sums); 4 bytes per
+                // node and level, so only while the table stays below kMaxLineageEntries
+                (void)prepare_lineage_sums(B.T, kMaxLineageEntries);
+            }
+        }
+    }
+    if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
+    if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
+        return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
+    return ST_OK;
+}
+
+static int upload_tree(BuiltTables &B, int device, st_tree **out)
+{
+    TreeTables &T = B.T;
+    int n_dev = 0;
+    ST_HIP(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev)
+        return fail(ST_ERR_HIP, "device " + std::to_string(device) + " not available (" +
+                                    std::to_string(n_dev) + " visible)");
+    ST_DEVICE(device);
+    hipDeviceProp_t prop;
+    ST_HIP(hipGetDeviceProperties(&prop, device));
+
+    st_tree *t = new (std::nothrow) st_tree();
+    if (!t) return fail(ST_ERR_NOMEM, "out of host memory");
+    t->device = device;
+    t->dp = pipe_acquire(device);
+    t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    t->n_nodes = T.n;
+    t->n_leaves = T.n_leaves;
+    if (B.deep) { t->pairs_per_lane = 0; t->tile_sort = 1; }
+    int64_t bytes = 0;
+    int rc = upload(&t->d_nodes, T.nodes, &bytes);
+    if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
+    if (rc == ST_OK) rc = upload(&t->d_stride, T.stride, &bytes);
+    if (rc == ST_OK && !T.tree_rmq.empty()) rc = upload(&t->d_tree_rmq, T.tree_rmq, &bytes);
+    if (rc == ST_OK && B.canopy_ok) {
+        t->has_canopy = true;
+        t->canopy_nodes = T.canopy_nodes;
+        t->rec_bytes = T.record_bytes;
+        t->rec_cap = T.record_cap;
+        t->parity = T.parity_layout ? 1 : 0;
+        for (const CanopyEntry &e : T.canopy) t->canopy_depth = std::max<int>(t->canopy_depth, (int)(e.link >> 16));
+        std::vector<CanopyEntry> image = T.canopy;
+        if (image.size() & 1) image.push_back(CanopyEntry{0.0f, 0u});   // 16-byte staging granule
+        rc = upload(&t->d_canopy, image, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_canopy_id, T.canopy_id, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_ladder, T.ladder, &bytes);
+        if (rc == ST_OK) {
+            std::vector<uint16_t> cd = T.canopy_depth;
+            cd.resize((cd.size() + 7) / 8 * 8, 0);     // 16-byte staging granule
+            rc = upload(&t->d_cdepth, cd, &bytes);
+        }
+        if (rc == ST_OK && B.deep && T.inorder_ids && !T.canopy_rmq.empty()) {
+            rc = upload(&t->d_cpos, T.canopy_pos, &bytes);
+            if (rc == ST_OK) rc = upload(&t->d_rmq, T.canopy_rmq, &bytes);
+        }
+        if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
+        if (rc == ST_OK && !T.rec_r.empty()) {
+            rc = upload(&t->d_rec_r, T.rec_r, &bytes);
+            if (rc == ST_OK) rc = upload(&t->d_rmq64, T.canopy_rmq64, &bytes);
+        }
+        if (rc == ST_OK && t->d_rmq && t->d_rmq64 && !T.lineage_sum.empty()) {
+            rc = upload(&t->d_rec_p, T.rec_p, &bytes);
+            if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
+        }
+    }
+    if (rc == ST_OK) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_fault), 2 * sizeof(Fault));
+        const Fault init2[2] = {kFaultInit, kFaultInit};
+        if (e == hipSuccess) e = hipMemcpy(t->d_fault, init2, sizeof(init2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
+        else t->d_fault_host = t->d_fault + 1;
+    }
+    if (rc != ST_OK) {
+        std::string keep = g_last_error;
+        st_tree_destroy(t);
+        g_last_error = keep;
+        return rc;
+    }
+    t->strategy = B.canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
+    t->info.n_nodes = T.n;
+    t->info.n_leaves = T.n_leaves;
+    t->info.root = T.root;
+    t->info.depth = T.tree_depth;
+    t->info.device = device;
+    t->info.canopy_nodes = B.canopy_ok ? T.canopy_nodes : 0;
+    t->info.understory_max = B.canopy_ok ? T.understory_max : 0;
+    t->info.record_bytes = B.canopy_ok ? T.record_bytes : 0;
+    t->info.n_devices = 1;
+    t->info.device_bytes = bytes;
+    t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
+    *out = t;
+    return ST_OK;
+}
