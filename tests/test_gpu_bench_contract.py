@@ -35,7 +35,8 @@ def test_bench_line_contract():
     assert r["required_bytes_per_pair"] == 156 and 0 < r["required_frac"] < 1
     assert d["hardware_measured"]["table"]["Greads_per_s"] > 1 and d["hardware_measured"]["stream_copy_GBps"] > 100
     e = d["end_to_end_host_path"]
-    assert e["pairs_per_s"] > 1e8 and e["pairs_per_s_fresh_arrays"] > 1e8
+    assert e["pairs_per_s"] > 1e8 and e["pairs_per_s_fresh_arrays"] > 1e8 and e["pairs_per_s_call_and_drop_loop"] > 1e8
+    assert d["mrca_ids_only"]["matches_the_fused_launch"] and d["mrca_ids_only"]["ids_per_s"] > 1e9
 
 
 def test_bench_under_torchrun_one_rank():
