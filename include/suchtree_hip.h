@@ -229,6 +229,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * form (default for deep canopies).
  * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
  * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
+ * "tree_rmq": 1 (default) = the walk family takes the meeting node from the whole-tree sparse table
+ * where the tree has one (in-order ids; up to 64 MB, up to 4 GiB when the canopy family is not
+ * available); 0 = it searches it by climbing both lineages.
  * "mrca_ranks": 1 (default) = MRCA-only requests on trees with in-order ids are answered from a
  * per-node rank table and a sparse table over the canopy (no LDS, no understory records);
  * 0 = they go through the distance kernels.

@@ -199,10 +199,11 @@ static WalkParams walk_params(const st_tree *t)
     P.nodes = t->d_nodes;
     P.depth = t->d_depth;
     P.stride = t->d_stride;
-    P.rmq = t->d_tree_rmq;
+    P.rmq = t->tree_rmq ? t->d_tree_rmq : nullptr;
     P.n_nodes = t->n_nodes;
     if (t->d_lineage && t->lineage_sums) {
         P.lineage.rec_p = t->d_rec_p;
+        P.lineage.node_off = t->d_lineage_node_off;
         P.lineage.sums = t->d_lineage;
         P.lineage.n_leaves = t->n_leaves;
         P.lineage.parity = t->parity != 0;

@@ -17,6 +17,7 @@ constexpr int64_t kHostChunk = (int64_t)1 << 22;      // most pairs per pipeline
 constexpr int64_t kHostChunkMin = (int64_t)1 << 18;   // fewest, when a batch is dealt over several GPUs
 constexpr int kDeepCanopyDepth = 100;     // canopies deeper than this (edges) are "deep"
 constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
+constexpr int64_t kMaxWalkLineageEntries = (int64_t)1 << 30;   // 4 GiB of lineage sums at most on trees the canopy family refuses
 constexpr int64_t kMaxLineageEntries = (int64_t)1 << 28;   // 1 GiB of lineage sums at most (ml.tree: 48 MB)
 constexpr int64_t kMailboxPairs = 8192;   // largest batch served through the mailbox (beyond it the staged pipe's fixed ~60 us pay off)
 

@@ -56,6 +56,7 @@ struct st_tree {
     uint64_t *d_rmq64 = nullptr;
     uint32_t *d_rec_r = nullptr;      // MRCA-only queries (in-order ids), else NULL
     float *d_lineage = nullptr;
+    uint32_t *d_lineage_node_off = nullptr;   // walk-only trees: lineage offsets by node id
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the
     // device pipe's mutex) and is never confused by a caller who skipped st_fault_check
@@ -67,6 +68,7 @@ struct st_tree {
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
+    int tree_rmq = 1;         // tuning: 0 = the walk family searches the meeting node by climbing even when the whole-tree sparse table exists
     int mrca_ranks = 1;       // tuning: 0 = MRCA-only requests go through the distance kernels
     int lineage_sums = 1;     // tuning: 0 = the tile-sorted kernel climbs a's canopy lineage even when the lineage-sum table exists
     LadderEntry *d_ladder = nullptr;

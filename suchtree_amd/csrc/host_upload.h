@@ -40,6 +40,12 @@ static int build_tables(const int32_t *parent, const float *distance, int64_t n_
         }
     }
     if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
+    // a tree that only the walk family serves (canopy refused, or asked for) gets the whole-tree
+    // sparse table up to 4 GiB: the meeting node in two reads instead of a lock-step climb of both
+    // lineages matters most exactly there (large, deep trees)
+    if (!B.canopy_ok && B.T.tree_rmq.empty()) (void)build_tree_rmq(B.T, kMaxTreeRmqBytesWalkOnly);
+    // ... and lineage sums (a's side of a pair in one read; offsets by node id), up to 4 GiB
+    if (!B.canopy_ok) (void)prepare_walk_lineage(B.T, kMaxWalkLineageEntries);
     if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
         return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
     return ST_OK;
@@ -70,6 +76,10 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_stride, T.stride, &bytes);
     if (rc == ST_OK && !T.tree_rmq.empty()) rc = upload(&t->d_tree_rmq, T.tree_rmq, &bytes);
+    if (rc == ST_OK && !B.canopy_ok && !T.lineage_node_off.empty()) {
+        rc = upload(&t->d_lineage_node_off, T.lineage_node_off, &bytes);
+        if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
+    }
     if (rc == ST_OK && B.canopy_ok) {
         t->has_canopy = true;
         t->canopy_nodes = T.canopy_nodes;

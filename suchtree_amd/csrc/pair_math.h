@@ -83,6 +83,7 @@ ST_HD float walk_sum(const Stride3 *__restrict__ stride, float s, int32_t u, int
 // second word of rec_p at a's record slot.
 struct LineageView {
     const uint8_t *rec_p = nullptr;
+    const uint32_t *node_off = nullptr;   // walk-only trees: offsets by node id instead of rec_p
     const float *sums = nullptr;
     int64_t n_leaves = 0;
     bool parity = false;
@@ -98,8 +99,11 @@ ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__res
     const int32_t m = pair_walk_mrca(nodes, depth, stride, a, b, &dm, rmq, n_nodes);
     float s;
     if (lin.sums) {
-        const uint32_t off = *reinterpret_cast<const uint32_t *>(lin.rec_p + record_slot(a, lin.parity, lin.n_leaves) * 8 + 4);
-        s = lin.sums[(size_t)(off & 0x0FFFFFFFu) + (size_t)(da - dm)];     // (the top 4 bits of the word are a chunk count)
+        size_t off;
+        if (lin.node_off) off = lin.node_off[a];
+        else      // (rec_p: the top 4 bits of the word are a chunk count)
+            off = *reinterpret_cast<const uint32_t *>(lin.rec_p + record_slot(a, lin.parity, lin.n_leaves) * 8 + 4) & 0x0FFFFFFFu;
+        s = lin.sums[off + (size_t)(da - dm)];
     } else {
         s = walk_sum(stride, 0.0f, a, da - dm);
     }

@@ -253,6 +253,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_rmq64);
         (void)hipFree(t->d_rec_r);
         (void)hipFree(t->d_lineage);
+        (void)hipFree(t->d_lineage_node_off);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
@@ -305,6 +306,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "tile_sort") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tile_sort must be 0 or 1");
         t->tile_sort = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "tree_rmq") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tree_rmq must be 0 or 1");
+        t->tree_rmq = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "mrca_ranks") == 0) {

@@ -3,10 +3,36 @@
 // accumulates (/root/reference/SuchTree/MuchTree.pyx:922,934-938).
 #include "tree_prep.h"
 
+#include <thread>
+
 #include <algorithm>
 #include <cstring>
 
 namespace st {
+
+bool build_tree_rmq(TreeTables &T, int64_t max_bytes)
+{
+    T.tree_rmq.clear();
+    T.tree_rmq_levels = 0;
+    if (!T.inorder_ids) return false;
+    const int64_t n = T.n;
+    int32_t levels = 1;
+    while (((int64_t)1 << levels) <= n) levels++;
+    if ((int64_t)levels * n * 8 > max_bytes) return false;
+    T.tree_rmq_levels = levels;
+    T.tree_rmq.resize((size_t)levels * (size_t)n);
+    for (int64_t i = 0; i < n; i++) T.tree_rmq[(size_t)i] = ((uint64_t)(uint32_t)T.depth[(size_t)i] << 32) | (uint64_t)(uint32_t)i;
+    for (int32_t k = 1; k < levels; k++) {
+        const uint64_t *lo = T.tree_rmq.data() + (size_t)(k - 1) * (size_t)n;
+        uint64_t *cur = T.tree_rmq.data() + (size_t)k * (size_t)n;
+        const int64_t half = (int64_t)1 << (k - 1);
+        for (int64_t i = 0; i < n; i++) {
+            const uint64_t a = lo[i], b = i + half < n ? lo[i + half] : a;
+            cur[i] = b < a ? b : a;        // depth in the high word: the shallower entry is the smaller
+        }
+    }
+    return true;
+}
 
 bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
                    TreeTables &T, std::string &err)
@@ -84,26 +110,7 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
         }
         T.inorder_ids = ok;
     }
-    T.tree_rmq.clear();
-    T.tree_rmq_levels = 0;
-    if (T.inorder_ids) {
-        int32_t levels = 1;
-        while (((int64_t)1 << levels) <= n) levels++;
-        if ((int64_t)levels * n * 8 <= kMaxTreeRmqBytes) {
-            T.tree_rmq_levels = levels;
-            T.tree_rmq.resize((size_t)levels * (size_t)n);
-            for (int64_t i = 0; i < n; i++) T.tree_rmq[(size_t)i] = ((uint64_t)(uint32_t)T.depth[(size_t)i] << 32) | (uint64_t)(uint32_t)i;
-            for (int32_t k = 1; k < levels; k++) {
-                const uint64_t *lo = T.tree_rmq.data() + (size_t)(k - 1) * (size_t)n;
-                uint64_t *cur = T.tree_rmq.data() + (size_t)k * (size_t)n;
-                const int64_t half = (int64_t)1 << (k - 1);
-                for (int64_t i = 0; i < n; i++) {
-                    const uint64_t a = lo[i], b = i + half < n ? lo[i + half] : a;
-                    cur[i] = b < a ? b : a;        // depth in the high word: the shallower entry is the smaller
-                }
-            }
-        }
-    }
+    build_tree_rmq(T, kMaxTreeRmqBytes);
     T.tree_depth = max_leaf_depth + 1;   // MuchTree.pyx:218-225 counts nodes
 
     T.nodes.resize((size_t)n);
@@ -338,6 +345,59 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
             v = T.nodes[(size_t)v].parent;
         }
         off += (int64_t)k_max + 1;
+    }
+    return true;
+}
+
+bool prepare_walk_lineage(TreeTables &T, int64_t max_entries)
+{
+    T.lineage_sum.clear();
+    T.lineage_node_off.clear();
+    const int64_t n = T.n;
+    int64_t entries = 0;
+    for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
+    if (entries > max_entries || entries >= ((int64_t)1 << 32)) return false;
+    T.lineage_node_off.resize((size_t)n);
+    int64_t off = 0;
+    for (int64_t x = 0; x < n; x++) {
+        T.lineage_node_off[(size_t)x] = (uint32_t)off;
+        off += (int64_t)T.depth[(size_t)x] + 1;
+    }
+    T.lineage_sum.resize((size_t)entries);
+    auto fill = [&](int64_t lo, int64_t hi) {
+        for (int64_t x = lo; x < hi; x++) {
+            // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
+            volatile float acc = 0.0f;
+            float *dst = T.lineage_sum.data() + T.lineage_node_off[(size_t)x];
+            int32_t v = (int32_t)x;
+            const int32_t k_max = T.depth[(size_t)x];
+            dst[0] = 0.0f;
+            for (int32_t k = 1; k <= k_max; k++) {
+                acc = acc + T.nodes[(size_t)v].dist;
+                dst[k] = acc;
+                v = T.nodes[(size_t)v].parent;
+            }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 32), entries >> 22));
+    if (n_threads <= 1) {
+        fill(0, n);
+    } else {
+        // ranges of equal table size, not equal node count (depths differ)
+        std::vector<std::thread> threads;
+        int64_t lo = 0;
+        for (int t = 1; t <= n_threads; t++) {
+            int64_t hi = n;
+            if (t < n_threads) {
+                const uint32_t want = (uint32_t)((uint64_t)entries * (uint64_t)t / (uint64_t)n_threads);
+                hi = std::lower_bound(T.lineage_node_off.begin(), T.lineage_node_off.end(), want) - T.lineage_node_off.begin();
+                if (hi < lo) hi = lo;
+            }
+            threads.emplace_back(fill, lo, hi);
+            lo = hi;
+        }
+        for (auto &th : threads) th.join();
     }
     return true;
 }

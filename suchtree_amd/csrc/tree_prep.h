@@ -78,6 +78,7 @@ constexpr int kMaxCanopyNodes = 16384;   // 16384 * 8 B = 128 KiB of the 160 KiB
 constexpr int kMaxRecordBytes = 512;
 constexpr int kMinRecordBytes = 16;
 constexpr int64_t kMaxTreeRmqBytes = (int64_t)64 << 20;   // whole-tree sparse table: trees of up to ~450k nodes
+constexpr int64_t kMaxTreeRmqBytesWalkOnly = (int64_t)4 << 30;   // ... up to ~20M nodes when the walk family is all a tree has
 inline int record_cap_for(int rec_bytes) { return rec_bytes / 8 - 1; }
 
 struct TreeTables {
@@ -140,6 +141,9 @@ struct TreeTables {
     // understory records or LDS: two 4-byte reads and two table entries per pair
     // (prepare_rank_table; in-order ids).
     std::vector<uint32_t> rec_r;        // [n], slot order, or empty
+    // Trees that only the walk family serves (prepare_walk_lineage): the same lineage sums,
+    // offsets by node id (no records there to carry them).
+    std::vector<uint32_t> lineage_node_off;   // [n] or empty
 };
 
 // Record slot of node id x.  With the parity layout leaf records come first
@@ -148,6 +152,10 @@ ST_HD int64_t record_slot(int64_t x, bool parity, int64_t n_leaves) {
     return parity ? ((x & 1) ? n_leaves + (x >> 1) : (x >> 1)) : x;
 }
 
+// (Re)builds the whole-tree sparse table if ids are in-order and it stays within max_bytes
+// (prepare_basic calls it with kMaxTreeRmqBytes).  Needs depth and inorder_ids.
+bool build_tree_rmq(TreeTables &T, int64_t max_bytes);
+
 // Validates the parent array and fills nodes/depth; returns false with `err`
 // set when it is not a single rooted tree.
 bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
@@ -155,6 +163,11 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
 
 // rec_r and canopy_rmq64 (see TreeTables) for trees with a canopy and in-order ids; false otherwise.
 bool prepare_rank_table(TreeTables &T);
+
+// Lineage sums for a tree without canopy tables: lineage_sum + lineage_node_off, when the table
+// has at most max_entries (< 2^32) entries.  Any node numbering.  Built on several threads (one
+// root-ward walk per node).
+bool prepare_walk_lineage(TreeTables &T, int64_t max_entries);
 
 // Lineage sums of every node (see TreeTables), for trees with a canopy and a sparse table and
 // at most max_entries table entries; returns false (tables left empty) otherwise.

@@ -34,11 +34,18 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
     bool canopy = false;
     bool lineage = false, ranks = false;
+    std::vector<float> walk_sums;            // lineage sums with offsets by node id (trees without canopy tables)
+    std::vector<uint32_t> walk_off;
     if (strategy == 1) {   // the walk family uses the lineage sums of trees that have them
         TreeTables C = T;
         if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27)) {
             T.lineage_sum = std::move(C.lineage_sum);
             T.rec_p = std::move(C.rec_p);
+        }
+        TreeTables W = T;
+        if (prepare_walk_lineage(W, (int64_t)1 << 27)) {
+            walk_sums = std::move(W.lineage_sum);
+            walk_off = std::move(W.lineage_node_off);
         }
     }
     if (strategy == 2) {
@@ -83,6 +90,20 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                     if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
                         g_err = "walk: lineage-sum form disagrees with the climb";
                         return 8;
+                    }
+                }
+            }
+            if (!walk_off.empty()) {     // ... and the walk-only form of the same table (offsets by node id), with and without the sparse table
+                LineageView lin;
+                lin.node_off = walk_off.data();
+                lin.sums = walk_sums.data();
+                for (const bool use_rmq : {false, true}) {
+                    if (use_rmq && T.tree_rmq.empty()) continue;
+                    const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
+                                                   use_rmq ? T.tree_rmq.data() : nullptr, T.n, lin);
+                    if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
+                        g_err = "walk: node-offset lineage form disagrees with the climb";
+                        return 12;
                     }
                 }
             }

@@ -175,6 +175,39 @@ def test_tree_too_deep_for_the_canopy_falls_back_to_walk():
     assert info["strategy"] == "walk" and info["depth"] == 40_000
 
 
+def test_walk_only_tree_with_sparse_table_and_lineage_sums():
+    """A large deep tree the canopy family refuses (120,000 leaves, depth ~840): the walk family
+    takes the meeting node from the whole-tree sparse table and a's side from lineage sums addressed
+    by node id; both switched off as well.  Leaf and internal nodes, near pairs, (x, x)."""
+    import torch
+    rng = np.random.default_rng(7)
+    parent, dist = _random_shape_tree(rng, 120_000, 0.97)
+    n = len(parent)
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert info["strategy"] == "walk" and info["lineage_entries"] > n, info
+    O = OracleTree(parent, dist)
+    pairs = rng.integers(0, n, (12_000, 2))
+    a = rng.integers(0, n - 30, 4_000)
+    allp = np.concatenate([pairs, np.stack([a, a + rng.integers(0, 30, a.size)], 1), np.stack([a[:500], a[:500]], 1)]).astype(np.int64)
+    want_d, want_m = O.distances(allp), O.mrca_bulk(allp)
+    t = torch.from_numpy(allp).cuda()
+    for rmq, sums in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        dev.set_option("tree_rmq", rmq)
+        dev.set_option("lineage_sums", sums)
+        out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+        out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+        dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+        dev.fault_check()
+        assert_bits_equal(out_d.cpu().numpy(), want_d, "rmq=%d sums=%d" % (rmq, sums))
+        assert np.array_equal(out_m.cpu().numpy(), want_m)
+        d, m = dev.distances_host(allp[:3000], True, True)            # mailbox
+        assert_bits_equal(d, want_d[:3000], "mailbox rmq=%d sums=%d" % (rmq, sums))
+        assert np.array_equal(m, want_m[:3000])
+        assert np.array_equal(dev.distances_host(allp, False, True)[1], want_m)
+    dev.close()
+
+
 def test_special_float_values():
     parent, dist = synth.random_binary_tree(3000, seed=4)
     rng = np.random.default_rng(4)
