@@ -17,15 +17,28 @@ pieces that overlap the next piece's kernel).  "scaling": "strong"; value = n pa
 max-over-ranks step time.  With N = 1 a step is one kernel launch and nothing travels.
 --weak restores per-rank batches without the gather (every rank its own --pairs pairs).
 
-For N > 1 the driver launches this file with torch.distributed.run, one rank per GPU.
-One JSON line on stdout from rank 0; see DESIGN.md section 6 for the fields.
+How it starts.  `python bench.py --gpus N` with N > 1 and no torch.distributed.run
+environment starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+CHILD process -- before this process has imported torch or loaded any HIP library -- relays
+the child's JSON line, returns its exit code, and kills the child's process group when
+--launch-timeout expires.  Launched by torch.distributed.run directly (the driver's form for
+N > 1) the file is simply one rank.  One JSON line on stdout from rank 0; DESIGN.md section 6
+explains the fields.  The CPU baseline (oracle, all host cores) and the parity block are
+produced by rank 0 at every N, the peers waiting at the closing barrier.
+
+Structure: `run_job` is backend-neutral (HipBackend here; the gloo test-suite injects a CPU
+backend whose compute step is the oracle, tests/test_bench_gloo.py) -- the sharded step, the
+barriers, the max-over-ranks timing, the deadline and the line are the same code on both.
 """
 import argparse
-import ctypes
 import glob
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,9 +47,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "leaf-pair patristic distances/sec (+ MRCA ids/sec), 1M-leaf tree"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -54,9 +68,96 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive end-to-end leg")
     ap.add_argument("--no-microbench", action="store_true", help="skip the in-process hardware-ceiling measurements")
-    return ap.parse_args()
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs on BASELINE configs 2, 4 and 5 (other_configs in the line)")
+    ap.add_argument("--deadline", type=float, default=600.0,
+                    help="seconds every rank allows for warmup + timed steps; a rank that misses it exits with code 3")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="N > 1 self-launch: seconds before the parent kills the torch.distributed.run child")
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------------------------
+# self-launch (N > 1 without a torch.distributed.run environment)
+# --------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(n_gpus, argv, port):
+    """The command the driver itself uses for N > 1 (task contract), as a child of this process.
+    SUCHTREE_AMD_BENCH_LAUNCHER replaces the launcher module (the CPU test-suite's stand-in)."""
+    module = os.environ.get("SUCHTREE_AMD_BENCH_LAUNCHER", "torch.distributed.run")
+    head = [sys.executable, module] if module.endswith(".py") else [sys.executable, "-m", module]
+    return head + ["--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """Parent side of `python bench.py --gpus N` (N > 1).  Nothing here may touch the GPU: no torch,
+    no HIP library (the box forbids replacing or forking a process that has initialised the GPU, so
+    the ranks are children of a process that never did)."""
+    cmd = launcher_command(args.gpus, argv, _free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True)
+    try:
+        out, _ = child.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        sys.stderr.write("bench.py: the %d-rank job did not finish within %.0f s; killed\n" % (args.gpus, args.launch_timeout))
+        return 124
+    lines = [l for l in out.decode("utf-8", "replace").splitlines() if l.lstrip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    if child.returncode != 0:
+        sys.stderr.write("bench.py: torch.distributed.run exited with code %d\n" % child.returncode)
+        return child.returncode if child.returncode > 0 else 1
+    if not lines:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no JSON line\n")
+        return 1
+    return 0
+
+
+class Deadline:
+    """All-ranks deadline: every rank arms one around its warmup + timed steps; a rank still inside
+    when it expires (a hung peer, a lost link) says so and exits with code 3, which makes
+    torch.distributed.run tear the job down instead of waiting for RCCL's own 10-minute timeout."""
+
+    def __init__(self, seconds, what, rank=0, on_expire=None):
+        self.seconds, self.what, self.rank = float(seconds), what, rank
+        self.on_expire = on_expire or self._die
+        self._timer = None
+
+    def _die(self):
+        sys.stderr.write("bench.py: rank %d missed the %.0f s deadline for %s; exiting\n" % (self.rank, self.seconds, self.what))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self._timer = threading.Timer(self.seconds, self.on_expire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
+# --------------------------------------------------------------------------------------------
+# CPU legs (oracle = checker and baseline; never part of the timed GPU region)
+# --------------------------------------------------------------------------------------------
 def cpu_baseline(parent, dist, pairs_host, gpu_dist, gpu_mrca, seconds):
     """Oracle (CPU port of the reference algorithm) on a bounded sample of the same
     pairs, all host cores, fork-pool-style contiguous chunks.  Also the parity check
@@ -89,29 +190,37 @@ def cpu_baseline(parent, dist, pairs_host, gpu_dist, gpu_mrca, seconds):
         "checked_pairs": n}
 
 
-def sample_parity(parent, dist, pairs_t, out_d, out_m, plan):
-    """N > 1: the assembled vector against the oracle around every slice and piece boundary."""
+def spread_parity(parent, dist, pairs_t, out_d, out_m, plan, per_edge=500, strided=1_000_000):
+    """The assembled result against the oracle (a) around every slice and piece boundary and (b) on
+    an evenly strided sample of the whole batch, so that every rank's slice is covered."""
+    import torch
     from oracle.oracle import OracleTree
     O = OracleTree(parent, dist)
     idx = set()
-    for g in range(plan.world):
-        for lo, hi in plan.pieces(g):
-            idx.update(range(max(0, lo - 500), min(plan.n, lo + 500)))
-            idx.update(range(max(0, hi - 500), min(plan.n, hi)))
+    if plan.world > 1:
+        for g in range(plan.world):
+            for lo, hi in plan.pieces(g):
+                idx.update(range(max(0, lo - per_edge), min(plan.n, lo + per_edge)))
+                idx.update(range(max(0, hi - per_edge), min(plan.n, hi)))
+    n_edge = len(idx)
+    if plan.n:
+        idx.update(range(0, plan.n, max(1, plan.n // max(1, strided))))
     idx = np.array(sorted(idx), dtype=np.int64)
-    import torch
     it = torch.from_numpy(idx).to(pairs_t.device)
     p = pairs_t[it].cpu().numpy()
     d, m = out_d[it].cpu().numpy(), out_m[it].cpu().numpy()
-    return {"distances_bit_exact": bool(np.array_equal(O.distances(p).view(np.int64), d.view(np.int64))),
+    cores = len(os.sched_getaffinity(0))
+    return {"distances_bit_exact": bool(np.array_equal(O.distances_mt(p, cores).view(np.int64), d.view(np.int64))),
             "mrca_bit_exact": bool(np.array_equal(O.mrca_bulk(p), m)), "checked_pairs": int(len(idx)),
-            "what": "pairs within 500 of every slice / piece boundary of the assembled result, vs the oracle"}
+            "what": "assembled result vs the oracle: %d pairs within %d of every slice / piece boundary + every %d-th "
+                    "pair of the batch" % (n_edge, per_edge, max(1, plan.n // max(1, strided)))}
 
 
 def latest_traffic():
     """Per-launch counter summary of the rocprofv3 PMC passes of this same command, if one
     was committed (scripts/profile_gpu.sh -> profiles/traffic_rNN*.json)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")))
+    files = [f for f in files if "_ml_" not in f and "_walk_" not in f and "_tri_" not in f]
     if not files:
         return None, None
     try:
@@ -120,54 +229,301 @@ def latest_traffic():
         return None, None
 
 
-def hardware_ceilings(device_index, footprint_bytes):
-    """Measured in this process, on this GPU: the random 64-byte-sector read rate for a table
-    the size of the record tables the kernel gathers from, and the streaming copy rate."""
-    from suchtree_amd import build as st_build
-    try:
-        lib = ctypes.CDLL(st_build.MICRO_LIB)
-    except OSError:
-        return None     # helper library not built: the line simply carries no measured ceilings
-    lib.stmb_random_sector_reads.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                             ctypes.POINTER(ctypes.c_double)]
-    lib.stmb_stream_copy.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
-    out = {}
-    table = 1 << max(21, int(np.ceil(np.log2(max(footprint_bytes, 1)))))
-    g = ctypes.c_double(0)
-    for name, size in (("table", table), ("table_half", table // 2)):
-        rc = lib.stmb_random_sector_reads(device_index, size, 32, 512, 3, ctypes.byref(g))
-        if rc != 0:
-            return None
-        out[name] = {"MiB": size >> 20, "Greads_per_s": g.value}
-    rc = lib.stmb_stream_copy(device_index, 1 << 30, 3, ctypes.byref(g))
-    if rc == 0:
-        out["stream_copy_GBps"] = g.value
-    return out
+# --------------------------------------------------------------------------------------------
+# the MI355X backend
+# --------------------------------------------------------------------------------------------
+class HipBackend:
+    """The product path: suchtree_amd._capi.DeviceTree on this rank's GPU, torch only for device
+    buffers, events and the process group."""
+
+    name = "hip"
+
+    def __init__(self, args, parent, dist, local_rank):
+        import torch
+        from suchtree_amd import _capi
+        self.torch = torch
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.device = torch.device("cuda", local_rank)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.tree = _capi.DeviceTree(parent, dist, device=local_rank, strategy=args.strategy)
+        self.n_leaves = 1 << args.levels
+        self._events = []
+
+    def info(self):
+        return self.tree.info()
+
+    def make_pairs(self, n, seed):
+        torch = self.torch
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)
+        return torch.randint(0, self.n_leaves, (n, 2), generator=gen, device=self.device, dtype=torch.int64) * 2
+
+    def bind(self, pairs):
+        torch, tree, stream = self.torch, self.tree, self.stream
+
+        def compute(lo, hi, dst_d, dst_m):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            tree.distances_device(pairs.data_ptr() + lo * 16, hi - lo, dst_d.data_ptr(), dst_m.data_ptr(),
+                                  stream=stream.cuda_stream, f32=dst_d.dtype == torch.float32)
+            e1.record(stream)
+            self._events.append((e0, e1))
+        return compute
+
+    def kernel_clock_reset(self):
+        self._events.clear()
+
+    def kernel_ms_total(self):
+        return float(sum(a.elapsed_time(b) for a, b in self._events))
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def fault_check(self):
+        self.tree.fault_check(self.stream.cuda_stream)
+
+    def kernel_rate(self, pairs, m):
+        """This GPU's kernel rate on a prefix of the batch (for the root-share calibration)."""
+        torch = self.torch
+        d = torch.empty(m, dtype=torch.float32, device=self.device)
+        mm = torch.empty(m, dtype=torch.int32, device=self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            e0.record(self.stream)
+            self.tree.distances_device(pairs.data_ptr(), m, d.data_ptr(), mm.data_ptr(), stream=self.stream.cuda_stream, f32=True)
+            e1.record(self.stream)
+        self.synchronize()
+        return m / (e0.elapsed_time(e1) * 1e-3)
+
+    def close(self):
+        self.tree.close()
+
+    def extra_legs(self, args, line, roof, pairs, out_d, out_m, traffic, traffic_file, pairs_this_rank, kernel_ms):
+        """Rank 0 only, after the timed region: hardware ceilings, MRCA-only launch, host path, other configs."""
+        import bench_legs
+        info = self.info()
+        n = pairs.shape[0]
+        if not args.no_microbench:
+            foot = self.n_leaves * (8 + info["record_bytes"] // 2) if info["strategy"] == "canopy" else info["n_nodes"] * 12
+            hw = bench_legs.hardware_ceilings(self.local_rank, foot)
+            if hw:
+                line["hardware_measured"] = hw
+                if hw.get("stream_copy_GBps"):
+                    roof["measured_copy_GBps"] = hw["stream_copy_GBps"]
+                    roof["frac_of_measured_copy"] = roof["achieved"] / hw["stream_copy_GBps"]
+                if traffic and traffic.get("counters_mean_per_launch", {}).get("TCC_EA0_RDREQ_sum"):
+                    # fabric read requests per pair (committed PMC pass of this command) x this run's
+                    # pair rate, against the random-sector rate measured a moment ago in this process
+                    req_per_pair = traffic["counters_mean_per_launch"]["TCC_EA0_RDREQ_sum"] / traffic.get("pairs_per_launch", 1e8)
+                    rate = req_per_pair * pairs_this_rank / (kernel_ms * 1e-3)
+                    ceil = hw["table"]["Greads_per_s"]
+                    line["random_sector"] = {
+                        "fabric_reads_per_pair": req_per_pair, "achieved_Greads_per_s": rate / 1e9,
+                        "ceiling_Greads_per_s": ceil, "ceiling_table_MiB": hw["table"]["MiB"],
+                        "ceiling_shape": hw["table"].get("best_shape"),
+                        "frac": rate / 1e9 / ceil,
+                        "source": "requests: rocprofv3 TCC_EA0_RDREQ_sum in %s; ceiling: suchtree_amd/csrc/microbench.hip "
+                                  "run in this process (random 32-byte reads, one per 64-byte sector; best of a sweep over "
+                                  "unroll and grid shape)" % traffic_file}
+        line["mrca_ids_only"] = bench_legs.mrca_ids_only(self, pairs, out_m)
+        if not args.no_host_path:
+            line["end_to_end_host_path"] = bench_legs.host_path_leg(self, pairs, out_d, out_m)
+        if not args.no_other_configs:
+            line["other_configs"] = bench_legs.other_configs(self)
 
 
-def calibrate_root_share(tree, pairs, n, world, rank, device, stream, dist_, sharding):
-    """Untimed, before the benchmark: this GPU's kernel rate on a prefix of the batch and the rate
-    at which rank 0 receives from all peers at once (the gather's pattern), then the root's share
-    of the batch for which its kernels and the peers' transfers end together
-    (sharding.balanced_root_share).  Rank 0 decides; everyone gets its number."""
+# --------------------------------------------------------------------------------------------
+# the job (backend-neutral)
+# --------------------------------------------------------------------------------------------
+def _depths(parent):
+    from suchtree_amd.newick import node_depths
+    return node_depths(parent).astype(np.int64)
+
+
+def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
+    """Warmup, the timed sharded steps, the line.  `be`: backend (HipBackend, or the test-suite's CPU
+    backend); `dg`: torch.distributed with an initialised default group, or None (plain one-process
+    run); `peers_wait`: what ranks > 0 do after the timed region while rank 0 finishes the line.
+    Returns the line on rank 0, None elsewhere."""
     import torch
-    m = min(n, 20_000_000)
-    d = torch.empty(m, dtype=torch.float32, device=device)
-    mm = torch.empty(m, dtype=torch.int32, device=device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for k in range(2):
-        e0.record(stream)
-        tree.distances_device(pairs.data_ptr(), m, d.data_ptr(), mm.data_ptr(), stream=stream.cuda_stream, f32=True)
-        e1.record(stream)
-    torch.cuda.synchronize(device)
-    kernel_rate = m / (e0.elapsed_time(e1) * 1e-3)
-    share, link, k_rate = sharding.measure_root_share(world, rank, kernel_rate, device=device)
-    del d, mm
-    return share, {"kernel_pairs_per_s": k_rate, "link_GBps_into_root_per_peer": link / 1e9}
+    from suchtree_amd import sharding
+
+    info = be.info()
+    n = args.pairs
+    strong = not args.weak
+    # strong scaling: every rank generates the SAME batch (same seed) and owns a slice of it
+    pairs = be.make_pairs(n, 3 + (rank if args.weak else 0))
+    root_share, calib = None, None
+    if strong and world > 1 and args.root_share != "even":
+        if args.root_share == "auto":
+            # untimed: this GPU's kernel rate on a prefix of the batch and the rate at which rank 0
+            # receives from all peers at once (the gather's pattern); rank 0 decides, everyone agrees
+            k_rate = be.kernel_rate(pairs, min(n, 20_000_000))
+            root_share, link, k_rate = sharding.measure_root_share(world, rank, k_rate, device=be.device,
+                                                                    nbytes=getattr(be, "calibration_bytes", 64 << 20))
+            calib = {"kernel_pairs_per_s": k_rate, "link_GBps_into_root_per_peer": link / 1e9}
+        else:
+            root_share = float(args.root_share)
+    plan = sharding.ShardPlan(n, world if strong else 1, rank if strong else 0,
+                              chunks=args.chunks if (strong and world > 1) else 1, root_share=root_share)
+    out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=be.device)
+    compute = be.bind(pairs)
+
+    def step():
+        sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
+
+    def barrier():
+        if dg is not None:
+            dg.barrier()
+
+    with Deadline(args.deadline, "warmup + %d timed steps" % args.steps, rank):
+        for _ in range(args.warmup):
+            step()
+        be.fault_check()
+        be.kernel_clock_reset()
+
+        be.synchronize()
+        barrier()
+        be.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        be.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        kernel_ms = be.kernel_ms_total() / max(args.steps, 1)      # this rank, per step
+        kernel_ms_max = kernel_ms
+        if dg is not None:
+            t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=be.device)
+            dg.all_reduce(t, op=dg.ReduceOp.MAX)
+            elapsed, kernel_ms_max = float(t[0].item()), float(t[1].item())
+        be.fault_check()
+    lo0, hi0 = plan.bounds(plan.rank)
+    pairs_this_rank = hi0 - lo0
+
+    line = None
+    if rank != 0 and peers_wait is not None:
+        peers_wait()
+    if rank == 0:
+        # algorithmic bytes per pair: 16 in + 8 + 4 out + 8 per edge of the path (SURVEY 8d),
+        # h measured from the assembled results of the whole batch
+        depth_t = torch.from_numpy(_depths(parent)).to(be.device)
+        h = depth_t[pairs[:, 0]] + depth_t[pairs[:, 1]] - 2 * depth_t[out_m.long()]
+        h_mean = float(h.double().mean().item())
+        del h
+        checksum = float(out_d.sum().item())
+        traffic, traffic_file = latest_traffic()
+        line = build_line(args, world, plan, info, len(parent), elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
+                          pairs_this_rank, calib, traffic, traffic_file)
+        roof = line["roofline"]
+        if hasattr(be, "extra_legs"):
+            be.extra_legs(args, line, roof, pairs, out_d, out_m, traffic, traffic_file, pairs_this_rank, kernel_ms)
+        if strong and world > 1:
+            line["parity_across_slices"] = spread_parity(parent, dist, pairs, out_d, out_m, plan)
+        if not args.no_cpu_baseline:
+            k = min(n, 50_000_000)
+            cpu, parity = cpu_baseline(parent, dist, pairs[:k].cpu().numpy(), out_d[:k].cpu().numpy(),
+                                       out_m[:k].cpu().numpy(), args.cpu_seconds)
+            line["cpu_baseline"] = cpu
+            line["parity"] = parity
+            if strong and world > 1:
+                # at N > 1 the first pairs all belong to rank 0's slice: the verdict on the whole
+                # assembled vector needs the spread sample too
+                s = line["parity_across_slices"]
+                parity["distances_bit_exact"] = parity["distances_bit_exact"] and s["distances_bit_exact"]
+                parity["mrca_bit_exact"] = parity["mrca_bit_exact"] and s["mrca_bit_exact"]
+                parity["checked_pairs"] += s["checked_pairs"]
+    return line
 
 
-def main():
-    args = parse()
+def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
+               pairs_this_rank, calib, traffic, traffic_file):
+    """The contract's JSON line from the measured quantities (no measurement happens here)."""
+    n = args.pairs
+    strong = not args.weak
+    bytes_per_pair = 16 + 8 + 4 + 8 * h_mean
+    n_job = n * (world if args.weak else 1)
+    value = float(n_job) * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    achieved = bytes_per_pair * pairs_this_rank / (kernel_ms * 1e-3) / 1e9
+    kernel_name = {"canopy": "k_canopy_ilp", "walk": "k_walk"}.get(info["strategy"], info["strategy"])
+    # bytes the algorithm has to request from the fabric per pair when no record is cache
+    # resident: the coalesced streams plus one 64-byte sector per record read
+    required = 16 + 12 + 2 * 64
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": kernel_name, "kernel_ms": kernel_ms, "pairs_per_launch": pairs_this_rank // plan.chunks,
+            "launches_per_step": plan.chunks,
+            "algorithmic_bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean,
+            "required_bytes_per_pair": required,
+            "required_GBps": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9,
+            "required_frac": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "note": "achieved/frac: SURVEY 8d's algorithmic bytes of the reference's walk (28 + 8*h per pair) / "
+                    "kernel time; the canopy kernel climbs in LDS and reads pre-summed understory records, so it "
+                    "does not move those bytes and frac can exceed 1. required_*: the bytes this kernel must request "
+                    "per pair (16 in + 12 out + two 64-byte record sectors). traffic: fabric bytes per launch from "
+                    "request counts of the committed PMC passes (64 B per record request, 128 B per stream request, "
+                    "+ WRITE_SIZE; calibration in profiles/README.md). The ceiling that binds is random_sector."}
+    if traffic and traffic.get("hbm_bytes_per_launch"):
+        roof["traffic"] = traffic["hbm_bytes_per_launch"] * (pairs_this_rank / plan.chunks) / traffic.get("pairs_per_launch", 1e8)
+        roof["traffic_source"] = traffic_file
+    line = {
+        "metric": METRIC,
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "balanced 2^%d-leaf tree (%d nodes), %s, int64 ids in HBM -> float64 distance + "
+                               "int32 MRCA id%s"
+                               % (args.levels, n_nodes,
+                                  ("%d uniform random leaf pairs per GPU per step" % n) if args.weak else
+                                  ("one batch of %d uniform random leaf pairs per step, sharded over %d GPU(s)" % (n, world)),
+                                  "" if (args.weak or world == 1) else " assembled on rank 0 inside the timed region"),
+                   "pairs_per_step": n_job, "pairs_per_gpu": pairs_this_rank if strong else n,
+                   "tree_levels": args.levels, "kernel_family": info["strategy"],
+                   "canopy_nodes": info["canopy_nodes"], "record_bytes": info["record_bytes"],
+                   "sharding": ("contiguous pair slices (rank 0: %.0f %% of the batch, the peers share the rest: its kernels "
+                                "end when their transfers do), tree replicated, no data-path collective; results to rank 0 "
+                                "by RCCL send/recv over xGMI (float32 + int32 on the wire, %d pieces per slice)"
+                                % (100.0 * pairs_this_rank / max(n, 1), plan.chunks))
+                   if (strong and world > 1) else "none" if world == 1 else
+                   "weak: every rank its own batch, tree replicated, nothing gathered"},
+        "roofline": roof,
+        "kernel_only_pairs_per_s": (n if strong else n * world) / (kernel_ms_max * 1e-3),
+        "kernel_pairs_per_s_per_gpu": pairs_this_rank / (kernel_ms * 1e-3),
+        "checksum": checksum,
+    }
+    if strong and world > 1:
+        # what the gather costs on top of the slowest rank's kernels (exposed, after overlap)
+        line["gather_ms"] = max(0.0, ms_per_step - kernel_ms_max)
+        line["gather_bytes_into_root"] = 8 * (n - pairs_this_rank)
+        line["root_share"] = pairs_this_rank / max(n, 1)
+        if calib:
+            line["root_share_calibration"] = calib
+    return line
+
+
+def closing_wait(dg, rank, timeout_s, release=False):
+    """While rank 0 runs the CPU baseline and the side legs (a minute or two) the peers wait on the
+    process group's key-value store -- on the host, with a generous timeout -- instead of inside an
+    RCCL barrier kernel that spins on their GPUs and is subject to the collective timeout."""
+    import datetime
+    store = dg.distributed_c10d._get_default_store()
+    if rank == 0:
+        if release:
+            store.set("suchtree_bench_rank0_done", "1")
+    elif not release:
+        store.wait(["suchtree_bench_rank0_done"], datetime.timedelta(seconds=max(60.0, timeout_s)))
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher's parent (before torch / HIP)
+        sys.exit(self_launch(args, argv))
+
     # Only the JSON line may reach stdout: RCCL prints a version banner to fd 1 when a
     # communicator is created, so everything else is sent to stderr until the line is ready.
     sys.stdout.flush()
@@ -180,8 +536,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)"
+                         % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible")
     torch.cuda.set_device(local_rank)
@@ -198,243 +555,21 @@ def main():
         # group ... all ranks must participate"): build the communicator here, deterministically
         dist_.barrier()
 
-    from suchtree_amd import _capi, sharding, synth
+    from suchtree_amd import synth
     parent, dist = synth.balanced_tree(args.levels)
-    n_leaves = 1 << args.levels
-    tree = _capi.DeviceTree(parent, dist, device=local_rank, strategy=args.strategy)
-    info = tree.info()
-
-    # the synthetic batch, generated on the device (leaf ids are the even ids).  Strong scaling:
-    # every rank generates the SAME batch (same seed) and owns a slice of it.
-    n = args.pairs
-    gen = torch.Generator(device=device)
-    gen.manual_seed(3 + (rank if args.weak else 0))
-    pairs = torch.randint(0, n_leaves, (n, 2), generator=gen, device=device, dtype=torch.int64) * 2
-    stream = torch.cuda.current_stream(device)
-    strong = not args.weak
-    root_share, calib = None, None
-    if strong and world > 1 and args.root_share != "even":
-        if args.root_share == "auto":
-            root_share, calib = calibrate_root_share(tree, pairs, n, world, rank, device, stream, dist_, sharding)
-        else:
-            root_share = float(args.root_share)
-    plan = sharding.ShardPlan(n, world if strong else 1, rank if strong else 0,
-                              chunks=args.chunks if (strong and world > 1) else 1, root_share=root_share)
-    out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=device)
-    piece_events = []
-
-    def compute(lo, hi, dst_d, dst_m):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        tree.distances_device(pairs.data_ptr() + lo * 16, hi - lo, dst_d.data_ptr(), dst_m.data_ptr(),
-                              stream=stream.cuda_stream, f32=dst_d.dtype == torch.float32)
-        e1.record(stream)
-        piece_events.append((e0, e1))
-
-    def step():
-        sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
-
-    def barrier():
-        if distributed:
-            dist_.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    tree.fault_check(stream.cuda_stream)
-    piece_events.clear()
-
-    torch.cuda.synchronize(device)
-    barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    torch.cuda.synchronize(device)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    kernel_ms = float(sum(a.elapsed_time(b) for a, b in piece_events)) / max(args.steps, 1)   # this rank, per step
-    kernel_ms_max = kernel_ms
-    if distributed:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
-        dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
-        elapsed, kernel_ms_max = float(t[0].item()), float(t[1].item())
-    tree.fault_check(stream.cuda_stream)
-    lo0, hi0 = plan.bounds(plan.rank)
-    pairs_this_rank = hi0 - lo0
-
+    be = HipBackend(args, parent, dist, local_rank)
+    line = run_job(args, be, dist_ if distributed else None, world, rank, parent, dist,
+                   peers_wait=(lambda: closing_wait(dist_, rank, args.launch_timeout)) if distributed else None)
     if rank == 0:
-        # algorithmic bytes per pair: 16 in + 8 + 4 out + 8 per edge of the path,
-        # h measured from the assembled results of the whole batch
-        depth_t = torch.from_numpy(_depths(parent)).to(device)
-        h = depth_t[pairs[:, 0]] + depth_t[pairs[:, 1]] - 2 * depth_t[out_m.long()]
-        h_mean = float(h.double().mean().item())
-        del h
-        bytes_per_pair = 16 + 8 + 4 + 8 * h_mean
-        checksum = float(out_d.sum().item())
-        n_job = n * (world if args.weak else 1)
-        value = float(n_job) * args.steps / elapsed
-        ms_per_step = elapsed / args.steps * 1e3
-        achieved = bytes_per_pair * pairs_this_rank / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_file = latest_traffic()
-        kernel_name = {"canopy": "k_canopy_ilp", "walk": "k_walk"}.get(info["strategy"], info["strategy"])
-        # bytes the algorithm has to request from the fabric per pair when no record is cache
-        # resident: the coalesced streams plus one 64-byte sector per record read
-        required = 16 + 12 + 2 * 64
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel": kernel_name, "kernel_ms": kernel_ms, "pairs_per_launch": pairs_this_rank // plan.chunks,
-                "launches_per_step": plan.chunks,
-                "algorithmic_bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean,
-                "required_bytes_per_pair": required,
-                "required_GBps": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9,
-                "required_frac": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "note": "achieved/frac: SURVEY 8d's algorithmic bytes of the reference's walk (28 + 8*h per pair) / "
-                        "kernel time; the canopy kernel climbs in LDS and reads pre-summed understory records, so it "
-                        "does not move those bytes and frac can exceed 1. required_*: the bytes this kernel must request "
-                        "per pair (16 in + 12 out + two 64-byte record sectors). traffic: fabric bytes per launch from "
-                        "request counts of the committed PMC passes (64 B per record request, 128 B per stream request, "
-                        "+ WRITE_SIZE; calibration in profiles/README.md). The ceiling that binds is random_sector."}
-        if traffic and traffic.get("hbm_bytes_per_launch"):
-            roof["traffic"] = traffic["hbm_bytes_per_launch"] * (pairs_this_rank / plan.chunks) / traffic.get("pairs_per_launch", 1e8)
-            roof["traffic_source"] = traffic_file
-        line = {
-            "metric": "leaf-pair patristic distances/sec (+ MRCA ids/sec), 1M-leaf tree",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "balanced 2^%d-leaf tree (%d nodes), %s, int64 ids in HBM -> float64 distance + "
-                                   "int32 MRCA id%s"
-                                   % (args.levels, len(parent),
-                                      ("%d uniform random leaf pairs per GPU per step" % n) if args.weak else
-                                      ("one batch of %d uniform random leaf pairs per step, sharded over %d GPU(s)" % (n, world)),
-                                      "" if (args.weak or world == 1) else " assembled on rank 0 inside the timed region"),
-                       "pairs_per_step": n_job, "pairs_per_gpu": pairs_this_rank if strong else n,
-                       "tree_levels": args.levels, "kernel_family": info["strategy"],
-                       "canopy_nodes": info["canopy_nodes"], "record_bytes": info["record_bytes"],
-                       "sharding": ("contiguous pair slices (rank 0: %.0f %% of the batch, the peers share the rest: its kernels "
-                                    "end when their transfers do), tree replicated, no data-path collective; results to rank 0 "
-                                    "by RCCL send/recv over xGMI (float32 + int32 on the wire, %d pieces per slice)"
-                                    % (100.0 * pairs_this_rank / n, plan.chunks))
-                       if (strong and world > 1) else "none" if world == 1 else
-                       "weak: every rank its own batch, tree replicated, nothing gathered"},
-            "roofline": roof,
-            "kernel_only_pairs_per_s": (n if strong else n * world) / (kernel_ms_max * 1e-3),
-            "kernel_pairs_per_s_per_gpu": pairs_this_rank / (kernel_ms * 1e-3),
-            "checksum": checksum,
-        }
-        if strong and world > 1:
-            # what the gather costs on top of the slowest rank's kernels (exposed, after overlap)
-            line["gather_ms"] = max(0.0, ms_per_step - kernel_ms_max)
-            line["gather_bytes_into_root"] = 8 * (n - pairs_this_rank)
-            line["root_share"] = pairs_this_rank / n
-            if calib:
-                line["root_share_calibration"] = calib
-            line["parity"] = sample_parity(parent, dist, pairs, out_d, out_m, plan)
-        if not args.no_microbench:
-            # footprint the record gathers fall on: rec_a (8 B) + rec_b (record_bytes / 2) per leaf
-            foot = n_leaves * (8 + info["record_bytes"] // 2) if info["strategy"] == "canopy" else len(parent) * 12
-            hw = hardware_ceilings(local_rank, foot)
-            if hw:
-                line["hardware_measured"] = hw
-                if hw.get("stream_copy_GBps"):
-                    roof["measured_copy_GBps"] = hw["stream_copy_GBps"]
-                    roof["frac_of_measured_copy"] = achieved / hw["stream_copy_GBps"]
-                if traffic and traffic.get("counters_mean_per_launch", {}).get("TCC_EA0_RDREQ_sum"):
-                    # fabric read requests per pair (committed PMC pass of this command) x this run's
-                    # pair rate, against the random-sector rate measured a moment ago in this process
-                    req_per_pair = traffic["counters_mean_per_launch"]["TCC_EA0_RDREQ_sum"] / traffic.get("pairs_per_launch", 1e8)
-                    rate = req_per_pair * pairs_this_rank / (kernel_ms * 1e-3)
-                    ceil = hw["table"]["Greads_per_s"]
-                    line["random_sector"] = {
-                        "fabric_reads_per_pair": req_per_pair, "achieved_Greads_per_s": rate / 1e9,
-                        "ceiling_Greads_per_s": ceil, "ceiling_table_MiB": hw["table"]["MiB"],
-                        "frac": rate / 1e9 / ceil,
-                        "source": "requests: rocprofv3 TCC_EA0_RDREQ_sum in %s; ceiling: suchtree_amd/csrc/microbench.hip "
-                                  "run in this process (random 32-byte reads, one per 64-byte sector)" % traffic_file}
-        if world == 1:
-            # MRCA ids alone (common_ancestors_bulk, quartets): on trees with in-order ids they come
-            # from a rank table and a sparse table over the canopy, without the distance kernels
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            chk = torch.empty(n, dtype=torch.int32, device=device)
-            tree.distances_device(pairs.data_ptr(), n, 0, chk.data_ptr(), stream=stream.cuda_stream)
-            ev0.record(stream)
-            for _ in range(5):
-                tree.distances_device(pairs.data_ptr(), n, 0, chk.data_ptr(), stream=stream.cuda_stream)
-            ev1.record(stream)
-            ev1.synchronize()
-            tree.fault_check(stream.cuda_stream)
-            line["mrca_ids_only"] = {"ids_per_s": 5.0 * n / (ev0.elapsed_time(ev1) * 1e-3),
-                                     "matches_the_fused_launch": bool(torch.equal(chk, out_m))}
-            del chk
-        if world == 1 and not args.no_host_path:
-            # end-to-end leg (SURVEY 8d asks for it next to the kernel-only figure; it is never
-            # `value`): the same batch prefix from pageable host numpy arrays through the library's
-            # staged host path -- what T.distances_bulk(numpy) costs, PCIe inclusive
-            k2 = min(n, 50_000_000)
-            host_pairs = pairs[:k2].cpu().numpy()
-            ref_d, ref_m = out_d[:k2].cpu().numpy(), out_m[:k2].cpu().numpy()
-            h_d, h_m = np.empty(k2), np.empty(k2, dtype=np.int32)
-            tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
-            t_h = time.perf_counter()
-            tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
-            t_h = time.perf_counter() - t_h
-            t_f = time.perf_counter()
-            f_d, f_m = tree.distances_host(host_pairs, True, True)     # fresh result arrays, as the facade returns
-            t_f = time.perf_counter() - t_f
-            # what a caller's loop sees: "r = distances_host(...)", result dropped, again -- the
-            # result blocks (>= 32 MiB) come back to the library's recycle pool and go out resident
-            loop_ok = True
-            t_l = time.perf_counter()
-            for _ in range(3):
-                l_d, l_m = tree.distances_host(host_pairs, True, True)
-                loop_ok = loop_ok and bool(l_d[k2 - 1] == ref_d[k2 - 1] and l_m[0] == ref_m[0])
-                del l_d, l_m
-            t_l = (time.perf_counter() - t_l) / 3
-            # opt-in: result arrays from the recycled pinned pool, written by the kernel directly
-            tree.pinned_results = True
-            p_d, p_m = tree.distances_host(host_pairs, True, True)
-            pooled_ok = bool(np.array_equal(p_d.view(np.int64), ref_d.view(np.int64)) and np.array_equal(p_m, ref_m))
-            del p_d, p_m
-            t_p = time.perf_counter()
-            p_d, p_m = tree.distances_host(host_pairs, True, True)
-            t_p = time.perf_counter() - t_p
-            del p_d, p_m
-            tree.pinned_results = False
-            line["end_to_end_host_path"] = {
-                "pairs_per_s": k2 / t_h, "pairs_per_s_fresh_arrays": k2 / t_f,
-                "pairs_per_s_call_and_drop_loop": k2 / t_l,
-                "pairs_per_s_pinned_result_pool": k2 / t_p, "pairs": k2,
-                "what": "pageable numpy int64 pairs in -> float64 distances + int32 MRCA ids out, PCIe inclusive "
-                        "(ids cross as int32, distances as float32, widened on the host); reused result arrays / "
-                        "result arrays allocated by the call, first use of their memory (what a single "
-                        "SuchTree.distances_bulk call returns) / the same call in a loop that drops each result "
-                        "(blocks recycled by the library, release included) / opt-in pinned result pool (float64 + "
-                        "int32 written by the kernel straight into the returned arrays)",
-                "matches_device_results": bool(np.array_equal(h_d.view(np.int64), ref_d.view(np.int64))
-                                               and np.array_equal(h_m, ref_m)
-                                               and np.array_equal(f_d.view(np.int64), ref_d.view(np.int64))
-                                               and np.array_equal(f_m, ref_m) and pooled_ok and loop_ok)}
-            del host_pairs, ref_d, ref_m, h_d, h_m, f_d, f_m
-        if world == 1 and not args.no_cpu_baseline:
-            k = min(n, 50_000_000)
-            cpu, parity = cpu_baseline(parent, dist, pairs[:k].cpu().numpy(), out_d[:k].cpu().numpy(),
-                                       out_m[:k].cpu().numpy(), args.cpu_seconds)
-            line["cpu_baseline"] = cpu
-            line["parity"] = parity
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
     if distributed:
+        closing_wait(dist_, rank, args.launch_timeout, release=True)
         dist_.barrier()
         dist_.destroy_process_group()
-    tree.close()
-
-
-def _depths(parent):
-    from suchtree_amd.newick import node_depths
-    return node_depths(parent).astype(np.int64)
+    be.close()
 
 
 if __name__ == "__main__":

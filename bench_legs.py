@@ -1,0 +1,365 @@
+"""Side legs of bench.py (rank 0, after the timed region; none of this is `value`):
+
+  hardware_ceilings   random-sector and streaming-copy rates of THIS GPU, best over a sweep of
+                      launch shapes (suchtree_amd/csrc/microbench.hip)
+  mrca_ids_only       MRCA ids without distances on the same batch
+  host_path_leg       the same batch prefix from pageable numpy arrays (PCIe inclusive)
+  other_configs       short legs on BASELINE configs 2 (ml.tree / nj.tree, 1e7 pairs), 4 (100k-leaf
+                      lower triangle, generated on the device; a prefix streamed to the host) and
+                      5 (fish-worm linked_distances + Laplacian), each with its SURVEY 8d
+                      algorithmic bytes and an oracle check of a sample
+
+`be` is bench.HipBackend.  The oracle is used as the checker only.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HBM_PEAK_GBPS = 8000.0
+
+
+# --------------------------------------------------------------------------------------------
+def _micro():
+    from suchtree_amd import build as st_build
+    try:
+        lib = ctypes.CDLL(st_build.MICRO_LIB)
+    except OSError:
+        return None     # helper library not built: the line simply carries no measured ceilings
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.stmb_random_sector_reads_shape.argtypes = [ctypes.c_int, ctypes.c_longlong] + [ctypes.c_int] * 5 + [dp]
+    lib.stmb_stream_copy_shape.argtypes = [ctypes.c_int, ctypes.c_longlong] + [ctypes.c_int] * 5 + [dp]
+    return lib
+
+
+SECTOR_SHAPES = [(u, b, t) for u in (4, 8, 16) for b, t in ((256, 1024), (512, 1024), (1024, 1024), (1024, 512), (2048, 256))]
+COPY_SHAPES = [(u, b, t, nt) for u in (1, 2, 4, 8) for b, t in ((0, 256), (0, 1024), (2048, 1024), (4096, 512)) for nt in (0, 1)]
+
+
+def hardware_ceilings(device_index, footprint_bytes, sweep_log=None):
+    """Measured in this process, on this GPU: the random 64-byte-sector read rate for a table the size
+    of the record tables the kernel gathers from, and the streaming copy rate -- each the BEST over a
+    sweep of launch shapes (unroll x grid x block; copy: also non-temporal), because a ceiling taken
+    at one shape is only a floor.  `sweep_log`: list that receives one dict per measured shape."""
+    lib = _micro()
+    if lib is None:
+        return None
+    g = ctypes.c_double(0)
+    out = {}
+    table = 1 << max(21, int(np.ceil(np.log2(max(footprint_bytes, 1)))))
+    for name, size in (("table", table), ("table_half", table // 2)):
+        best = None
+        for unroll, blocks, threads in SECTOR_SHAPES:
+            rc = lib.stmb_random_sector_reads_shape(device_index, size, 32, unroll, blocks, threads, 2, ctypes.byref(g))
+            if rc != 0:
+                return None
+            if sweep_log is not None:
+                sweep_log.append({"what": "random_sector", "MiB": size >> 20, "unroll": unroll, "blocks": blocks,
+                                  "threads": threads, "Greads_per_s": g.value})
+            if best is None or g.value > best[0]:
+                best = (g.value, {"unroll": unroll, "blocks": blocks, "threads": threads})
+        out[name] = {"MiB": size >> 20, "Greads_per_s": best[0], "best_shape": best[1], "shapes_swept": len(SECTOR_SHAPES)}
+    best = None
+    for unroll, blocks, threads, nt in COPY_SHAPES:
+        rc = lib.stmb_stream_copy_shape(device_index, 1 << 30, 2, unroll, blocks, threads, nt, ctypes.byref(g))
+        if rc != 0:
+            break
+        if sweep_log is not None:
+            sweep_log.append({"what": "stream_copy", "unroll": unroll, "blocks": blocks, "threads": threads, "nt": nt,
+                              "GBps": g.value})
+        if best is None or g.value > best[0]:
+            best = (g.value, {"unroll": unroll, "blocks": blocks or "exact", "threads": threads, "non_temporal": bool(nt)})
+    if best:
+        out["stream_copy_GBps"] = best[0]
+        out["stream_copy_best_shape"] = best[1]
+        out["stream_copy_shapes_swept"] = len(COPY_SHAPES)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def mrca_ids_only(be, pairs, out_m, reps=5):
+    """MRCA ids alone (common_ancestors_bulk, quartets): on trees with in-order ids they come from a
+    rank table and a sparse table over the canopy, without the distance kernels."""
+    torch, tree, stream = be.torch, be.tree, be.stream
+    n = pairs.shape[0]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    chk = torch.empty(n, dtype=torch.int32, device=be.device)
+    tree.distances_device(pairs.data_ptr(), n, 0, chk.data_ptr(), stream=stream.cuda_stream)
+    ev0.record(stream)
+    for _ in range(reps):
+        tree.distances_device(pairs.data_ptr(), n, 0, chk.data_ptr(), stream=stream.cuda_stream)
+    ev1.record(stream)
+    ev1.synchronize()
+    tree.fault_check(stream.cuda_stream)
+    return {"ids_per_s": float(reps) * n / (ev0.elapsed_time(ev1) * 1e-3),
+            "matches_the_fused_launch": bool(torch.equal(chk, out_m[:n]))}
+
+
+def host_path_leg(be, pairs, out_d, out_m):
+    """End-to-end leg (SURVEY 8d asks for it next to the kernel-only figure; it is never `value`):
+    the same batch prefix from pageable host numpy arrays through the library's staged host path --
+    what T.distances_bulk(numpy) costs, PCIe inclusive."""
+    tree = be.tree
+    n = pairs.shape[0]
+    k2 = min(n, 50_000_000)
+    host_pairs = pairs[:k2].cpu().numpy()
+    ref_d, ref_m = out_d[:k2].cpu().numpy(), out_m[:k2].cpu().numpy()
+    h_d, h_m = np.empty(k2), np.empty(k2, dtype=np.int32)
+    tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+    t_h = 1e30
+    for _ in range(2):
+        t = time.perf_counter()
+        tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+        t_h = min(t_h, time.perf_counter() - t)
+    t_f = time.perf_counter()
+    f_d, f_m = tree.distances_host(host_pairs, True, True)     # fresh result arrays, as the facade returns
+    t_f = time.perf_counter() - t_f
+    # what a caller's loop sees: "r = distances_host(...)", result dropped, again -- the
+    # result blocks (>= 32 MiB) come back to the library's recycle pool and go out resident
+    loop_ok = True
+    t_l = time.perf_counter()
+    for _ in range(3):
+        l_d, l_m = tree.distances_host(host_pairs, True, True)
+        loop_ok = loop_ok and bool(l_d[k2 - 1] == ref_d[k2 - 1] and l_m[0] == ref_m[0])
+        del l_d, l_m
+    t_l = (time.perf_counter() - t_l) / 3
+    # int32 ids, C order (what a caller who keeps ids as int32 hands over): no narrowing pass
+    pairs32 = host_pairs.astype(np.int32)
+    tree.distances_host(pairs32, True, True, out_dist=h_d, out_mrca=h_m)
+    t_32 = time.perf_counter()
+    tree.distances_host(pairs32, True, True, out_dist=h_d, out_mrca=h_m)
+    t_32 = time.perf_counter() - t_32
+    i32_ok = bool(np.array_equal(h_d.view(np.int64), ref_d.view(np.int64)) and np.array_equal(h_m, ref_m))
+    tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+    # opt-in: result arrays from the recycled pinned pool, written by the kernel directly
+    tree.pinned_results = True
+    p_d, p_m = tree.distances_host(host_pairs, True, True)
+    pooled_ok = bool(np.array_equal(p_d.view(np.int64), ref_d.view(np.int64)) and np.array_equal(p_m, ref_m))
+    del p_d, p_m
+    t_p = time.perf_counter()
+    p_d, p_m = tree.distances_host(host_pairs, True, True)
+    t_p = time.perf_counter() - t_p
+    del p_d, p_m
+    tree.pinned_results = False
+    return {
+        "pairs_per_s": k2 / t_h, "pairs_per_s_fresh_arrays": k2 / t_f,
+        "pairs_per_s_call_and_drop_loop": k2 / t_l,
+        "pairs_per_s_int32_ids": k2 / t_32,
+        "pairs_per_s_pinned_result_pool": k2 / t_p, "pairs": k2,
+        "link_GBps_each_way": 8.0 * k2 / t_h / 1e9,
+        "what": "pageable numpy int64 pairs in -> float64 distances + int32 MRCA ids out, PCIe inclusive "
+                "(ids cross as int32, distances as float32, widened on the host); reused result arrays / "
+                "result arrays allocated by the call, first use of their memory (what a single "
+                "SuchTree.distances_bulk call returns) / the same call in a loop that drops each result "
+                "(blocks recycled by the library, release included) / int32 ids handed over as they are / opt-in "
+                "pinned result pool (float64 + int32 written by the kernel straight into the returned arrays)",
+        "matches_device_results": bool(np.array_equal(f_d.view(np.int64), ref_d.view(np.int64))
+                                       and np.array_equal(f_m, ref_m)
+                                       and np.array_equal(h_d.view(np.int64), ref_d.view(np.int64))
+                                       and np.array_equal(h_m, ref_m) and pooled_ok and loop_ok and i32_ok)}
+
+
+# --------------------------------------------------------------------------------------------
+def _device_rate(be, tree, pairs_t, reps=5):
+    """Median kernel time over `reps` launches of the whole batch (HIP events on the launch stream)."""
+    torch, stream = be.torch, be.stream
+    n = pairs_t.shape[0]
+    out_d = torch.empty(n, dtype=torch.float64, device=be.device)
+    out_m = torch.empty(n, dtype=torch.int32, device=be.device)
+    ms = []
+    for r in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        tree.distances_device(pairs_t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(be.device)
+        if r:
+            ms.append(e0.elapsed_time(e1))
+    tree.fault_check(stream.cuda_stream)
+    return float(np.median(ms)), out_d, out_m
+
+
+def _mean_path_edges(be, parent, pairs_t, out_m):
+    from suchtree_amd.newick import node_depths
+    torch = be.torch
+    depth_t = torch.from_numpy(node_depths(parent).astype(np.int64)).to(be.device)
+    h = depth_t[pairs_t[:, 0]] + depth_t[pairs_t[:, 1]] - 2 * depth_t[out_m.long()]
+    return float(h.double().mean().item())
+
+
+def config2(be, name, n=10_000_000, sample=400_000):
+    """BASELINE configs[1]: data/bigtrees/{ml,nj}.tree (flat-array fixture), 1e7 random leaf pairs."""
+    from oracle.oracle import OracleTree
+    from suchtree_amd import _capi
+    torch = be.torch
+    z = np.load(os.path.join(GOLDEN, "%s_tree.npz" % name))
+    parent, dist, leaf_ids = z["parent"], z["distance"], z["leaf_ids"].astype(np.int64)
+    tree = _capi.DeviceTree(parent, dist, device=be.local_rank)
+    try:
+        pairs = np.random.default_rng(2).choice(leaf_ids, size=(n, 2))
+        pairs_t = torch.from_numpy(pairs).to(be.device)
+        O = OracleTree(parent, dist)
+        cores = len(os.sched_getaffinity(0))
+        want_d, want_m = O.distances_mt(pairs[:sample], cores), O.mrca_bulk(pairs[:sample])
+        out = {"workload": "%s.tree (%d leaves, %d nodes, depth %d), %d uniform random leaf pairs, int64 ids in HBM -> "
+                           "float64 distance + int32 MRCA id" % (name, len(leaf_ids), len(parent), tree.info()["depth"], n)}
+        for strategy in ("canopy", "walk"):
+            tree.set_strategy(strategy)
+            ms, out_d, out_m = _device_rate(be, tree, pairs_t)
+            if strategy == "canopy":
+                h_mean = _mean_path_edges(be, parent, pairs_t, out_m)
+                out["mean_path_edges"] = h_mean
+                out["algorithmic_bytes_per_pair"] = 28 + 8 * h_mean
+            ok = (np.array_equal(out_d[:sample].cpu().numpy().view(np.int64), want_d.view(np.int64))
+                  and np.array_equal(out_m[:sample].cpu().numpy(), want_m))
+            gbps = (28 + 8 * out["mean_path_edges"]) * n / (ms * 1e-3) / 1e9
+            out[strategy] = {"kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok),
+                             "sample_pairs": sample, "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+            del out_d, out_m
+        tree.set_strategy("auto")
+        h_d, h_m = np.empty(n), np.empty(n, dtype=np.int32)
+        tree.distances_host(pairs, True, True, out_dist=h_d, out_mrca=h_m)
+        t = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tree.distances_host(pairs, True, True, out_dist=h_d, out_mrca=h_m)
+            t = min(t, time.perf_counter() - t0)
+        out["host_path"] = {"pairs_per_s": n / t,
+                            "bit_exact_on_sample": bool(np.array_equal(h_d[:sample].view(np.int64), want_d.view(np.int64))
+                                                        and np.array_equal(h_m[:sample], want_m))}
+        out["kernel_family_info"] = {k: tree.info()[k] for k in ("canopy_nodes", "record_bytes", "lineage_entries")}
+        return out
+    finally:
+        tree.close()
+
+
+def config4(be, m=100_000, host_pairs=1 << 30):
+    """BASELINE configs[3]: full lower triangle of the complete 100,000-leaf tree in linked_distances order
+    (k = i(i-1)/2 + j -> (ids[j], ids[i]), MuchTree.pyx:2918-2925), generated on the device; a prefix
+    of the stream through the host entry point into one reused numpy buffer."""
+    from oracle.oracle import OracleTree
+    from suchtree_amd import _capi, synth
+    from suchtree_amd.sharding import triangle_row_of
+    torch, stream = be.torch, be.stream
+    parent, dist = synth.complete_tree(m, seed=44)
+    tree = _capi.DeviceTree(parent, dist, device=be.local_rank)
+    try:
+        ids = np.arange(0, 2 * m, 2, dtype=np.int64)
+        ids_t = torch.from_numpy(ids).to(be.device)
+        total = m * (m - 1) // 2
+        tile = 1 << 27
+        out_d = torch.empty(tile, dtype=torch.float64, device=be.device)
+        out_m = torch.empty(tile, dtype=torch.int32, device=be.device)
+        out = {"workload": "full lower triangle of the complete %d-leaf binary tree (seed 44): %d pairs in "
+                           "linked_distances order, generated on the device" % (m, total), "pairs": total}
+        # mean path length from one tile in the middle of the stream
+        k_mid = total // 2
+        tree.triangle_device(ids_t.data_ptr(), m, k_mid, tile, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
+        kk = torch.arange(k_mid, k_mid + tile, device=be.device, dtype=torch.int64)
+        rows = ((1.0 + torch.sqrt(1.0 + 8.0 * kk.double())) / 2.0).long()
+        rows = torch.where(rows * (rows - 1) // 2 > kk, rows - 1, rows)
+        rows = torch.where((rows + 1) * rows // 2 <= kk, rows + 1, rows)
+        cols = kk - rows * (rows - 1) // 2
+        pp = torch.stack([cols * 2, rows * 2], 1)
+        h_mean = _mean_path_edges(be, parent, pp, out_m)
+        del kk, rows, cols, pp
+        out["mean_path_edges"] = h_mean
+        out["algorithmic_bytes_per_pair"] = 12 + 8 * h_mean      # generated pairs: no ids in
+        for strategy in ("canopy", "walk"):
+            tree.set_strategy(strategy)
+            best = 1e30
+            for _ in range(2):
+                torch.cuda.synchronize(be.device)
+                t0 = time.perf_counter()
+                for k0 in range(0, total, tile):
+                    tree.triangle_device(ids_t.data_ptr(), m, k0, min(tile, total - k0), out_d.data_ptr(), out_m.data_ptr(),
+                                         stream=stream.cuda_stream)
+                torch.cuda.synchronize(be.device)
+                best = min(best, time.perf_counter() - t0)
+            tree.fault_check(stream.cuda_stream)
+            gbps = out["algorithmic_bytes_per_pair"] * total / best / 1e9
+            out[strategy] = {"seconds_whole_triangle": best, "pairs_per_s": total / best, "algorithmic_GBps": gbps,
+                             "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+        tree.set_strategy("auto")
+        del out_d, out_m
+        host_tile = 1 << 26
+        buf_d = np.empty(host_tile, dtype=np.float64)
+        tree.triangle_host(ids, k_begin=0, k_count=host_tile, out_dist=buf_d)
+        budget = min(total, host_pairs)
+        t0 = time.perf_counter()
+        done = 0
+        while done < budget:
+            c = min(host_tile, budget - done)
+            tree.triangle_host(ids, k_begin=done, k_count=c, out_dist=buf_d[:c])
+            done += c
+        dt = time.perf_counter() - t0
+        out["streamed_to_host"] = {"pairs": done, "pairs_per_s": done / dt, "float64_GBps_into_host_memory": done * 8 / dt / 1e9,
+                                   "what": "first %d pairs of the triangle through st_triangle_host in %d-pair tiles into "
+                                           "one reused float64 buffer" % (done, host_tile)}
+        O = OracleTree(parent, dist)
+        k0 = total // 3
+        d, mm = tree.triangle_host(ids, k_begin=k0, k_count=200_000, want_mrca=True)
+        kk = np.arange(k0, k0 + 200_000)
+        rows = triangle_row_of(kk)
+        cols = kk - rows * (rows - 1) // 2
+        pp = np.stack([ids[cols], ids[rows]], 1)
+        out["bit_exact_on_sample"] = bool(np.array_equal(d.view(np.int64), O.distances(pp).view(np.int64))
+                                          and np.array_equal(mm, O.mrca_bulk(pp)))
+        out["sample_pairs"] = 200_000
+        return out
+    finally:
+        tree.close()
+
+
+def config5(be):
+    """BASELINE configs[4]: fish-worm SuchLinkedTrees -- linked_distances on both trees + the Laplacian."""
+    import pandas as pd
+    from oracle import oracle as orc
+    from suchtree_amd import SuchTree
+    from suchtree_amd.linked import SuchLinkedTrees
+    d = os.path.join(GOLDEN, "fish_worm")
+    links = pd.read_csv(d + "/links.csv", index_col=0)
+    A, B = SuchTree(d + "/host.tree", device=be.local_rank), SuchTree(d + "/guest.tree", device=be.local_rank)
+    SLT = SuchLinkedTrees(A, B, links)
+    r = SLT.linked_distances()
+    best = 1e30
+    for _ in range(10):
+        t0 = time.perf_counter()
+        SLT.linked_distances()
+        best = min(best, time.perf_counter() - t0)
+    ids_a, ids_b = orc.linked_pairs(SLT.linklist)
+    OA = orc.OracleTree(A._flat.parent, A._flat.distance)
+    OB = orc.OracleTree(B._flat.parent, B._flat.distance)
+    ok = bool(np.array_equal(np.asarray(r["TreeA"]).view(np.int64), OA.distances(ids_a).view(np.int64))
+              and np.array_equal(np.asarray(r["TreeB"]).view(np.int64), OB.distances(ids_b).view(np.int64)))
+    SLT.laplacian()
+    t0 = time.perf_counter()
+    lap = SLT.laplacian()
+    t_lap = time.perf_counter() - t0
+    # the oracle's own dense-block restatement of MuchTree.pyx:1750-1813 + 3081-3145
+    fa, fb = A._flat, B._flat
+    aj_o = orc.linked_adjacency((fa.parent, fa.left, fa.right, fa.distance), (fb.parent, fb.left, fb.right, fb.distance),
+                                SLT.linklist, SLT.subset_a_root, SLT.subset_b_root, A.polytomy_epsilon, B.polytomy_epsilon)
+    lap_ok = bool(np.array_equal(lap.view(np.int64), orc.linked_laplacian(aj_o).view(np.int64)))
+    return {"workload": "fish-worm: host 21 leaves / guest 191 leaves, 191 links -> 18,145 link pairs on each tree",
+            "pairs": 2 * len(ids_a), "seconds_linked_distances": best, "pairs_per_s": 2 * len(ids_a) / best,
+            "distances_bit_exact": ok, "seconds_laplacian": t_lap, "laplacian_shape": list(lap.shape),
+            "laplacian_bit_exact": lap_ok}
+
+
+def other_configs(be):
+    """The other BASELINE configs, a few seconds in all.  A failing leg reports its error instead of
+    taking the headline line down with it."""
+    out = {}
+    for key, fn in (("config2_ml_tree", lambda: config2(be, "ml")), ("config2_nj_tree", lambda: config2(be, "nj")),
+                    ("config4_triangle_100k", lambda: config4(be)), ("config5_fish_worm", lambda: config5(be))):
+        t0 = time.perf_counter()
+        try:
+            out[key] = fn()
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[key]["leg_seconds"] = time.perf_counter() - t0
+    return out

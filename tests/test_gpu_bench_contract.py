@@ -37,6 +37,23 @@ def test_bench_line_contract():
     e = d["end_to_end_host_path"]
     assert e["pairs_per_s"] > 1e8 and e["pairs_per_s_fresh_arrays"] > 1e8 and e["pairs_per_s_call_and_drop_loop"] > 1e8
     assert d["mrca_ids_only"]["matches_the_fused_launch"] and d["mrca_ids_only"]["ids_per_s"] > 1e9
+    # ceilings are the best of a sweep of launch shapes, and the shape is reported
+    hw = d["hardware_measured"]
+    assert hw["table"]["shapes_swept"] >= 9 and hw["table"]["best_shape"]["unroll"] in (4, 8, 16)
+    assert hw["stream_copy_shapes_swept"] >= 8 and hw["stream_copy_GBps"] > 3000
+    # the other BASELINE configs ride in the same line (driver-observed numbers for configs 2, 4, 5)
+    oc = d["other_configs"]
+    for key in ("config2_ml_tree", "config2_nj_tree", "config4_triangle_100k", "config5_fish_worm"):
+        assert "error" not in oc[key], oc[key]
+    for key in ("config2_ml_tree", "config2_nj_tree"):
+        c = oc[key]
+        assert c["canopy"]["bit_exact_on_sample"] and c["walk"]["bit_exact_on_sample"] and c["host_path"]["bit_exact_on_sample"]
+        assert c["canopy"]["pairs_per_s"] > 1e9 and c["walk"]["pairs_per_s"] > 1e9 and c["algorithmic_bytes_per_pair"] > 500
+    t = oc["config4_triangle_100k"]
+    assert t["pairs"] == 4_999_950_000 and t["bit_exact_on_sample"] and t["canopy"]["pairs_per_s"] > 1e10
+    assert t["streamed_to_host"]["pairs"] == 1 << 30 and t["streamed_to_host"]["pairs_per_s"] > 1e9
+    f = oc["config5_fish_worm"]
+    assert f["distances_bit_exact"] and f["laplacian_bit_exact"] and f["pairs"] == 2 * 18145 and f["laplacian_shape"] == [422, 422]
 
 
 def test_bench_under_torchrun_one_rank():
@@ -44,10 +61,13 @@ def test_bench_under_torchrun_one_rank():
     1-GPU box can run of it; the slicing / gather itself is covered by the gloo tests."""
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "2000000", "--no-cpu-baseline",
-                          "--no-host-path", "--no-microbench"], capture_output=True, text=True, timeout=900)
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "2000000", "--cpu-seconds", "1",
+                          "--no-host-path", "--no-microbench", "--no-other-configs"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 1e8
+    # the CPU baseline and the parity block are produced under the process group too (every N)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"]["distances_bit_exact"] and d["parity"]["mrca_bit_exact"]

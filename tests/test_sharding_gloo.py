@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size-2 gloo process group, pairs sharded across
+"""The N>1 path on CPU: gloo process groups of 2, 3 and 4 ranks, pairs sharded across
 ranks, result slices all-gathered.  The compute step is the oracle (a checker,
 injected) because the product path refuses to run without a GPU; what is under
 test is the partitioning and the gather, which are the same code on RCCL."""
@@ -101,49 +101,55 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs,chunks,root,root_share", [(1001, 3, 0, None), (4, 4, 0, None), (777, 1, 1, None),
-                                                            (1001, 4, 0, 0.8), (1001, 2, 1, 0.37), (50, 3, 0, 1.0)])
-def test_run_sharded_world_size_2_gloo(n_pairs, chunks, root, root_share):
+@pytest.mark.parametrize("world,n_pairs,chunks,root,root_share", [
+    (2, 1001, 3, 0, None), (2, 4, 4, 0, None), (2, 777, 1, 1, None), (2, 1001, 4, 0, 0.8), (2, 1001, 2, 1, 0.37), (2, 50, 3, 0, 1.0),
+    # more than one peer: the root posts receives from several ranks per piece, peers are indexed around the root
+    (3, 1001, 4, 0, None), (3, 1001, 1, 1, 0.5), (3, 1000, 4, 2, 0.31), (4, 1001, 4, 0, 0.5), (4, 1003, 1, 2, None),
+    (4, 1003, 4, 1, 0.41), (4, 3, 4, 0, None), (4, 1001, 3, 3, 0.9)])
+def test_run_sharded_gloo(world, n_pairs, chunks, root, root_share):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_run_sharded, args=(r, 2, port, n_pairs, chunks, root, q, root_share))
-             for r in range(2)]
+    procs = [ctx.Process(target=_worker_run_sharded, args=(r, world, port, n_pairs, chunks, root, q, root_share))
+             for r in range(world)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in procs)
     [p.join(timeout=60) for p in procs]
-    assert [r[1] for r in res] == [True, True]
+    assert [r[1] for r in res] == [True] * world
     assert all(p.exitcode == 0 for p in procs)
 
 
-def _worker_measure(rank, world, port, q):
+def _worker_measure(rank, world, port, root, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # each rank passes a different kernel rate: the root's must win, and everyone must agree
-        share, link, k = sharding.measure_root_share(world, rank, 1e9 * (rank + 1), nbytes=1 << 20)
+        share, link, k = sharding.measure_root_share(world, rank, 1e9 * (rank + 1), nbytes=1 << 20, root=root)
         q.put((rank, share, link, k))
     finally:
         dist.destroy_process_group()
 
 
-def test_measure_root_share_world_size_2_gloo():
-    """bench.py's calibration step (batched point-to-point transfers into the root + broadcast)."""
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 0), (4, 0), (4, 2)])
+def test_measure_root_share_gloo(world, root):
+    """bench.py's calibration step (batched point-to-point transfers from every peer into the root at
+    once + broadcast of the root's decision)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_measure, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_measure, args=(r, world, port, root, q)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in procs)
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (r0, s0, l0, k0), (r1, s1, l1, k1) = res
-    assert (s0, l0, k0) == (s1, l1, k1) and k0 == 1e9 and l0 > 0 and 0.5 <= s0 <= 0.95
-    assert s0 == min(0.95, max(0.5, sharding.balanced_root_share(2, 1e9, l0)))
+    s0, l0, k0 = res[0][1:]
+    assert all(r[1:] == (s0, l0, k0) for r in res)
+    assert k0 == 1e9 * (root + 1) and l0 > 0 and 1.0 / world <= s0 <= 0.95
+    assert s0 == min(0.95, max(1.0 / world, sharding.balanced_root_share(world, k0, l0)))
 
 
 def test_balanced_root_share():
