@@ -376,27 +376,3 @@ def test_sharded_device_path_with_rccl_single_rank(ml_arrays):
     assert (lo, hi) == (0, 100_001) and torch.equal(ds, d) and torch.equal(ms, m)
     assert_bits_equal(d.cpu().numpy(), O.distances(host))
     assert np.array_equal(m.cpu().numpy(), O.mrca_bulk(host))
-
-
-def test_sample_linked_distances_statistics():
-    d = golden_path("fish_worm")
-    links = pd.read_csv(d + "/links.csv", index_col=0)
-    SLT = SuchLinkedTrees(SuchTree(d + "/host.tree"), SuchTree(d + "/guest.tree"), links)
-    exact = SLT.linked_distances()
-    res = SLT.sample_linked_distances(sigma=0.05, buckets=16, n=2048, maxcycles=50, seed=1)
-    assert res is not None and res["n_samples"] == len(res["TreeA"]) == len(res["TreeB"])
-    assert res["n_samples"] % (16 * 2048) == 0 and res["n_pairs"] == 191 * 190 / 2
-    assert res["deviation_a"] < 0.05 and res["deviation_b"] < 0.05
-    # every sampled value is a real link-pair distance (or 0 for a link paired with itself); the
-    # sampler draws ordered pairs, and d(a,b) vs d(b,a) may differ in the last float32 ulp
-    for key in ("TreeA", "TreeB"):
-        known = np.unique(np.concatenate([exact[key], [0.0]]))
-        got = np.unique(res[key])
-        pos = np.clip(np.searchsorted(known, got), 1, len(known) - 1)
-        nearest = np.where(np.abs(known[pos] - got) < np.abs(known[pos - 1] - got), known[pos], known[pos - 1])
-        assert np.all(np.abs(nearest - got) <= 1e-6 * np.maximum(np.abs(got), 1e-9)), key
-    # sampling with replacement over ordered link pairs: mean = (L-1)/L * mean over unordered pairs
-    L = SLT.n_links
-    assert abs(res["TreeA"].mean() - exact["TreeA"].mean() * (L - 1) / L) < 0.02 * exact["TreeA"].mean()
-    assert abs(res["TreeB"].mean() - exact["TreeB"].mean() * (L - 1) / L) < 0.02 * exact["TreeB"].mean()
-    assert SLT.sample_linked_distances(sigma=1e-12, buckets=4, n=256, maxcycles=2, seed=2) is None
