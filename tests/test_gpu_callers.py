@@ -376,3 +376,81 @@ def test_sharded_device_path_with_rccl_single_rank(ml_arrays):
     assert (lo, hi) == (0, 100_001) and torch.equal(ds, d) and torch.equal(ms, m)
     assert_bits_equal(d.cpu().numpy(), O.distances(host))
     assert np.array_equal(m.cpu().numpy(), O.mrca_bulk(host))
+
+
+def _sum_of_all_pairwise_distances(parent, dist, n_leaves_total):
+    """Closed form, float64: every edge e contributes length(e) * s(e) * (m - s(e)) to the sum over all
+    unordered leaf pairs, s(e) = leaves below e.  Children have smaller depth-order than parents in a
+    pass from the deepest node up; here a plain accumulation over nodes sorted by depth."""
+    from suchtree_amd.newick import node_depths
+    n = len(parent)
+    depth = node_depths(parent)
+    below = np.zeros(n, dtype=np.int64)
+    is_leaf = np.ones(n, dtype=bool)
+    is_leaf[parent[parent >= 0]] = False
+    below[is_leaf] = 1
+    for x in np.argsort(-depth, kind="stable"):          # deepest first: a node is complete before its parent
+        p = parent[x]
+        if p >= 0:
+            below[p] += below[x]
+    s = below.astype(np.float64)
+    w = dist.astype(np.float64)
+    inner = parent >= 0
+    return float(np.sum(w[inner] * s[inner] * (n_leaves_total - s[inner])))
+
+
+def test_config4_full_triangle_streamed_to_host(monkeypatch):
+    """BASELINE config 4 at FULL size: all 4,999,950,000 pairs of the 100,000-leaf lower triangle in
+    linked_distances order (MuchTree.pyx:2918-2925) streamed through st_triangle_host, tile by tile, into
+    one reused host buffer.  Per tile: a sampled oracle check; on some tiles walk == canopy bit for bit;
+    over the whole stream: exact pair count, the closed-form sum of all pairwise distances, and the same
+    stream once more through a two-device handle (both entries device 0) so that the dealing of chunks
+    over devices runs at this size -- every tile's checksum must be identical."""
+    m = 100_000
+    parent, dist = synth.complete_tree(m, seed=44)
+    O = OracleTree(parent, dist)
+    ids = np.arange(0, 2 * m, 2, dtype=np.int64)
+    total = m * (m - 1) // 2
+    assert total == 4_999_950_000
+    tile = 1 << 26
+    buf = np.empty(tile, dtype=np.float64)
+    buf_w = np.empty(1 << 22, dtype=np.float64)
+    rng = np.random.default_rng(44)
+
+    def stream(dev, check):
+        sums, done, t = [], 0, 0
+        while done < total:
+            c = min(tile, total - done)
+            dev.triangle_host(ids, k_begin=done, k_count=c, out_dist=buf[:c])
+            sums.append(float(buf[:c].sum()))
+            if check:
+                pick = np.unique(np.concatenate([[0, c - 1], rng.integers(0, c, 1500)]))
+                kk = done + pick
+                rows = sharding.triangle_row_of(kk)
+                cols = kk - rows * (rows - 1) // 2
+                assert_bits_equal(buf[pick], O.distances(np.stack([ids[cols], ids[rows]], 1)), "tile %d" % t)
+                if t % 16 == 5:        # a window of the same tile by the other kernel family
+                    w0 = int(rng.integers(0, max(1, c - len(buf_w))))
+                    wn = min(len(buf_w), c - w0)
+                    dev.set_strategy("walk")
+                    dev.triangle_host(ids, k_begin=done + w0, k_count=wn, out_dist=buf_w[:wn])
+                    dev.set_strategy("auto")
+                    assert_bits_equal(buf_w[:wn], buf[w0:w0 + wn], "walk vs canopy, tile %d" % t)
+            done += c
+            t += 1
+        assert done == total and t == (total + tile - 1) // tile
+        return sums
+
+    dev = _capi.DeviceTree(parent, dist)
+    assert dev.info()["strategy"] == "canopy"
+    sums = stream(dev, True)
+    dev.close()
+    want = _sum_of_all_pairwise_distances(parent, dist, m)
+    assert abs(sum(sums) - want) <= 1e-6 * want          # float32 sums per pair, 5e9 of them, against float64
+
+    monkeypatch.setenv("SUCHTREE_AMD_ALLOW_DUPLICATE_DEVICES", "1")
+    T = SuchTree((parent, dist), devices=[0, 0])
+    dev2 = T._device_tree()
+    assert dev2.info()["n_devices"] == 2
+    sums2 = stream(dev2, False)
+    assert sums2 == sums
