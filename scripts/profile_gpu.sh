@@ -13,14 +13,14 @@ mkdir -p $OUT $REPO/scripts/micro/bin
 # the calibration program (known traffic) is built on demand; binaries are not kept in git
 [ -x $REPO/scripts/micro/bin/calib_requests ] || hipcc --offload-arch=gfx950 -O3 -o $REPO/scripts/micro/bin/calib_requests $REPO/scripts/micro/calib_requests.hip
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
+timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" ; do
   N=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$N.log 2>&1
   echo "pmc $N rc=$?"
   # the same counters on two launches of exactly known traffic (scripts/micro/calib_requests.hip)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cal_$N -- $REPO/scripts/micro/bin/calib_requests > $OUT/cal_$N.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/cal_$N -- $REPO/scripts/micro/bin/calib_requests > $OUT/cal_$N.log 2>&1
   echo "cal $N rc=$?"
 done
 cd $REPO

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: arbitrary PMC counter sets (one pass per quoted set) over one tune_gpu.py run.
+# Every pass runs under `timeout` (a counter set the hardware cannot collect makes rocprofv3 abort and then hang).
 # usage: COUNTERS="A B;C D" scripts/profile_pmc.sh <tag> <tune_gpu.py args...>
 TAG=$1; shift
 REPO=$(pwd)
@@ -9,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 IFS=';' read -ra SETS <<< "$COUNTERS"
 for C in "${SETS[@]}"; do
   N=$(echo $C | cut -d' ' -f1)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$N -- python3 $REPO/scripts/tune_gpu.py "$@" > $OUT/$N.log 2>&1
+  timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$N -- python3 $REPO/scripts/tune_gpu.py "$@" > $OUT/$N.log 2>&1
   echo "pmc $N rc=$?"; grep -i "error\|invalid\|not found" $OUT/$N.log | head -2
 done
 cd $REPO

@@ -201,14 +201,27 @@ static WalkParams walk_params(const st_tree *t)
     P.stride = t->d_stride;
     P.rmq = t->tree_rmq ? t->d_tree_rmq : nullptr;
     P.n_nodes = t->n_nodes;
-    if (t->d_lineage && t->lineage_sums) {
-        P.lineage.rec_p = t->d_rec_p;
-        P.lineage.node_off = t->d_lineage_node_off;
+    if (t->d_lineage && t->d_lineage_node_rec && t->lineage_sums) {
+        P.lineage.node_rec = t->d_lineage_node_rec;
         P.lineage.sums = t->d_lineage;
-        P.lineage.n_leaves = t->n_leaves;
-        P.lineage.parity = t->parity != 0;
+        P.lineage.lens = t->lineage_lens ? t->d_lineage_len : nullptr;
+        P.lineage.shared_blocks = t->walk_crown != 0;
+        if (t->walk_crown && t->d_crown_rmq) {
+            P.lineage.crown_rmq = t->d_crown_rmq;
+            P.lineage.crown_nodes = t->crown_nodes;
+        }
     }
     return P;
+}
+
+// Smallest batch the tile-sorted walk kernel takes (below it k_walk's shorter start-up wins).
+constexpr int64_t kWalkSortedMinPairs = 32768;
+constexpr int kWalkSortQ = 4;      // 4096-pair tiles: 57 KiB of LDS scratch, two workgroups per CU
+
+static bool walk_sorted_ready(const st_tree *t)
+{
+    return t->walk_sort && t->tree_rmq && t->d_tree_rmq && t->lineage_sums && t->d_lineage && t->d_lineage_node_rec &&
+           t->lineage_lens && t->d_lineage_len;
 }
 
 template <typename Src>
@@ -216,6 +229,15 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
                               int32_t *out_m, Fault *fault, hipStream_t stream)
 {
     const WalkParams P = walk_params(t);
+    if (out_d.any() && n >= kWalkSortedMinPairs && walk_sorted_ready(t)) {
+        constexpr int64_t tile = (int64_t)kWalkSortQ * kWalkSortBlock;
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + tile - 1) / tile, (int64_t)t->n_cu * 2));
+        int key_shift = 0;      // keys are edge counts of b's lineage below the meeting node
+        while ((t->info.depth >> key_shift) >= kWalkSortBuckets) key_shift++;
+        hipLaunchKernelGGL((k_walk_sorted<kWalkSortQ, Src>), dim3((unsigned)blocks), dim3(kWalkSortBlock),
+                           walk_sort_scratch_bytes(kWalkSortQ), stream, P, src, (long long)n, out_d, out_m, fault, key_shift);
+        return hipGetLastError();
+    }
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
     blocks = std::max<int64_t>(blocks, 1);

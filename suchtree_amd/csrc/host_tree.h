@@ -56,7 +56,10 @@ struct st_tree {
     uint64_t *d_rmq64 = nullptr;
     uint32_t *d_rec_r = nullptr;      // MRCA-only queries (in-order ids), else NULL
     float *d_lineage = nullptr;
-    uint32_t *d_lineage_node_off = nullptr;   // walk-only trees: lineage offsets by node id
+    float *d_lineage_len = nullptr;           // lineage lengths (same blocks as d_lineage), else NULL
+    uint32_t *d_lineage_node_rec = nullptr;   // {depth, lineage offset, portal's lineage offset, nb | portal rank << 8} by node id
+    uint64_t *d_crown_rmq = nullptr;          // sparse table over the walk family's crown (in-order ids), else NULL
+    int32_t crown_nodes = 0;
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the
     // device pipe's mutex) and is never confused by a caller who skipped st_fault_check
@@ -70,6 +73,9 @@ struct st_tree {
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
     int tree_rmq = 1;         // tuning: 0 = the walk family searches the meeting node by climbing even when the whole-tree sparse table exists
     int mrca_ranks = 1;       // tuning: 0 = MRCA-only requests go through the distance kernels
+    int walk_crown = 1;       // tuning: 0 = the walk family streams b's side from b's own block alone and finds meeting nodes in the whole-tree table
+    int walk_sort = 1;        // tuning: 0 = the walk family never uses its tile-sorted kernel (k_walk_sorted)
+    int lineage_lens = 1;     // tuning: 0 = the walk family climbs b's lineage through the stride-3 image even when the lineage-length table exists
     int lineage_sums = 1;     // tuning: 0 = the tile-sorted kernel climbs a's canopy lineage even when the lineage-sum table exists
     LadderEntry *d_ladder = nullptr;
     uint16_t *d_cdepth = nullptr;

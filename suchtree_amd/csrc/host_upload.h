@@ -10,7 +10,27 @@ struct BuiltTables {
     bool deep = false;
 };
 
-static int build_tables(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
+// Budget of the OPTIONAL walk-family tables of a tree the canopy family does not serve (whole-tree
+// sparse table, lineage sums, lineage lengths), in bytes: SUCHTREE_AMD_WALK_TABLE_MB (default 12288;
+// 0 = build none of them: the walk kernel then climbs).  They are aids, never requirements: a table
+// over budget, or one that later does not fit the device, is simply left out.
+static int64_t walk_table_budget()
+{
+    int64_t mb = 12288;
+    if (const char *env = std::getenv("SUCHTREE_AMD_WALK_TABLE_MB")) mb = std::atoll(env);
+    return std::max<int64_t>(0, mb) << 20;
+}
+
+// Lineage-length bytes the crown's (shared) blocks may occupy: small enough to live in an XCD's
+// 4 MiB L2 next to the streams.  SUCHTREE_AMD_CROWN_KB: tuning experiments.
+static int64_t crown_hot_budget()
+{
+    int64_t kb = 1024;
+    if (const char *env = std::getenv("SUCHTREE_AMD_CROWN_KB")) kb = std::atoll(env);
+    return std::max<int64_t>(1, kb) << 10;
+}
+
+static int build_tables_impl(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
 {
     std::string err;
     if (!prepare_basic(parent, distance, n_nodes, B.T, err)) return fail(ST_ERR_TREE, err);
@@ -33,22 +53,71 @@ static int build_tables(const int32_t *parent, const float *distance, int64_t n_
                     TreeTables T2 = B.T;
                     if (prepare_canopy(parent, distance, T2, deep_nodes)) B.T = std::move(T2);
                 }
-                // a's side of every pair from one read (tree_prep.h: lineage sums); 4 bytes per
-                // node and level, so only while the table stays below kMaxLineageEntries
-                (void)prepare_lineage_sums(B.T, kMaxLineageEntries);
+                // a's side of every pair from one read (tree_prep.h: lineage sums), b's side of the walk
+                // family as a stream (lineage lengths); 4 bytes per node and level each, so only while
+                // the table stays below kMaxLineageEntries
+                if (prepare_lineage_sums(B.T, kMaxLineageEntries)) (void)prepare_walk_crown(B.T, crown_hot_budget());
             }
         }
     }
-    if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
-    // a tree that only the walk family serves (canopy refused, or asked for) gets the whole-tree
-    // sparse table up to 4 GiB: the meeting node in two reads instead of a lock-step climb of both
-    // lineages matters most exactly there (large, deep trees)
-    if (!B.canopy_ok && B.T.tree_rmq.empty()) (void)build_tree_rmq(B.T, kMaxTreeRmqBytesWalkOnly);
-    // ... and lineage sums (a's side of a pair in one read; offsets by node id), up to 4 GiB
-    if (!B.canopy_ok) (void)prepare_walk_lineage(B.T, kMaxWalkLineageEntries);
     if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
         return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
+    if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
+    if (!B.canopy_ok) {
+        // a tree that only the walk family serves (canopy refused, or asked for) gets the whole-tree
+        // sparse table beyond prepare_basic's 64 MB -- the meeting node in two reads instead of a
+        // lock-step climb of both lineages matters most exactly there (large, deep trees) -- and the
+        // lineage tables with offsets by node id (a's side in one read, b's side as a stream), all
+        // within walk_table_budget()
+        int64_t budget = walk_table_budget();
+        if (B.T.tree_rmq.empty() && budget > 0) (void)build_tree_rmq(B.T, std::min<int64_t>(budget, kMaxTreeRmqBytesWalkOnly));
+        if (budget > 0) {
+            budget -= (int64_t)B.T.tree_rmq.size() * 8;
+            // sums + lens when both fit, else the sums alone
+            if (!prepare_walk_lineage(B.T, std::min<int64_t>(budget / 8, kMaxWalkLineageEntries), true))
+                (void)prepare_walk_lineage(B.T, std::min<int64_t>(budget / 4, kMaxWalkLineageEntries), false);
+            if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget());
+        }
+    }
     return ST_OK;
+}
+
+// Nothing may be thrown through the C ABI: allocation failures of the (large) optional tables
+// become ST_ERR_NOMEM.
+static int build_tables(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
+{
+    try {
+        return build_tables_impl(parent, distance, n_nodes, strategy, B);
+    } catch (const std::bad_alloc &) {
+        return fail(ST_ERR_NOMEM, "out of host memory while building the tree tables");
+    } catch (const std::exception &e) {
+        return fail(ST_ERR_NOMEM, std::string("building the tree tables failed: ") + e.what());
+    }
+}
+
+// An optional table: uploaded when it fits comfortably (at most half of the device memory that is
+// free right now), left out -- pointer NULL, kernels use the form without it -- otherwise, and also
+// when its allocation or copy fails.  Never an error.
+template <typename P, typename V>
+static bool upload_optional(P **dst, const V &v, int64_t *bytes)
+{
+    *dst = nullptr;
+    if (v.empty()) return false;
+    size_t free_b = 0, total_b = 0;
+    const size_t need = v.size() * sizeof(v[0]);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 2) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const std::string keep = g_last_error;
+    if (upload(dst, v, bytes) != ST_OK) {
+        if (*dst) (void)hipFree(*dst);
+        *dst = nullptr;
+        (void)hipGetLastError();
+        g_last_error = keep;
+        return false;
+    }
+    return true;
 }
 
 static int upload_tree(BuiltTables &B, int device, st_tree **out)
@@ -75,11 +144,20 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     int rc = upload(&t->d_nodes, T.nodes, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_stride, T.stride, &bytes);
-    if (rc == ST_OK && !T.tree_rmq.empty()) rc = upload(&t->d_tree_rmq, T.tree_rmq, &bytes);
-    if (rc == ST_OK && !B.canopy_ok && !T.lineage_node_off.empty()) {
-        rc = upload(&t->d_lineage_node_off, T.lineage_node_off, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
-    }
+    if (rc == ST_OK) (void)upload_optional(&t->d_tree_rmq, T.tree_rmq, &bytes);
+    // lineage tables of the walk family: {node_rec, sums} or nothing; lengths and the crown's table are further options
+    auto upload_walk_lineage = [&]() {
+        if (T.lineage_node_rec.empty() || T.lineage_sum.empty()) return;
+        if (!upload_optional(&t->d_lineage_node_rec, T.lineage_node_rec, &bytes)) return;
+        if (!t->d_lineage && !upload_optional(&t->d_lineage, T.lineage_sum, &bytes)) {
+            (void)hipFree(t->d_lineage_node_rec);
+            t->d_lineage_node_rec = nullptr;
+            return;
+        }
+        (void)upload_optional(&t->d_lineage_len, T.lineage_len, &bytes);
+        if (upload_optional(&t->d_crown_rmq, T.crown_rmq, &bytes)) t->crown_nodes = T.crown_nodes;
+    };
+    if (rc == ST_OK && !B.canopy_ok) upload_walk_lineage();
     if (rc == ST_OK && B.canopy_ok) {
         t->has_canopy = true;
         t->canopy_nodes = T.canopy_nodes;
@@ -109,8 +187,14 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
             if (rc == ST_OK) rc = upload(&t->d_rmq64, T.canopy_rmq64, &bytes);
         }
         if (rc == ST_OK && t->d_rmq && t->d_rmq64 && !T.lineage_sum.empty()) {
-            rc = upload(&t->d_rec_p, T.rec_p, &bytes);
-            if (rc == ST_OK) rc = upload(&t->d_lineage, T.lineage_sum, &bytes);
+            if (upload_optional(&t->d_rec_p, T.rec_p, &bytes)) {
+                if (!upload_optional(&t->d_lineage, T.lineage_sum, &bytes)) {
+                    (void)hipFree(t->d_rec_p);
+                    t->d_rec_p = nullptr;
+                } else {
+                    upload_walk_lineage();      // (the walk family's view of the same sums)
+                }
+            }
         }
     }
     if (rc == ST_OK) {

@@ -41,6 +41,163 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
     }
 }
 
+// Tile-sorted form of k_walk for trees that have the whole-tree sparse table and both lineage tables
+// (tree_prep.h): large AND deep trees the canopy family refuses, and deep-canopy trees when the walk
+// family is asked for.  There a pair costs two table reads for the meeting node, one read for a's
+// whole side and k_b consecutive floats for b's side -- and k_b is anything from 0 to the depth of
+// the tree, so in k_walk a wave is as slow as its longest lane (counters on data/bigtrees/ml.tree:
+// 103 scattered load instructions per 64 pairs where the mean lane needs 28).  Here a workgroup
+// takes a tile of Q * 1024 pairs.  Key phase (input order, the Q chains of a lane in flight
+// together): {depth, offset} of both nodes, the meeting node, a's side; the MRCA id leaves at once,
+// coalesced; a's side, b's offset and k_b stay in LDS.  The tile is counting-sorted by k_b, every
+// wave streams 64 pairs of similar length (sorted groups w, 31 - w, ...: short with long), and the
+// distances leave together in input order, coalesced.  Every pair is read once and every store is
+// coalesced, so the kernel may also work on pinned host memory.  Same operands, same order of
+// additions as k_walk.
+constexpr int kWalkSortBlock = 1024;
+constexpr int kWalkSortBuckets = 256;
+__host__ __device__ constexpr size_t walk_sort_scratch_bytes(int q)
+{
+    return (size_t)q * kWalkSortBlock * 18 + (size_t)kWalkSortBuckets * 4 + 64;
+}
+
+template <int Q, typename Src>
+__global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Src src, long long n, DistSink out_d,
+                                                                 int *__restrict__ out_m, Fault *fault, int key_shift)
+{
+    extern __shared__ __align__(16) unsigned char walk_lds[];
+    constexpr int kTile = Q * kWalkSortBlock;
+    uint32_t *HIST = reinterpret_cast<uint32_t *>(walk_lds);     // [kWalkSortBuckets] counts, then exclusive starts
+    uint32_t *WSUM = HIST + kWalkSortBuckets;                    // [4] scan carries, [4] = pairs to stream
+    uint32_t *KB = WSUM + 16;                                    // [kTile] b's edges below the meeting node | nodes of b below its portal << 24
+    float *SIDE = reinterpret_cast<float *>(KB + kTile);         // [kTile] a's side of the pair, then its distance
+    uint32_t *OFFB = reinterpret_cast<uint32_t *>(SIDE + kTile); // [kTile] offset of b's block in the lineage tables
+    uint32_t *OFFP = OFFB + kTile;                               // [kTile] offset of the block of b's portal
+    uint16_t *PERM = reinterpret_cast<uint16_t *>(OFFP + kTile); // [kTile] sorted position -> pair of the tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LineageView &lin = P.lineage;
+    for (long long base = (long long)blockIdx.x * kTile; base < n; base += (long long)gridDim.x * kTile) {
+        if (threadIdx.x < kWalkSortBuckets) HIST[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t key[Q], rank[Q];
+        {
+            long long a_[Q], b_[Q];
+            bool in_[Q], valid_[Q];
+            NodeKey ka_[Q], kb_[Q];
+            uint64_t e1_[Q], e2_[Q];
+            float side_[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const long long i = base + (int)threadIdx.x + q * kWalkSortBlock;
+                in_[q] = i < n;
+                a_[q] = 0;
+                b_[q] = 0;
+                if (in_[q]) src.load(i, a_[q], b_[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                valid_[q] = (unsigned long long)a_[q] < (unsigned long long)P.n_nodes &&
+                            (unsigned long long)b_[q] < (unsigned long long)P.n_nodes;
+                ka_[q] = lineage_key(lin, valid_[q] ? (int32_t)a_[q] : 0);
+                kb_[q] = lineage_key(lin, valid_[q] ? (int32_t)b_[q] : 0);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                // the meeting node: of the two portals in the crown's table when they differ (a few
+                // hundred KB, cache resident), else of the two nodes in the whole-tree table
+                const uint32_t ra = ka_[q].nb_rank >> 8, rb = kb_[q].nb_rank >> 8;
+                const bool crown = lin.crown_rmq != nullptr && ra != rb;
+                const uint32_t a = crown ? ra : (valid_[q] ? (uint32_t)a_[q] : 0u), b = crown ? rb : (valid_[q] ? (uint32_t)b_[q] : 0u);
+                const uint64_t *tab = crown ? lin.crown_rmq : P.rmq;
+                const size_t width = crown ? (size_t)lin.crown_nodes : (size_t)P.n_nodes;
+                const uint32_t l = a < b ? a : b, r = a < b ? b : a;
+                const uint32_t len = r - l + 1;
+                const uint32_t k = 31u - (uint32_t)__clz((int)len);      // floor(log2(len))
+                e1_[q] = tab[(size_t)k * width + l];
+                e2_[q] = tab[(size_t)k * width + (r + 1 - (1u << k))];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                e1_[q] = e2_[q] < e1_[q] ? e2_[q] : e1_[q];      // the meeting node: depth << 32 | id
+                side_[q] = lin.sums[(size_t)ka_[q].off + (size_t)(ka_[q].depth - (uint32_t)(e1_[q] >> 32))];
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = (int)threadIdx.x + q * kWalkSortBlock;
+                const long long i = base + j;
+                key[q] = 0xFFFFFFFFu;
+                rank[q] = 0;
+                if (!in_[q]) continue;
+                if (!valid_[q]) {
+                    record_fault(fault, a_[q], b_[q], P.n_nodes);
+                    SIDE[j] = __builtin_nanf("");
+                    if (out_m) out_m[i] = -1;
+                    continue;
+                }
+                if (out_m) out_m[i] = (int)(uint32_t)e1_[q];
+                const uint32_t kb = kb_[q].depth - (uint32_t)(e1_[q] >> 32);
+                KB[j] = kb | ((kb_[q].nb_rank & 0xFFu) << 24);      // (k_b < 2^24: the lineage tables exist)
+                SIDE[j] = side_[q];
+                OFFB[j] = kb_[q].off;
+                OFFP[j] = kb_[q].portal_off;
+                const uint32_t k = kb >> key_shift;
+                key[q] = k < (uint32_t)kWalkSortBuckets - 1 ? k : (uint32_t)kWalkSortBuckets - 1;
+                rank[q] = atomicAdd(&HIST[key[q]], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the 256 bucket counts (4 waves of 64)
+        uint32_t cnt = 0, incl = 0;
+        if (threadIdx.x < kWalkSortBuckets) {
+            cnt = HIST[threadIdx.x];
+            incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) WSUM[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < kWalkSortBuckets) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += WSUM[w];
+            HIST[threadIdx.x] = carry + incl - cnt;
+            if (threadIdx.x == kWalkSortBuckets - 1) WSUM[4] = carry + incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+            if (key[q] != 0xFFFFFFFFu) PERM[HIST[key[q]] + rank[q]] = (uint16_t)((int)threadIdx.x + q * kWalkSortBlock);
+        __syncthreads();
+        const uint32_t total = WSUM[4];
+#pragma unroll 1
+        for (int q = 0; q < Q; q++) {
+            const uint32_t pos = (uint32_t)((q * 16 + ((q & 1) ? 15 - wave : wave)) * 64 + lane);
+            if (pos >= total) continue;
+            const int j = PERM[pos];
+            const int32_t kb = (int32_t)(KB[j] & 0xFFFFFFu), nb = (int32_t)(KB[j] >> 24);
+            float s = SIDE[j];
+            if (!lin.shared_blocks || kb <= nb) {
+                s = stream_sum(lin.lens + OFFB[j], s, kb);
+            } else {      // below the portal from b's own block, above it from the portal's (shared, cache resident)
+                s = stream_sum(lin.lens + OFFB[j], s, nb);
+                s = stream_sum(lin.lens + OFFP[j], s, kb - nb);
+            }
+            SIDE[j] = s;
+        }
+        __syncthreads();
+        if (out_d.any()) {
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const int j = (int)threadIdx.x + q * kWalkSortBlock;
+                if (base + j < n) store_result(out_d, nullptr, base + j, SIDE[j], 0);
+            }
+        }
+        __syncthreads();     // the next tile overwrites the scratch
+    }
+}
+
 // The mailbox form of k_walk (small host batches, one lane per pair, no grid stride): pairs and
 // results live in pinned host memory, and so does a completion word -- the last workgroup to
 // finish publishes the call's sequence number there (system-scope release after every block's

@@ -78,36 +78,115 @@ ST_HD float walk_sum(const Stride3 *__restrict__ stride, float s, int32_t u, int
     return s;
 }
 
-// Lineage sums for the walk family (tree_prep.h; NULL when the tree has none): a's side of
-// a pair is lineage[offset of a + edges of a below the meeting node], the offset being the
-// second word of rec_p at a's record slot.
+// Lineage tables for the walk family (tree_prep.h; NULL when the tree has none): a's side of a
+// pair is sums[offset of a + edges of a below the meeting node]; b's side continues that
+// accumulator with the first k_b lineage lengths of b, consecutive floats: b's own block for the
+// nodes below its portal, then its portal's block (the same floats as the rest of its own block,
+// but shared by every node below that portal: a hot set of a few MB).  node_rec[4 x ..] = {depth,
+// offset of x's block, offset of its portal's block, nodes below the portal | rank of the portal
+// << 8}.  crown_rmq: the meeting node of two nodes with different portals from a table over the
+// crown alone.
 struct LineageView {
-    const uint8_t *rec_p = nullptr;
-    const uint32_t *node_off = nullptr;   // walk-only trees: offsets by node id instead of rec_p
+    const uint32_t *node_rec = nullptr;
     const float *sums = nullptr;
-    int64_t n_leaves = 0;
-    bool parity = false;
+    const float *lens = nullptr;          // lineage lengths (same blocks), or NULL: b's side climbs the stride-3 image
+    const uint64_t *crown_rmq = nullptr;  // or NULL: meeting nodes from the whole-tree table / by climbing
+    int32_t crown_nodes = 0;
+    bool shared_blocks = false;           // b's stream switches to its portal's block above the portal
 };
+
+struct alignas(16) NodeKey {
+    uint32_t depth, off, portal_off, nb_rank;
+};
+
+ST_HD NodeKey lineage_key(const LineageView &lin, int32_t x)
+{
+    return *reinterpret_cast<const NodeKey *>(lin.node_rec + (size_t)x * 4);
+}
+
+// Meeting node (depth << 32 | node id) of two nodes whose portals differ, from their ranks.
+ST_HD uint64_t crown_meet(const uint64_t *__restrict__ rmq, int32_t n_crown, uint32_t ra, uint32_t rb)
+{
+    const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
+    const uint32_t len = r - l + 1;
+    uint32_t k = 0;
+    while ((2u << k) <= len) k++;
+    const uint64_t e1 = rmq[(size_t)k * (size_t)n_crown + l];
+    const uint64_t e2 = rmq[(size_t)k * (size_t)n_crown + (r + 1 - (1u << k))];
+    return e2 < e1 ? e2 : e1;
+}
+
+struct alignas(16) Quad {
+    float x, y, z, w;
+};
+
+// s += p[0]; s += p[1]; ... s += p[k-1], in that order (the reference's b-side loop, pyx:939-942,
+// over operands laid out contiguously).  p is 16-byte aligned and its block is padded to whole
+// quads, so every load is one aligned 16-byte read; the loads do not depend on each other.
+ST_HD float stream_sum(const float *__restrict__ p, float s, int32_t k)
+{
+    const Quad *__restrict__ q = reinterpret_cast<const Quad *>(p);
+    while (k >= 16) {      // one 64-byte sector per trip
+        const Quad a = q[0], b = q[1], c = q[2], d = q[3];
+        q += 4;
+        k -= 16;
+        s += a.x; s += a.y; s += a.z; s += a.w;
+        s += b.x; s += b.y; s += b.z; s += b.w;
+        s += c.x; s += c.y; s += c.z; s += c.w;
+        s += d.x; s += d.y; s += d.z; s += d.w;
+    }
+    while (k >= 4) {
+        const Quad a = *q++;
+        k -= 4;
+        s += a.x; s += a.y; s += a.z; s += a.w;
+    }
+    if (k) {
+        const Quad a = *q;
+        s += a.x;
+        if (k > 1) s += a.y;
+        if (k > 2) s += a.z;
+    }
+    return s;
+}
+
+// b's side: k_b lineage lengths of b onto s, in lineage order -- in one piece from b's own block,
+// or (shared blocks) the part below the portal from b's block and the rest from the portal's.
+ST_HD float stream_b(const LineageView &lin, const NodeKey &kb, float s, int32_t k)
+{
+    const int32_t nb = (int32_t)(kb.nb_rank & 0xFFu);
+    if (!lin.shared_blocks || k <= nb) return stream_sum(lin.lens + kb.off, s, k);
+    s = stream_sum(lin.lens + kb.off, s, nb);
+    return stream_sum(lin.lens + kb.portal_off, s, k - nb);
+}
 
 ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
                            const Stride3 *__restrict__ stride, int32_t a, int32_t b,
                            const uint64_t *__restrict__ rmq = nullptr, int64_t n_nodes = 0,
                            const LineageView &lin = LineageView())
 {
-    int32_t dm;
-    const int32_t da = depth[a], db = depth[b];
-    const int32_t m = pair_walk_mrca(nodes, depth, stride, a, b, &dm, rmq, n_nodes);
-    float s;
+    int32_t dm, da, db, m;
+    NodeKey ka{}, kb{};
     if (lin.sums) {
-        size_t off;
-        if (lin.node_off) off = lin.node_off[a];
-        else      // (rec_p: the top 4 bits of the word are a chunk count)
-            off = *reinterpret_cast<const uint32_t *>(lin.rec_p + record_slot(a, lin.parity, lin.n_leaves) * 8 + 4) & 0x0FFFFFFFu;
-        s = lin.sums[off + (size_t)(da - dm)];
+        ka = lineage_key(lin, a);
+        kb = lineage_key(lin, b);
+        da = (int32_t)ka.depth;
+        db = (int32_t)kb.depth;
     } else {
-        s = walk_sum(stride, 0.0f, a, da - dm);
+        da = depth[a];
+        db = depth[b];
     }
-    s = walk_sum(stride, s, b, db - dm);
+    if (lin.sums && lin.crown_rmq && (ka.nb_rank >> 8) != (kb.nb_rank >> 8)) {
+        const uint64_t e = crown_meet(lin.crown_rmq, lin.crown_nodes, ka.nb_rank >> 8, kb.nb_rank >> 8);
+        dm = (int32_t)(e >> 32);
+        m = (int32_t)(uint32_t)e;
+    } else {
+        m = pair_walk_mrca(nodes, depth, stride, a, b, &dm, rmq, n_nodes);
+    }
+    float s;
+    if (lin.sums) s = lin.sums[(size_t)ka.off + (size_t)(da - dm)];
+    else s = walk_sum(stride, 0.0f, a, da - dm);
+    if (lin.sums && lin.lens) s = stream_b(lin, kb, s, db - dm);
+    else s = walk_sum(stride, s, b, db - dm);
     PairResult r;
     r.dist = s;
     r.mrca = m;

@@ -253,7 +253,9 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_rmq64);
         (void)hipFree(t->d_rec_r);
         (void)hipFree(t->d_lineage);
-        (void)hipFree(t->d_lineage_node_off);
+        (void)hipFree(t->d_lineage_len);
+        (void)hipFree(t->d_lineage_node_rec);
+        (void)hipFree(t->d_crown_rmq);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
@@ -316,6 +318,21 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "mrca_ranks") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "mrca_ranks must be 0 or 1");
         t->mrca_ranks = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "walk_crown") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_crown must be 0 or 1");
+        t->walk_crown = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "walk_sort") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_sort must be 0 or 1");
+        t->walk_sort = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "lineage_lens") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "lineage_lens must be 0 or 1");
+        t->lineage_lens = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "lineage_sums") == 0) {

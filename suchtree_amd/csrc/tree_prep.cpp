@@ -7,6 +7,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
+#include <utility>
 
 namespace st {
 
@@ -307,21 +309,49 @@ bool prepare_rank_table(TreeTables &T)
     return true;
 }
 
-bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
+// One node's block of the lineage tables: the reference's a-side accumulator after each prefix of
+// x's lineage (d = 0; d += dist[n] up the lineage, pyx:934-938) and, optionally, the operands.
+static inline void fill_lineage_block(const TreeTables &T, int64_t x, float *sums, float *lens)
+{
+    volatile float acc = 0.0f;
+    int32_t v = (int32_t)x;
+    const int32_t k_max = T.depth[(size_t)x];
+    const int64_t block = lineage_block(k_max);
+    sums[0] = 0.0f;
+    for (int32_t k = 1; k <= k_max; k++) {
+        const float d = T.nodes[(size_t)v].dist;
+        acc = acc + d;
+        sums[k] = acc;
+        if (lens) lens[k - 1] = d;
+        v = T.nodes[(size_t)v].parent;
+    }
+    for (int64_t k = (int64_t)k_max + 1; k < block; k++) sums[k] = 0.0f;
+    if (lens)
+        for (int64_t k = k_max; k < block; k++) lens[k] = 0.0f;
+}
+
+bool prepare_lineage_sums(TreeTables &T, int64_t max_entries, bool with_lens)
 {
     T.lineage_sum.clear();
+    T.lineage_len.clear();
     T.rec_p.clear();
+    T.lineage_node_off.clear();
+    T.lineage_node_rec.clear();
+    T.crown_rmq.clear();
     if (!T.has_canopy || !T.inorder_ids || T.canopy_rmq.empty()) return false;
     const int64_t n = T.n;
     int64_t entries = 0;
-    for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
+    for (int64_t x = 0; x < n; x++) entries += lineage_block(T.depth[(size_t)x]);
     // (offsets share their word with a 4-bit chunk count; slots are kept in 28 bits by the kernel)
     if (entries > max_entries || entries >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28) || T.tree_depth > 65535) return false;
     build_rmq64(T);
     T.lineage_sum.resize((size_t)entries);
+    if (with_lens) T.lineage_len.resize((size_t)entries);
     T.rec_p.assign((size_t)n * 8, 0);
+    T.lineage_node_off.resize((size_t)n);
     int64_t off = 0;
     for (int64_t x = 0; x < n; x++) {
+        T.lineage_node_off[(size_t)x] = (uint32_t)off;
         const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
         uint32_t w0a;
         std::memcpy(&w0a, T.rec_a.data() + slot * 8, 4);
@@ -333,71 +363,132 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries)
         const uint32_t wp = (uint32_t)T.canopy_pos[(size_t)(w0 & 0xFFFFu)] | ((uint32_t)T.depth[(size_t)x] << 16);
         std::memcpy(T.rec_p.data() + slot * 8, &wp, 4);
         std::memcpy(T.rec_p.data() + slot * 8 + 4, &off32, 4);
-        // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
-        volatile float acc = 0.0f;
-        float *dst = T.lineage_sum.data() + off;
-        int32_t v = (int32_t)x;
-        const int32_t k_max = T.depth[(size_t)x];
-        dst[0] = 0.0f;
-        for (int32_t k = 1; k <= k_max; k++) {
-            acc = acc + T.nodes[(size_t)v].dist;
-            dst[k] = acc;
-            v = T.nodes[(size_t)v].parent;
-        }
-        off += (int64_t)k_max + 1;
+        fill_lineage_block(T, x, T.lineage_sum.data() + off, with_lens ? T.lineage_len.data() + off : nullptr);
+        off += lineage_block(T.depth[(size_t)x]);
     }
     return true;
 }
 
-bool prepare_walk_lineage(TreeTables &T, int64_t max_entries)
+bool prepare_walk_lineage(TreeTables &T, int64_t max_entries, bool with_lens)
 {
     T.lineage_sum.clear();
+    T.lineage_len.clear();
     T.lineage_node_off.clear();
+    T.lineage_node_rec.clear();
+    T.crown_rmq.clear();
     const int64_t n = T.n;
     int64_t entries = 0;
-    for (int64_t x = 0; x < n; x++) entries += (int64_t)T.depth[(size_t)x] + 1;
+    for (int64_t x = 0; x < n; x++) entries += lineage_block(T.depth[(size_t)x]);
     if (entries > max_entries || entries >= ((int64_t)1 << 32)) return false;
     T.lineage_node_off.resize((size_t)n);
     int64_t off = 0;
     for (int64_t x = 0; x < n; x++) {
         T.lineage_node_off[(size_t)x] = (uint32_t)off;
-        off += (int64_t)T.depth[(size_t)x] + 1;
+        off += lineage_block(T.depth[(size_t)x]);
     }
     T.lineage_sum.resize((size_t)entries);
+    if (with_lens) T.lineage_len.resize((size_t)entries);
     auto fill = [&](int64_t lo, int64_t hi) {
         for (int64_t x = lo; x < hi; x++) {
-            // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
-            volatile float acc = 0.0f;
-            float *dst = T.lineage_sum.data() + T.lineage_node_off[(size_t)x];
-            int32_t v = (int32_t)x;
-            const int32_t k_max = T.depth[(size_t)x];
-            dst[0] = 0.0f;
-            for (int32_t k = 1; k <= k_max; k++) {
-                acc = acc + T.nodes[(size_t)v].dist;
-                dst[k] = acc;
-                v = T.nodes[(size_t)v].parent;
-            }
+            const size_t o = T.lineage_node_off[(size_t)x];
+            fill_lineage_block(T, x, T.lineage_sum.data() + o, with_lens ? T.lineage_len.data() + o : nullptr);
         }
     };
     const unsigned hw = std::thread::hardware_concurrency();
     const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 32), entries >> 22));
-    if (n_threads <= 1) {
-        fill(0, n);
-    } else {
-        // ranges of equal table size, not equal node count (depths differ)
-        std::vector<std::thread> threads;
-        int64_t lo = 0;
-        for (int t = 1; t <= n_threads; t++) {
-            int64_t hi = n;
-            if (t < n_threads) {
-                const uint32_t want = (uint32_t)((uint64_t)entries * (uint64_t)t / (uint64_t)n_threads);
-                hi = std::lower_bound(T.lineage_node_off.begin(), T.lineage_node_off.end(), want) - T.lineage_node_off.begin();
-                if (hi < lo) hi = lo;
-            }
-            threads.emplace_back(fill, lo, hi);
-            lo = hi;
+    // ranges of equal table size, not equal node count (depths differ)
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    int64_t lo = 0;
+    for (int t = 1; t <= n_threads; t++) {
+        int64_t hi = n;
+        if (t < n_threads) {
+            const uint32_t want = (uint32_t)((uint64_t)entries * (uint64_t)t / (uint64_t)n_threads);
+            hi = std::lower_bound(T.lineage_node_off.begin(), T.lineage_node_off.end(), want) - T.lineage_node_off.begin();
+            if (hi < lo) hi = lo;
         }
-        for (auto &th : threads) th.join();
+        ranges.emplace_back(lo, hi);
+        lo = hi;
+    }
+    // a thread that cannot be started (std::system_error) leaves its range to the caller's thread:
+    // nothing joinable is ever abandoned, nothing is thrown past this function
+    std::vector<std::thread> threads;
+    std::vector<std::pair<int64_t, int64_t>> mine;
+    for (size_t t = 0; t < ranges.size(); t++) {
+        if (t + 1 == ranges.size()) { mine.push_back(ranges[t]); break; }
+        try {
+            threads.emplace_back(fill, ranges[t].first, ranges[t].second);
+        } catch (const std::exception &) {
+            mine.push_back(ranges[t]);
+        }
+    }
+    for (const auto &r : mine) fill(r.first, r.second);
+    for (auto &th : threads) th.join();
+    return true;
+}
+
+bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes)
+{
+    T.lineage_node_rec.clear();
+    T.crown_rmq.clear();
+    T.crown_nodes = T.crown_levels = T.crown_height = 0;
+    T.crown_hot_bytes = 0;
+    const int64_t n = T.n;
+    if (T.lineage_node_off.size() != (size_t)n || T.height.size() != (size_t)n) return false;
+    // bytes of the crown's blocks by H: suffix sums over heights
+    int32_t hmax = 0;
+    for (int64_t i = 0; i < n; i++) hmax = std::max(hmax, T.height[(size_t)i]);
+    std::vector<int64_t> bytes_ge((size_t)hmax + 2, 0);      // blocks of nodes with height == h, then suffix sums
+    for (int64_t i = 0; i < n; i++) bytes_ge[(size_t)T.height[(size_t)i]] += 4 * lineage_block(T.depth[(size_t)i]);
+    for (int32_t h = hmax - 1; h >= 0; h--) bytes_ge[(size_t)h] += bytes_ge[(size_t)h + 1];
+    // crown(H) = height > H; the root stays in the crown (H <= hmax - 1); nb <= H must fit 8 bits
+    int32_t H = 0;
+    const int32_t h_top = std::min(hmax - 1, 255);
+    while (H < h_top && bytes_ge[(size_t)H + 1] > hot_bytes) H++;
+    T.crown_height = H;
+    T.crown_hot_bytes = bytes_ge[(size_t)H + 1];
+    // crown nodes by id, their ranks
+    std::vector<int32_t> rank((size_t)n, -1);
+    int64_t C = 0;
+    for (int64_t x = 0; x < n; x++)
+        if (T.height[(size_t)x] > H) rank[(size_t)x] = (int32_t)C++;
+    if (C < 1 || C >= ((int64_t)1 << 24)) return false;
+    T.crown_nodes = (int32_t)C;
+    // portal and nb, parents first
+    std::vector<int32_t> portal((size_t)n);
+    std::vector<uint8_t> nb((size_t)n);
+    for (int64_t k = 0; k < n; k++) {
+        const int32_t x = T.bfs_order[(size_t)k];
+        if (rank[(size_t)x] >= 0) { portal[(size_t)x] = x; nb[(size_t)x] = 0; continue; }
+        const int32_t p = T.nodes[(size_t)x].parent;      // (the root is in the crown: p >= 0 here)
+        portal[(size_t)x] = portal[(size_t)p];
+        nb[(size_t)x] = (uint8_t)(nb[(size_t)p] + 1);
+    }
+    T.lineage_node_rec.resize((size_t)n * 4);
+    for (int64_t x = 0; x < n; x++) {
+        uint32_t *r = T.lineage_node_rec.data() + (size_t)x * 4;
+        const int32_t p = portal[(size_t)x];
+        r[0] = (uint32_t)T.depth[(size_t)x];
+        r[1] = T.lineage_node_off[(size_t)x];
+        r[2] = T.lineage_node_off[(size_t)p];
+        r[3] = (uint32_t)nb[(size_t)x] | ((uint32_t)rank[(size_t)p] << 8);
+    }
+    if (T.inorder_ids) {
+        int32_t levels = 1;
+        while (((int64_t)1 << levels) <= C) levels++;
+        T.crown_levels = levels;
+        T.crown_rmq.resize((size_t)levels * (size_t)C);
+        for (int64_t x = 0; x < n; x++)
+            if (rank[(size_t)x] >= 0)
+                T.crown_rmq[(size_t)rank[(size_t)x]] = ((uint64_t)(uint32_t)T.depth[(size_t)x] << 32) | (uint64_t)(uint32_t)x;
+        for (int32_t k = 1; k < levels; k++) {
+            const uint64_t *lo = T.crown_rmq.data() + (size_t)(k - 1) * (size_t)C;
+            uint64_t *cur = T.crown_rmq.data() + (size_t)k * (size_t)C;
+            const int64_t half = (int64_t)1 << (k - 1);
+            for (int64_t i = 0; i < C; i++) {
+                const uint64_t a = lo[i], b = i + half < C ? lo[i + half] : a;
+                cur[i] = b < a ? b : a;
+            }
+        }
     }
     return true;
 }

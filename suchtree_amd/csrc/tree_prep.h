@@ -133,7 +133,15 @@ struct TreeTables {
     // comes from the two ranks, a's edge count and b's from the depths.
     // canopy_rmq64 = canopy_rmq with entries depth << 32 | NODE ID of the shallowest node (the
     // MRCA id of a pair falls out of the same two reads that find its meeting depth).
-    std::vector<float> lineage_sum;     // [sum over nodes of depth + 1] or empty
+    // Every node's block of the table holds depth + 1 entries rounded up to a multiple of sixteen, so
+    // that blocks start on 64-byte boundaries: a stream of lineage lengths touches whole sectors.
+    // Lineage lengths, same blocks and offsets: lineage_len[off(x) + k] = branch length of the k-th
+    // node of x's lineage (k = 0: x itself; k < depth(x)), i.e. the operands of the reference's b-side
+    // loop (pyx:939-942) laid out contiguously.  With the meeting node known, b's side of a pair is
+    // k_b consecutive floats added in order -- independent 16-byte loads, four per 64-byte sector --
+    // instead of k_b / 3 dependent gathers through the stride-3 image.
+    std::vector<float> lineage_sum;     // [sum over nodes of round_up16(depth + 1)] or empty
+    std::vector<float> lineage_len;     // same shape, or empty
     std::vector<uint8_t> rec_p;         // [n * 8], slot order, or empty
     std::vector<uint64_t> canopy_rmq64; // [rmq_levels * canopy_nodes] or empty
     // rec_r[slot] = rank of x's portal | depth(x) << 16 (the first word of rec_p, on its own: 4
@@ -144,6 +152,23 @@ struct TreeTables {
     // Trees that only the walk family serves (prepare_walk_lineage): the same lineage sums,
     // offsets by node id (no records there to carry them).
     std::vector<uint32_t> lineage_node_off;   // [n] or empty
+    // Crown of the walk family (prepare_walk_crown): crown(H) = { x : height(x) > H }, closed under
+    // "parent of"; portal(x) = the lowest node of x's lineage (x included) that is in the crown;
+    // nb(x) = nodes of the lineage below the portal (<= H <= 255).  A node's lineage lengths are
+    // its own first nb entries followed by ITS PORTAL'S lineage lengths -- the same floats as the
+    // tail of its own block, but in a block that every node below that portal shares, so that the
+    // long part of every b-side stream falls on a hot set of a few MB (L2 / Infinity Cache) instead
+    // of a table of hundreds of MB.  H is the smallest height whose crown blocks fit crown_hot_bytes.
+    // lineage_node_rec[4 x + 0..3] = {depth, offset of x's block, offset of its portal's block,
+    // nb | rank of the portal << 8}: all the walk family reads of either node, one 16-byte gather.
+    // crown_rmq (in-order ids): sparse table over the crown sorted by node id, entries depth << 32 |
+    // node id; rank = position in that order.  Two nodes with different portals meet in the crown:
+    // their MRCA is the shallowest crown node between the two ranks (a table of a few hundred KB
+    // instead of the whole-tree table's hundreds of MB); equal portals use the whole-tree form.
+    std::vector<uint32_t> lineage_node_rec;   // [4 * n] or empty
+    std::vector<uint64_t> crown_rmq;          // [crown_levels * crown_nodes] or empty
+    int32_t crown_nodes = 0, crown_levels = 0, crown_height = 0;
+    int64_t crown_hot_bytes = 0;              // lineage-length bytes of the crown's blocks
 };
 
 // Record slot of node id x.  With the parity layout leaf records come first
@@ -167,11 +192,19 @@ bool prepare_rank_table(TreeTables &T);
 // Lineage sums for a tree without canopy tables: lineage_sum + lineage_node_off, when the table
 // has at most max_entries (< 2^32) entries.  Any node numbering.  Built on several threads (one
 // root-ward walk per node).
-bool prepare_walk_lineage(TreeTables &T, int64_t max_entries);
+// with_lens: also the lineage-length table (same size again).
+bool prepare_walk_lineage(TreeTables &T, int64_t max_entries, bool with_lens = true);
 
 // Lineage sums of every node (see TreeTables), for trees with a canopy and a sparse table and
 // at most max_entries table entries; returns false (tables left empty) otherwise.
-bool prepare_lineage_sums(TreeTables &T, int64_t max_entries);
+bool prepare_lineage_sums(TreeTables &T, int64_t max_entries, bool with_lens = true);
+
+// node_rec + crown tables for the walk family (see TreeTables); needs lineage_node_off (either
+// prepare_*lineage* function fills it).  hot_bytes: budget of the crown's lineage-length blocks.
+bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes);
+
+// Entries of a node's block in the lineage tables.
+ST_HD int64_t lineage_block(int32_t depth) { return ((int64_t)depth + 1 + 15) & ~(int64_t)15; }
 
 // Chooses the canopy and builds canopy + records.  Returns false (without
 // error) when the tree does not admit the canopy family (lineages below any

@@ -34,18 +34,23 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
     bool canopy = false;
     bool lineage = false, ranks = false;
-    std::vector<float> walk_sums;            // lineage sums with offsets by node id (trees without canopy tables)
-    std::vector<uint32_t> walk_off;
-    if (strategy == 1) {   // the walk family uses the lineage sums of trees that have them
-        TreeTables C = T;
-        if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27)) {
-            T.lineage_sum = std::move(C.lineage_sum);
-            T.rec_p = std::move(C.rec_p);
-        }
-        TreeTables W = T;
-        if (prepare_walk_lineage(W, (int64_t)1 << 27)) {
-            walk_sums = std::move(W.lineage_sum);
-            walk_off = std::move(W.lineage_node_off);
+    // the walk family's lineage tables, built both ways (offsets as the deep-canopy path assigns them,
+    // and the walk-only path), each with crowns of several sizes
+    struct WalkTables {
+        std::vector<float> sums, lens;
+        std::vector<uint32_t> node_rec;
+        std::vector<uint64_t> crown_rmq;
+        int32_t crown_nodes = 0;
+    };
+    std::vector<WalkTables> walk_tables;
+    if (strategy == 1) {
+        for (const int64_t hot : {(int64_t)256, (int64_t)16 << 10, (int64_t)4 << 20}) {
+            TreeTables C = T;
+            if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27) && prepare_walk_crown(C, hot))
+                walk_tables.push_back({C.lineage_sum, C.lineage_len, C.lineage_node_rec, C.crown_rmq, C.crown_nodes});
+            TreeTables W = T;
+            if (prepare_walk_lineage(W, (int64_t)1 << 27) && prepare_walk_crown(W, hot))
+                walk_tables.push_back({W.lineage_sum, W.lineage_len, W.lineage_node_rec, W.crown_rmq, W.crown_nodes});
         }
     }
     if (strategy == 2) {
@@ -77,33 +82,26 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                     return 7;
                 }
             }
-            {   // a's side from the lineage sums, where the tree has them (deep canopies, in-order ids)
-                const TreeTables &L = T;
-                if (!L.lineage_sum.empty()) {
-                    LineageView lin;
-                    lin.rec_p = L.rec_p.data();
-                    lin.sums = L.lineage_sum.data();
-                    lin.n_leaves = L.n_leaves;
-                    lin.parity = L.parity_layout;
-                    const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
-                                                   T.tree_rmq.empty() ? nullptr : T.tree_rmq.data(), T.n, lin);
-                    if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
-                        g_err = "walk: lineage-sum form disagrees with the climb";
-                        return 8;
-                    }
-                }
-            }
-            if (!walk_off.empty()) {     // ... and the walk-only form of the same table (offsets by node id), with and without the sparse table
-                LineageView lin;
-                lin.node_off = walk_off.data();
-                lin.sums = walk_sums.data();
-                for (const bool use_rmq : {false, true}) {
+            // every form of the lineage tables: a's side from the sums; b's side climbed, streamed from its
+            // own block, or streamed from its own block and then its portal's; the meeting node by
+            // climbing, from the whole-tree table, or from the crown's table
+            for (const WalkTables &W : walk_tables) {
+                for (int form = 0; form < 16; form++) {
+                    const bool use_rmq = form & 1, use_lens = form & 2, shared = form & 4, crown = form & 8;
                     if (use_rmq && T.tree_rmq.empty()) continue;
+                    if (crown && W.crown_rmq.empty()) continue;
+                    if (shared && !use_lens) continue;
+                    LineageView lin;
+                    lin.node_rec = W.node_rec.data();
+                    lin.sums = W.sums.data();
+                    lin.lens = use_lens ? W.lens.data() : nullptr;
+                    lin.shared_blocks = shared;
+                    if (crown) { lin.crown_rmq = W.crown_rmq.data(); lin.crown_nodes = W.crown_nodes; }
                     const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
                                                    use_rmq ? T.tree_rmq.data() : nullptr, T.n, lin);
                     if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
-                        g_err = "walk: node-offset lineage form disagrees with the climb";
-                        return 12;
+                        g_err = "walk: lineage-table form " + std::to_string(form) + " disagrees with the climb";
+                        return 8;
                     }
                 }
             }

@@ -56,6 +56,7 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
     }
     const bool canopy = prepare_canopy(parent.data(), dist.data(), T, max_canopy);
     const bool lineage = canopy && prepare_lineage_sums(T, (int64_t)1 << 24);       // (in-order ids: always, unless too large)
+    const bool crown = lineage && prepare_walk_crown(T, (int64_t)4 << 10);
     const int64_t n = T.n;
     std::uniform_int_distribution<int64_t> pick(0, n - 1);
     for (int k = 0; k < 20000; k++) {
@@ -74,11 +75,14 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
             return 3;
         }
         if (lineage) {      // the walk with a's side from the lineage sums, and the deep kernel's reads
-            LineageView lin;
-            lin.rec_p = T.rec_p.data();
+            if (!crown) return 6;
+            LineageView lin;      // every table of the walk family at once: sums, streamed lengths, shared blocks, crown table
+            lin.node_rec = T.lineage_node_rec.data();
             lin.sums = T.lineage_sum.data();
-            lin.n_leaves = T.n_leaves;
-            lin.parity = T.parity_layout;
+            lin.lens = T.lineage_len.data();
+            lin.shared_blocks = true;
+            lin.crown_rmq = T.crown_rmq.empty() ? nullptr : T.crown_rmq.data();
+            lin.crown_nodes = T.crown_nodes;
             const PairResult q = pair_walk(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b,
                                            T.tree_rmq.empty() ? nullptr : T.tree_rmq.data(), T.n, lin);
             if (q.mrca != w.mrca || std::memcmp(&q.dist, &w.dist, 4) != 0) return 4;
