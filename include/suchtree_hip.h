@@ -230,14 +230,23 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
  * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
  * "tree_rmq": 1 (default) = the walk family takes the meeting node from the whole-tree sparse table
- * where the tree has one (in-order ids; up to 64 MB, up to 4 GiB when the canopy family is not
- * available); 0 = it searches it by climbing both lineages.
+ * where the tree has one (in-order ids; up to 64 MB, more -- within SUCHTREE_AMD_WALK_TABLE_MB -- when
+ * the canopy family is not available); 0 = it searches it by climbing both lineages.
  * "mrca_ranks": 1 (default) = MRCA-only requests on trees with in-order ids are answered from a
  * per-node rank table and a sparse table over the canopy (no LDS, no understory records);
  * 0 = they go through the distance kernels.
- * "lineage_sums": 1 (default) = on deep canopies with in-order ids the tile-sorted kernel reads
- * the first node's whole side of a pair from a table of per-node lineage sums (one 4-byte read;
- * table built when it stays below 1 GiB); 0 = it climbs that side through the canopy as well.
+ * "lineage_sums": 1 (default) = the first node's whole side of a pair comes from a table of per-node
+ * lineage sums (one 4-byte read) wherever the tree has that table: in the tile-sorted canopy kernel
+ * (deep canopies with in-order ids, table below 1 GiB) and in the walk family (the same trees, and
+ * trees only the walk family serves); 0 = that side is climbed as well (this also switches off
+ * everything below that builds on the table).
+ * "lineage_lens": 1 (default) = the walk family adds the second node's side from the lineage-length
+ * table, consecutive floats, instead of climbing the stride-3 image; 0 = it climbs.
+ * "walk_crown": 1 (default) = the walk family reads the long upper part of that stream from the
+ * block of the node's portal (shared by all nodes below it: a cache-resident hot set) and takes
+ * meeting nodes of different portals from the crown's own sparse table; 0 = own block, whole-tree table.
+ * "walk_sort": 1 (default) = batches of >= 32768 pairs on trees with the sparse table and both lineage
+ * tables run the tile-sorted walk kernel (a wave's 64 pairs have streams of similar length); 0 = k_walk.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe. */
