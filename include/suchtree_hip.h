@@ -247,6 +247,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * meeting nodes of different portals from the crown's own sparse table; 0 = own block, whole-tree table.
  * "walk_sort": 1 (default) = batches of >= 32768 pairs on trees with the sparse table and both lineage
  * tables run the tile-sorted walk kernel (a wave's 64 pairs have streams of similar length); 0 = k_walk.
+ * "rec_a4": 1 (default) = on trees whose leaves sit in portal-uniform aligned blocks of leaf slots (balanced
+ * and near-balanced trees) the predicated canopy kernel gathers 4 bytes for the first node of a pair
+ * (its understory sum; the portal comes from a block table in LDS) instead of the 8-byte entry; 0 = 8 bytes.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe. */

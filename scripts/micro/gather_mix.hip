@@ -1,7 +1,7 @@
 // gather_mix.hip -- would splitting the understory records pay?  Emulates the memory side of
 // one pair: (A) two random 64-B-sector reads from one 64 MiB table [today], (B) one random
 // 8-byte read from an 8 MiB table + one random 32-byte read from a 32 MiB table [split],
-// each with the 16-byte pair stream in and 12 bytes out.
+// each with the 16-byte pair stream in and 12 bytes out.  Round 3: (C) a 4-byte a entry (4 MiB table).
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/gather_mix scripts/micro/gather_mix.hip && /tmp/gather_mix
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -27,9 +27,18 @@ __global__ __launch_bounds__(1024) void k_mix(const uint8_t *__restrict__ ta, ui
         uint32_t acc;
         if (MODE == 0) {   // today: word0 + pbot of a (two dwords of one 64-B record), 32 B of b's record
             acc = *reinterpret_cast<const uint32_t *>(pa) + *reinterpret_cast<const uint32_t *>(pa + 32);
-        } else {           // split: 8-byte a entry
+        } else if (MODE == 1) {   // split: 8-byte a entry
             const uint2 v = *reinterpret_cast<const uint2 *>(pa);
             acc = v.x + v.y;
+        } else if (MODE == 2) {   // 4-byte a entry (pbot alone; the portal recovered from the leaf-id range of each portal)
+            acc = *reinterpret_cast<const uint32_t *>(pa);
+        } else if (MODE == 3) {   // pbot (4 B, 4 MiB table) + portal (2 B, 2 MiB table): two small gathers
+            acc = *reinterpret_cast<const uint32_t *>(ta + (size_t)ia * 4) +
+                  *reinterpret_cast<const uint16_t *>(ta + (64u << 20) + (size_t)ia * 2);
+        } else {                  // 6-byte packed a entry: pbot + 16-bit portal, unaligned (6 MiB table)
+            const uint8_t *p6 = ta + (size_t)ia * 6;
+            acc = *reinterpret_cast<const uint16_t *>(p6) + *reinterpret_cast<const uint16_t *>(p6 + 2) +
+                  *reinterpret_cast<const uint16_t *>(p6 + 4);
         }
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         if (NTB) {
@@ -101,6 +110,11 @@ int main()
     if (run("split + non-temporal stream loads/stores", k_mix<1, true>, M1, 8, tb, M1, 32)) return 1;
     if (run("split + nt streams + nt b-record loads", k_mix<1, true, true>, M1, 8, tb, M1, 32)) return 1;
     if (run("split + nt b-record loads only", k_mix<1, false, true>, M1, 8, tb, M1, 32)) return 1;
+    if (run("r03   : a from 4 MiB (4 B), b from 32 MiB (32 B)", k_mix<2, false>, M1, 4, tb, M1, 32)) return 1;
+    if (run("r03   : a from 4 MiB (4 B) + nt streams", k_mix<2, true>, M1, 4, tb, M1, 32)) return 1;
+    if (run("r03   : a from 2 MiB (2 B stride: what a 16-bit entry would touch), b from 32 MiB", k_mix<2, false>, M1, 2, tb, M1, 32)) return 1;
+    if (run("r03   : a = pbot 4 B (4 MiB) + portal 2 B (2 MiB), b from 32 MiB (32 B)", k_mix<3, false>, M1, 4, tb, M1, 32)) return 1;
+    if (run("r03   : a = packed 6 B entry (6 MiB), b from 32 MiB (32 B)", k_mix<4, false>, M1, 6, tb, M1, 32)) return 1;
     if (run("split : a from 8 MiB (8 B), b from 64 MiB (64-B records)", k_mix<1, false>, M1, 8, tb, M1, 64)) return 1;
     if (run("floor : a and b from 2 MiB tables (L2 resident)", k_mix<1, false>, (1u << 15) - 1, 8, tb, (1u << 15) - 1, 32)) return 1;
     {

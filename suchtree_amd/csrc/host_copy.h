@@ -9,6 +9,8 @@
 // the copy pool (MADV_POPULATE_WRITE on huge-page-advised ranges) while the GPU works,
 // instead of one 4 KiB fault at a time inside the unpack loop.
 #pragma once
+#include <atomic>
+#include <cerrno>
 #include <emmintrin.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -101,12 +103,25 @@ inline void populate_for_write(void *p, int64_t bytes)
     const uintptr_t b = (reinterpret_cast<uintptr_t>(p) + (uintptr_t)page - 1) & ~((uintptr_t)page - 1);
     const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes) & ~((uintptr_t)page - 1);
     if (e <= b) return;
-    static int have_populate = 1;
-    if (have_populate) {
-        if (madvise(reinterpret_cast<void *>(b), e - b, MADV_POPULATE_WRITE) == 0) return;
-        have_populate = 0;   // old kernel: touch the pages instead
+    // 1 = not probed yet / available, 0 = this kernel does not know MADV_POPULATE_WRITE (EINVAL on
+    // the FIRST call ever: Linux < 5.14).  Any other failure (a file-backed or hugetlb range, ENOMEM,
+    // a later EINVAL) concerns this range only: nothing is touched -- the copy loops then take their
+    // page faults -- and the next call tries again.  Called from all copy threads: atomic.
+    static std::atomic<int> have_populate{1};
+    static std::atomic<int> probed{0};
+    if (have_populate.load(std::memory_order_relaxed)) {
+        const int rc = madvise(reinterpret_cast<void *>(b), e - b, MADV_POPULATE_WRITE);
+        const int err = rc == 0 ? 0 : errno;
+        const bool first = probed.exchange(1, std::memory_order_relaxed) == 0;
+        if (rc == 0) return;
+        if (!(first && err == EINVAL)) return;
+        have_populate.store(0, std::memory_order_relaxed);
     }
-    for (uintptr_t q = b; q < e; q += (uintptr_t)page) *reinterpret_cast<volatile char *>(q) = 0;
+    // old kernel: touch one byte per page, leaving its value as it is (the range belongs to the caller)
+    for (uintptr_t q = b; q < e; q += (uintptr_t)page) {
+        volatile char *c = reinterpret_cast<volatile char *>(q);
+        *c = *c;
+    }
 }
 
 // Are the pages of [p, p + bytes) already resident?  Judged from its first, middle and last

@@ -147,6 +147,12 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
             if (t->pairs_per_lane == 2)
                 return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, fault, stream);
         }
+        // explicit pair arrays on trees with the four-byte a side: 4-byte gathers from a table half the size
+        if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
+            if (P.rec_a4 && P.leaf_blocks)
+                return launch_canopy_k(k_canopy_ilp<CAP, 1, Src, true>, 1, t, P, src, n, out_d, out_m, fault, stream,
+                                       canopy_lds_bytes(t) + leaf_block_image_bytes(P.leaf_block_count));
+        }
         return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     }
 }
@@ -163,6 +169,10 @@ static hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, Dis
     P.cpos = t->d_cpos;
     P.rmq = t->d_rmq;
     P.rec_a = t->d_rec_a;
+    P.rec_a4 = t->rec_a4 ? t->d_rec_a4 : nullptr;
+    P.leaf_blocks = t->rec_a4 ? t->d_leaf_blocks : nullptr;
+    P.leaf_block_shift = t->leaf_block_shift;
+    P.leaf_block_count = t->leaf_block_count;
     P.rec_b = t->d_rec_b;
     P.rec_i = t->d_rec_i;
     P.rec_p = t->d_rec_p;

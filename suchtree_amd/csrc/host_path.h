@@ -55,15 +55,30 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
 {
     std::lock_guard<std::mutex> lock(t->mb_mutex);
     if (!t->mb_host) {
+        // set up in locals and committed to the handle only when every step has succeeded: a partly
+        // initialised mailbox (memory but no stream, no block counter) must never be launched on
         const size_t bytes = (size_t)kMailboxPairs * (16 + 8 + 4) + 64;     // + the completion word
-        ST_HIP(hipHostMalloc(&t->mb_host, bytes, hipHostMallocMapped));
-        ST_HIP(hipHostGetDevicePointer(&t->mb_dev, t->mb_host, 0));
-        ST_HIP(hipMalloc(reinterpret_cast<void **>(&t->d_fault_mb), sizeof(Fault)));      // [0]: block counter of the mailbox kernel
-        ST_HIP(hipStreamCreateWithFlags(&t->mb_stream, hipStreamNonBlocking));
+        void *host = nullptr, *dev = nullptr;
+        Fault *counter = nullptr;
+        hipStream_t stream = nullptr;
+        hipError_t e = hipHostMalloc(&host, bytes, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, host, 0);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&counter), sizeof(Fault));      // [0]: block counter of the mailbox kernel
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
         // cleared ON the mailbox stream: a hipMemset on the null stream is not ordered before
         // kernels of a non-blocking stream, and recycled device memory is not zero
-        ST_HIP(hipMemsetAsync(t->d_fault_mb, 0, sizeof(Fault), t->mb_stream));
-        *reinterpret_cast<volatile unsigned *>(static_cast<char *>(t->mb_host) + (size_t)kMailboxPairs * 28) = 0;
+        if (e == hipSuccess) e = hipMemsetAsync(counter, 0, sizeof(Fault), stream);
+        if (e != hipSuccess) {
+            if (stream) (void)hipStreamDestroy(stream);
+            if (counter) (void)hipFree(counter);
+            if (host) (void)hipHostFree(host);
+            return fail(ST_ERR_HIP, std::string("mailbox setup: ") + hipGetErrorString(e));
+        }
+        *reinterpret_cast<volatile unsigned *>(static_cast<char *>(host) + (size_t)kMailboxPairs * 28) = 0;
+        t->mb_dev = dev;
+        t->d_fault_mb = counter;
+        t->mb_stream = stream;
+        t->mb_host = host;
     }
     int64_t *h_pairs = static_cast<int64_t *>(t->mb_host);
     double *h_dist = reinterpret_cast<double *>(h_pairs + 2 * kMailboxPairs);

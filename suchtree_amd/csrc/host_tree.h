@@ -52,6 +52,10 @@ struct st_tree {
     CanopyEntry *d_canopy = nullptr;
     int32_t *d_canopy_id = nullptr;
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
+    float *d_rec_a4 = nullptr;            // four-byte form of the a side (balanced-like trees), else NULL
+    uint16_t *d_leaf_blocks = nullptr;
+    int32_t leaf_block_shift = 0, leaf_block_count = 0;
+    int rec_a4 = 1;           // tuning: 0 = the predicated canopy kernel reads the 8-byte rec_a entries even when the four-byte form exists
     uint8_t *d_rec_p = nullptr;       // lineage sums (deep canopies with a sparse table), else NULL
     uint64_t *d_rmq64 = nullptr;
     uint32_t *d_rec_r = nullptr;      // MRCA-only queries (in-order ids), else NULL

@@ -63,6 +63,8 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
     if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
         return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
     if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
+    // four-byte a side for the predicated kernel (shallow canopies): 32 KiB of LDS are left beside a full canopy image
+    if (B.canopy_ok && !B.deep && B.T.record_cap <= 15) (void)prepare_leaf_blocks(B.T, 8192);
     if (!B.canopy_ok) {
         // a tree that only the walk family serves (canopy refused, or asked for) gets the whole-tree
         // sparse table beyond prepare_basic's 64 MB -- the meeting node in two reads instead of a
@@ -180,6 +182,20 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
             if (rc == ST_OK) rc = upload(&t->d_rmq, T.canopy_rmq, &bytes);
         }
         if (rc == ST_OK) rc = upload(&t->d_rec_a, T.rec_a, &bytes);
+        if (rc == ST_OK && !T.rec_a4.empty() &&
+            canopy_lds_bytes(t) + leaf_block_image_bytes((int)T.leaf_block_portal.size()) <= 160 * 1024) {
+            std::vector<uint16_t> blocks = T.leaf_block_portal;
+            blocks.resize(leaf_block_image_bytes((int)blocks.size()) / 2, 0xFFFFu);     // 16-byte staging granule
+            if (upload_optional(&t->d_rec_a4, T.rec_a4, &bytes)) {
+                if (upload_optional(&t->d_leaf_blocks, blocks, &bytes)) {
+                    t->leaf_block_shift = T.leaf_block_shift;
+                    t->leaf_block_count = (int32_t)T.leaf_block_portal.size();
+                } else {
+                    (void)hipFree(t->d_rec_a4);
+                    t->d_rec_a4 = nullptr;
+                }
+            }
+        }
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
         if (rc == ST_OK && !T.rec_r.empty()) {

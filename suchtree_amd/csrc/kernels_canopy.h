@@ -16,6 +16,9 @@ struct CanopyParams {
     const uint16_t *cpos;          // [canopy_nodes] rank by node id; NULL unless ids are in-order positions
     const uint32_t *rmq;           // [levels * canopy_nodes] sparse table of shallowest nodes (tree_prep.h)
     const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
+    const float *rec_a4;           // [n_nodes]                pbot alone (tree_prep.h: four-byte form of the a side), or NULL
+    const uint16_t *leaf_blocks;   // [leaf_block_count]       portal of every aligned block of leaf slots (staged to LDS), or NULL
+    int32_t leaf_block_shift, leaf_block_count;
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
     const uint8_t *rec_p;          // [n_nodes * 8]            {portal rank | depth << 16, lineage offset | chunks << 28}; NULL without lineage sums
@@ -195,7 +198,12 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
 // the same loop iteration as independent ds_read_b64 (low word = dist bits, high word =
 // parent index).  All updates are predicated selects (a finished climb keeps re-reading its
 // meeting node), so the PPL chains never serialise behind a branch.
-template <int CAP, int PPL, typename Src>
+// A4: the four-byte form of the a side (tree_prep.h): pbot from rec_a4 (4 bytes, a table half the size
+// of rec_a), the portal from the block table of leaf slots, staged into LDS behind the canopy image;
+// leaves of straddling blocks and internal nodes take the 8-byte entry (a wave-uniform rare branch).
+__host__ __device__ inline size_t leaf_block_image_bytes(int count) { return ((size_t)count * 2 + 15) & ~(size_t)15; }
+
+template <int CAP, int PPL, typename Src, bool A4 = false>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              DistSink out_d,
                                                              int *__restrict__ out_m, Fault *fault)
@@ -203,6 +211,13 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
     static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
+    const uint16_t *BLK = reinterpret_cast<const uint16_t *>(lds_raw + (size_t)((P.canopy_nodes + 1) / 2) * 16);
+    if (A4) {      // (stage_canopy's barrier covers these stores too)
+        const uint4 *src16 = reinterpret_cast<const uint4 *>(P.leaf_blocks);
+        uint4 *dst16 = reinterpret_cast<uint4 *>(lds_raw + (size_t)((P.canopy_nodes + 1) / 2) * 16);
+        const int n16 = (int)(leaf_block_image_bytes(P.leaf_block_count) / 16);
+        for (int k = threadIdx.x; k < n16; k += blockDim.x) dst16[k] = src16[k];
+    }
     stage_canopy(P, lds_raw);
 
     constexpr int rec_bytes = 8 * (CAP + 1);
@@ -239,9 +254,16 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
             const uint8_t *rb = P.rec_b + sb[j] * (rec_bytes / 2);
-            const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa[j]];
-            const uint32_t wa = va.x;
-            s[j] = __uint_as_float(va.y);
+            uint32_t wa;
+            if (A4) {
+                s[j] = P.rec_a4[sa[j]];
+                wa = sa[j] < P.n_leaves ? (uint32_t)BLK[sa[j] >> P.leaf_block_shift] : 0xFFFFu;
+                if (wa == 0xFFFFu) wa = reinterpret_cast<const uint32_t *>(P.rec_a)[2 * sa[j]];      // rare
+            } else {
+                const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa[j]];
+                wa = va.x;
+                s[j] = __uint_as_float(va.y);
+            }
             uint32_t wb;
             if (CAP == 1) {
                 const uint2 q = *reinterpret_cast<const uint2 *>(rb);

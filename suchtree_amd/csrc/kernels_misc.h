@@ -10,13 +10,19 @@ namespace st {
 // selects the k smallest in k rounds: round r finds the smallest key greater than the one
 // chosen in round r-1, key = (order-preserving image of the float) << 32 | candidate index, so
 // ties resolve to the lower candidate index (the reference's argsort leaves tie order
-// unspecified).  O(k * n_c) per row, for small k; the facade sorts on the host beyond kKnnMaxK.
+// unspecified).  Special values order as numpy's argsort orders them: -0.0 ties with +0.0, every
+// NaN (either sign) comes last.  O(k * n_c) per row, for small k; the facade sorts on the host
+// beyond kKnnMaxK.
 constexpr int kKnnMaxK = 256;
 
 __device__ __forceinline__ unsigned long long knn_key(float d, unsigned idx)
 {
     unsigned u = __float_as_uint(d);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    if (d != d) u = 0xFFFFFFFEu;                  // NaN: after every number (~0ull stays "nothing found")
+    else {
+        if (u == 0x80000000u) u = 0;               // -0.0 == +0.0
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
     return ((unsigned long long)u << 32) | idx;
 }
 

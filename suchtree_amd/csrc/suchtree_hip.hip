@@ -247,6 +247,8 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_cpos);
         (void)hipFree(t->d_rmq);
         (void)hipFree(t->d_rec_a);
+        (void)hipFree(t->d_rec_a4);
+        (void)hipFree(t->d_leaf_blocks);
         (void)hipFree(t->d_rec_b);
         (void)hipFree(t->d_rec_i);
         (void)hipFree(t->d_rec_p);
@@ -318,6 +320,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "mrca_ranks") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "mrca_ranks must be 0 or 1");
         t->mrca_ranks = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "rec_a4") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "rec_a4 must be 0 or 1");
+        t->rec_a4 = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "walk_crown") == 0) {

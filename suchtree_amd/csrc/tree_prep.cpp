@@ -285,6 +285,35 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     return true;
 }
 
+bool prepare_leaf_blocks(TreeTables &T, int max_blocks)
+{
+    T.rec_a4.clear();
+    T.leaf_block_portal.clear();
+    T.leaf_block_shift = 0;
+    if (!T.has_canopy || !T.parity_layout || T.n_leaves < 1 || max_blocks < 1) return false;
+    int32_t shift = 0;
+    while (((T.n_leaves + ((int64_t)1 << shift) - 1) >> shift) > max_blocks) shift++;
+    const int64_t blocks = (T.n_leaves + ((int64_t)1 << shift) - 1) >> shift;
+    std::vector<uint16_t> table((size_t)blocks, 0xFFFFu);
+    std::vector<uint8_t> seen((size_t)blocks, 0);
+    for (int64_t slot = 0; slot < T.n_leaves; slot++) {      // leaves-first layout: slots [0, n_leaves) are the leaves
+        uint32_t w0;
+        std::memcpy(&w0, T.rec_a.data() + (size_t)slot * 8, 4);
+        const uint16_t portal = (uint16_t)(w0 & 0xFFFFu);
+        const size_t blk = (size_t)(slot >> shift);
+        if (!seen[blk]) { seen[blk] = 1; table[blk] = portal; }
+        else if (table[blk] != portal) table[blk] = 0xFFFFu;
+    }
+    int64_t covered = 0;
+    for (int64_t slot = 0; slot < T.n_leaves; slot++) covered += table[(size_t)(slot >> shift)] != 0xFFFFu;
+    if (covered * 100 < T.n_leaves * 99) return false;
+    T.leaf_block_portal = std::move(table);
+    T.leaf_block_shift = shift;
+    T.rec_a4.resize((size_t)T.n);
+    for (int64_t slot = 0; slot < T.n; slot++) std::memcpy(&T.rec_a4[(size_t)slot], T.rec_a.data() + (size_t)slot * 8 + 4, 4);
+    return true;
+}
+
 static void build_rmq64(TreeTables &T)
 {
     T.canopy_rmq64.resize(T.canopy_rmq.size());

@@ -119,6 +119,16 @@ struct TreeTables {
     std::vector<uint32_t> canopy_rmq;   // [rmq_levels * canopy_nodes]
     int32_t rmq_levels = 0;
     std::vector<uint8_t> rec_a;         // [n * 8], slot order
+    // Four-byte form of the a side (prepare_leaf_blocks; leaves-first layout): rec_a4[slot] = pbot
+    // alone, the portal from a small table kept in LDS -- leaf slots are in id order, the leaves
+    // below one portal are consecutive, so leaf_block_portal[slot >> leaf_block_shift] names the
+    // portal of a whole aligned block of leaf slots (0xFFFF: the block straddles two portals; such
+    // leaves, and all internal nodes, read the 8-byte rec_a entry instead).  Built only when at
+    // least 99 % of the leaves sit in uniform blocks (balanced and near-balanced trees): the a side
+    // of a pair then gathers 4 bytes from a table half the size -- more of it stays in L2.
+    std::vector<float> rec_a4;                 // [n] slot order, or empty
+    std::vector<uint16_t> leaf_block_portal;   // [ceil(n_leaves >> leaf_block_shift)] or empty
+    int32_t leaf_block_shift = 0;
     std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
     std::vector<uint8_t> rec_i;         // [n * record_bytes/2]
     // Lineage sums (deep canopies with a sparse table; prepare_lineage_sums): the a side of a
@@ -185,6 +195,10 @@ bool build_tree_rmq(TreeTables &T, int64_t max_bytes);
 // set when it is not a single rooted tree.
 bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
                    TreeTables &T, std::string &err);
+
+// rec_a4 + leaf_block_portal (see TreeTables); false (tables left empty) when the tree has no canopy,
+// no leaves-first layout, or too few leaves in portal-uniform blocks of at most max_blocks blocks.
+bool prepare_leaf_blocks(TreeTables &T, int max_blocks = 8192);
 
 // rec_r and canopy_rmq64 (see TreeTables) for trees with a canopy and in-order ids; false otherwise.
 bool prepare_rank_table(TreeTables &T);

@@ -432,7 +432,9 @@ class SuchTree:
             from_node_ids = [self._validate_node(n) for n in from_nodes]
             from_nodes_orig = from_nodes.copy()
         if len(from_node_ids) == 0:
-            return []
+            # the reference hands np.array([], dtype=int64) to distances_bulk here, whose shape check
+            # raises (pyx:1072, 892-894): same call, same exception
+            self.distances_bulk(np.array([], dtype=np.int64))
         cands = np.asarray(from_node_ids, dtype=np.int64)
         dev = self._device_tree()
         if k <= dev.KNN_MAX_K:

@@ -33,7 +33,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     TreeTables T;
     if (!prepare_basic(parent, distance, n_nodes, T, g_err)) return 1;
     bool canopy = false;
-    bool lineage = false, ranks = false;
+    bool lineage = false, ranks = false, leaf_blocks = false;
     // the walk family's lineage tables, built both ways (offsets as the deep-canopy path assigns them,
     // and the walk-only path), each with crowns of several sizes
     struct WalkTables {
@@ -44,7 +44,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     };
     std::vector<WalkTables> walk_tables;
     if (strategy == 1) {
-        for (const int64_t hot : {(int64_t)256, (int64_t)16 << 10, (int64_t)4 << 20}) {
+        for (const int64_t hot : {(int64_t)2048, (int64_t)4 << 20}) {
             TreeTables C = T;
             if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27) && prepare_walk_crown(C, hot))
                 walk_tables.push_back({C.lineage_sum, C.lineage_len, C.lineage_node_rec, C.crown_rmq, C.crown_nodes});
@@ -56,6 +56,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
     if (strategy == 2) {
         canopy = prepare_canopy(parent, distance, T);
         if (!canopy) { g_err = "canopy not admitted"; return 2; }
+        leaf_blocks = prepare_leaf_blocks(T, 8192) || prepare_leaf_blocks(T, 1 << 30);   // (the second form: one leaf per block, always uniform)
         lineage = prepare_lineage_sums(T, (int64_t)1 << 27);   // (in-order ids only)
         ranks = prepare_rank_table(T);                         // (in-order ids only)
     }
@@ -120,6 +121,13 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
             if (wa != (A.portal | (A.nb << 16)) || std::memcmp(&pbot_a, &A.pbot, 4) != 0) {
                 g_err = "rec_a disagrees with rec_b / rec_i";
                 return 3;
+            }
+            if (leaf_blocks) {     // the four-byte a side: pbot from rec_a4, the portal from the block table of leaf slots
+                if (std::memcmp(&T.rec_a4[(size_t)sa], &pbot_a, 4) != 0) { g_err = "rec_a4 disagrees with rec_a"; return 14; }
+                if (sa < T.n_leaves) {
+                    const uint16_t e = T.leaf_block_portal[(size_t)(sa >> T.leaf_block_shift)];
+                    if (e != 0xFFFFu && e != (wa & 0xFFFFu)) { g_err = "leaf block table names another portal"; return 15; }
+                }
             }
             if (ranks && A.portal != B.portal) {     // the MRCA-only kernel's form: two rank reads, two table entries
                 const uint64_t m64 = canopy_meet_ranks64(T.canopy_rmq64.data(), T.canopy_nodes, T.rec_r[(size_t)sa] & 0xFFFFu,

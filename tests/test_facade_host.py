@@ -87,6 +87,15 @@ def test_pair_array_conventions(T):
     assert T._coerce_pairs(np.array([[0, 2]], dtype=np.int16)).dtype == np.int64    # widened
 
 
+def test_nearest_neighbors_of_an_empty_candidate_list_fails_like_the_reference(T):
+    """The reference builds np.array([], dtype=int64) from the empty pair list and hands it to
+    distances_bulk, whose shape message indexes shape[1] of a 1-D array (MuchTree.pyx:1071-1072, 892-894)."""
+    with pytest.raises(IndexError):
+        T.nearest_neighbors(0, k=1, from_nodes=[])
+    with pytest.raises(ValueError, match="k must be positive"):
+        T.nearest_neighbors(0, k=0, from_nodes=[])
+
+
 def test_by_name_errors_come_before_any_device_work(T):
     with pytest.raises(TypeError, match="pairs must be a list of tuples"):
         T.distances_by_name((("Ttal", "Tbot"),))

@@ -158,6 +158,35 @@ def test_grid_generator_pairwise_matrix_and_knn_on_a_real_tree(ml_arrays):
     assert [x[1] for x in big] == np.sort(row)[:300].tolist()
 
 
+def test_nearest_neighbors_special_values_order_like_argsort():
+    """NaN distances (either sign bit) come last and -0.0 ties with +0.0, as in the reference's np.argsort
+    (MuchTree.pyx:1075); the device selection (k <= 256) and the host sort (k > 256) must agree."""
+    n_leaves = 400
+    parent, dist = synth.caterpillar_tree(n_leaves)
+    dist = dist.copy()
+    leaves = np.arange(0, 2 * n_leaves, 2)
+    dist[leaves[10:20]] = np.float32(np.nan)
+    dist[leaves[20:30]] = np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]      # NaN with the sign bit set
+    T = SuchTree((parent, dist))
+    cands = [int(x) for x in leaves[5:60]]
+    small = T.nearest_neighbors(int(leaves[0]), k=len(cands), from_nodes=cands)
+    ds = np.array([d for _, d in small])
+    n_nan = int(np.isnan(ds).sum())
+    assert n_nan == 20 and not np.isnan(ds[:-n_nan]).any() and np.isnan(ds[-n_nan:]).all()
+    assert np.all(np.diff(ds[:-n_nan]) >= 0)
+    big = T.nearest_neighbors(int(leaves[0]), k=300, from_nodes=cands)       # host argsort path
+    assert [x for x, _ in big[: len(cands) - n_nan]] == [x for x, _ in small[: len(cands) - n_nan]]
+    # zero-length and negative-zero-length branches give +0.0 and -0.0 ... as equal keys: index order decides
+    parent2, dist2 = synth.balanced_tree(4)
+    dist2 = dist2.copy()
+    dist2[:] = np.float32(0.0)
+    dist2[::4] = np.float32(-0.0)
+    Z = SuchTree((parent2, dist2))
+    zc = [int(x) for x in range(2, 32, 2)]
+    got = Z.nearest_neighbors(0, k=len(zc), from_nodes=zc)
+    assert [x for x, _ in got] == zc and all(d == 0.0 for _, d in got)
+
+
 @pytest.mark.parametrize("which", ["gopher_louse", "fish_worm"])
 def test_config5_linked_distances(which):
     d = golden_path(which)
