@@ -252,6 +252,9 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     fault = kFaultInit;
     // SUCHTREE_AMD_TRACE_PIPE=1: one line per call on stderr with the host thread's time by phase
     static const bool trace = std::getenv("SUCHTREE_AMD_TRACE_PIPE") != nullptr;
+    // SUCHTREE_AMD_PIPE_SKIP_CPU=1 (measurement only, results are garbage): no pack and no unpack passes --
+    // what the GPU / link side of the pipeline takes when the host's memory system is otherwise idle
+    static const bool skip_cpu = std::getenv("SUCHTREE_AMD_PIPE_SKIP_CPU") != nullptr;
     using Clock = std::chrono::steady_clock;
     double t_wait = 0, t_unpack = 0, t_pack = 0, t_launch = 0, t_prefault = 0;
     const Clock::time_point t_begin = Clock::now();
@@ -285,7 +288,7 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         const int32_t *src_m = static_cast<const int32_t *>(s.h_m);
         double *dst_d = out_dist ? out_dist + s.off : nullptr;
         int32_t *dst_m = out_mrca ? out_mrca + s.off : nullptr;
-        if (dst_d || dst_m)
+        if ((dst_d || dst_m) && !skip_cpu)
             P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) {
                 if (dst_d) widen_f32_to_f64(dst_d + b, src_d + b, e - b);
                 if (dst_m) copy_stream(dst_m + b, src_m + b, (e - b) * 4);
@@ -321,7 +324,7 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         Clock::time_point tp = trace ? Clock::now() : Clock::time_point();
-        pack(s, off, m);
+        if (!skip_cpu) pack(s, off, m);
         lap(t_pack, tp);
         const int rc = launch(s, off, m);
         if (rc != ST_OK) return bail(rc, g_last_error);
