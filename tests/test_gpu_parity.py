@@ -4,6 +4,7 @@ Bar (BASELINE.json north_star): MRCA ids bit-exact; distances within 1e-6
 relative.  Because the kernels reproduce the reference's float32 summation
 order the tests demand more: the float64 outputs must be bit-identical.
 """
+import os
 import threading
 
 import numpy as np
@@ -206,6 +207,117 @@ def test_walk_only_tree_with_sparse_table_and_lineage_sums():
         assert np.array_equal(m, want_m[:3000])
         assert np.array_equal(dev.distances_host(allp, False, True)[1], want_m)
     dev.close()
+
+
+@pytest.mark.parametrize("which", ["walk_only", "ml"])
+def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
+    """k_walk_sorted (batches >= 32768 pairs on trees with the sparse table and both lineage tables) and
+    every table it builds on, switched on and off in all combinations: tile sort, crown (shared portal
+    blocks + crown sparse table), lineage lengths, whole-tree sparse table.  A walk-only tree (the canopy
+    family refuses it) and ml.tree with the walk family forced.  Leaves and internal nodes, near pairs,
+    (x, x), a batch that is no multiple of the tile, device buffers and the host path."""
+    import itertools
+    import torch
+    rng = np.random.default_rng(17)
+    if which == "walk_only":
+        parent, dist = _random_shape_tree(rng, 120_000, 0.97)
+        dev = _capi.DeviceTree(parent, dist)
+        assert dev.info()["strategy"] == "walk"
+    else:
+        parent, dist, _ = ml_arrays
+        dev = _capi.DeviceTree(parent, dist)
+        dev.set_strategy("walk")
+    n = len(parent)
+    assert dev.info()["lineage_entries"] > n
+    O = OracleTree(parent, dist)
+    a = rng.integers(0, n - 30, 20_000)
+    allp = np.concatenate([rng.integers(0, n, (70_001, 2)), np.stack([a, a + rng.integers(0, 30, a.size)], 1),
+                           np.stack([a[:2000], a[:2000]], 1)]).astype(np.int64)
+    cores = len(os.sched_getaffinity(0))
+    want_d, want_m = O.distances_mt(allp, cores), O.mrca_bulk(allp)
+    t = torch.from_numpy(allp).cuda()
+    out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+    out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+    for srt, crown, lens, rmq in itertools.product((1, 0), repeat=4):
+        for name, v in (("walk_sort", srt), ("walk_crown", crown), ("lineage_lens", lens), ("tree_rmq", rmq)):
+            dev.set_option(name, v)
+        what = "sort=%d crown=%d lens=%d rmq=%d" % (srt, crown, lens, rmq)
+        out_d.fill_(-1.0)
+        dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+        dev.fault_check()
+        assert_bits_equal(out_d.cpu().numpy(), want_d, what)
+        assert np.array_equal(out_m.cpu().numpy(), want_m), what
+    for name in ("walk_sort", "walk_crown", "lineage_lens", "tree_rmq"):
+        dev.set_option(name, 1)
+    # distances only / MRCA ids only, float32 sink, the host path (pinned staging read once, coalesced stores)
+    dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), 0)
+    assert_bits_equal(out_d.cpu().numpy(), want_d, "distances only")
+    d, m = dev.distances_host(allp, True, True)
+    assert_bits_equal(d, want_d, "host path")
+    assert np.array_equal(m, want_m)
+    assert_bits_equal(dev.distances_host(allp.astype(np.int32), True, False)[0], want_d, "host path, int32 ids")
+    # an id out of range inside a sorted tile: reported like the reference reports it, the handle stays usable
+    bad = allp.copy()
+    bad[40_000, 1] = n + 5
+    with pytest.raises(InvalidNodeError) as err:
+        dev.distances_host(bad, True, True)
+    assert err.value.node_id == n + 5
+    tb = torch.from_numpy(bad).cuda()
+    dev.distances_device(tb.data_ptr(), len(bad), out_d.data_ptr(), out_m.data_ptr())
+    with pytest.raises(InvalidNodeError):
+        dev.fault_check()
+    got = out_d.cpu().numpy()
+    assert np.isnan(got[40_000]) and int(out_m[40_000].item()) == -1
+    keep = np.arange(len(bad)) != 40_000
+    assert_bits_equal(got[keep], want_d[keep], "the rest of a batch with a bad id")
+    dev.close()
+
+
+def test_walk_tables_are_optional(monkeypatch):
+    """SUCHTREE_AMD_WALK_TABLE_MB=0: a tree only the walk family serves is built without the sparse table
+    and the lineage tables (they are aids, never requirements) and answers by climbing."""
+    rng = np.random.default_rng(3)
+    parent, dist = _random_shape_tree(rng, 30_000, 0.97)
+    pairs = rng.integers(0, len(parent), (50_000, 2))
+    O = OracleTree(parent, dist)
+    want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
+    for mb, has_tables in (("0", False), ("1", False), ("4096", True)):
+        monkeypatch.setenv("SUCHTREE_AMD_WALK_TABLE_MB", mb)
+        dev = _capi.DeviceTree(parent, dist, strategy="walk")
+        info = dev.info()
+        assert (info["lineage_entries"] > 0) == has_tables, (mb, info)
+        d, m = dev.distances_host(pairs, True, True)
+        assert_bits_equal(d, want_d, "budget %s MB" % mb)
+        assert np.array_equal(m, want_m)
+        dev.close()
+
+
+def test_four_byte_a_side_of_the_predicated_kernel():
+    """rec_a4: on balanced-like trees the first node of a pair costs a 4-byte gather (its understory sum;
+    the portal comes from a block table in LDS).  On and off, leaves (the fast path) and internal nodes
+    (the 8-byte fallback), device buffers, int32 host path; a random tree, where the form is not built."""
+    import torch
+    for parent, dist in (synth.balanced_tree(16), synth.complete_tree(50_000, seed=2), synth.random_binary_tree(40_000, seed=9)):
+        n = len(parent)
+        rng = np.random.default_rng(n)
+        dev = _capi.DeviceTree(parent, dist)
+        O = OracleTree(parent, dist)
+        leaf = np.arange(0, n, 2)
+        pairs = np.concatenate([rng.choice(leaf, size=(150_000, 2)), rng.integers(0, n, (50_000, 2))]).astype(np.int64)
+        want_d, want_m = O.distances_mt(pairs, len(os.sched_getaffinity(0))), O.mrca_bulk(pairs)
+        t = torch.from_numpy(pairs).cuda()
+        out_d = torch.empty(len(pairs), dtype=torch.float64, device="cuda")
+        out_m = torch.empty(len(pairs), dtype=torch.int32, device="cuda")
+        for on in (1, 0):
+            dev.set_option("rec_a4", on)
+            dev.distances_device(t.data_ptr(), len(pairs), out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d.cpu().numpy(), want_d, "rec_a4=%d" % on)
+            assert np.array_equal(out_m.cpu().numpy(), want_m)
+            d, m = dev.distances_host(pairs.astype(np.int32), True, True)
+            assert_bits_equal(d, want_d, "rec_a4=%d host int32" % on)
+            assert np.array_equal(m, want_m)
+        dev.close()
 
 
 def test_special_float_values():
