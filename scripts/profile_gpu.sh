@@ -6,7 +6,7 @@
 # usage: scripts/profile_gpu.sh <round-tag> [bench args...]
 set -u
 TAG=${1:-r02}; shift || true
-ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-microbench"}
+ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-microbench --no-other-configs"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT $REPO/scripts/micro/bin

@@ -54,6 +54,7 @@ def counter_means(pmc_dir, kernel_substr):
 def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
     kernel = sys.argv[3] if len(sys.argv) > 3 else "k_canopy"
+    pairs_per_launch = float(sys.argv[4]) if len(sys.argv) > 4 else 1e8
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(prof, exist_ok=True)
     lines = []
@@ -64,7 +65,7 @@ def main():
         for r in stats:
             lines.append(",".join(str(r[c]) for c in cols))
     dur = per_kernel_durations(os.path.join(out_dir, "trace"))
-    summary = {"tag": tag, "kernel": kernel, "kernels": {}, "pairs_per_launch": 1e8}
+    summary = {"tag": tag, "kernel": kernel, "kernels": {}, "pairs_per_launch": pairs_per_launch}
     for k, v in dur.items():
         v2 = sorted(v)
         summary["kernels"][k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": v2[0], "max_ns": v2[-1]}
@@ -77,6 +78,7 @@ def main():
             means, counts = counter_means(d, full or kernel)
             counters.update(means)
     summary["counters_mean_per_launch"] = counters
+    summary["counters_per_pair"] = {k: v / pairs_per_launch for k, v in counters.items()}
     # calibration: the same counters on launches of exactly known traffic
     # (scripts/micro/calib_requests.hip): bytes per read request of a coalesced 16-B-per-lane
     # stream and of random 32-byte reads that touch one 64-byte sector each
