@@ -224,14 +224,37 @@ static WalkParams walk_params(const st_tree *t)
     return P;
 }
 
-// Smallest batch the tile-sorted walk kernel takes (below it k_walk's shorter start-up wins).
-constexpr int64_t kWalkSortedMinPairs = 32768;
-constexpr int kWalkSortQ = 4;      // 4096-pair tiles: 57 KiB of LDS scratch, two workgroups per CU
+// Smallest batch the tile-sorted walk kernel takes: below it k_walk's finer grain wins (a 1e5-pair
+// batch is 25 tiles of 4096 pairs on 256 CUs; measured on ml.tree, pairs per second unsorted / sorted:
+// 1e5 pairs 4.9e9 / 1.3e9, 4e5 8.0e9 / 5.3e9, 8e5 9.1e9 / 1.03e10, 3.2e6 1.0e10 / 1.08e10, 1e7 1.1e10 /
+// 1.35e10).  Tiles: 4096 pairs on trees with canopy tables, 2048 on trees only the walk family serves
+// (1e6-leaf depth-338 tree, 1e7 / 4e7 pairs: 5.93e9 / 6.43e9 against 5.76e9 / 5.90e9 with 4096;
+// ml.tree: 1.28e10 / 1.34e10 against 1.32e10 / 1.41e10).
+constexpr int64_t kWalkSortedMinPairs = 524288;
 
 static bool walk_sorted_ready(const st_tree *t)
 {
     return t->walk_sort && t->tree_rmq && t->d_tree_rmq && t->lineage_sums && t->d_lineage && t->d_lineage_node_rec &&
            t->lineage_lens && t->d_lineage_len;
+}
+
+template <int Q, typename Src>
+static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, const Src &src, int64_t n, DistSink out_d,
+                                     int32_t *out_m, Fault *fault, hipStream_t stream)
+{
+    constexpr int64_t tile = (int64_t)Q * kWalkSortBlock;
+    const size_t lds = walk_sort_scratch_bytes(Q);
+    const int wg_per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / lds)));
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + tile - 1) / tile, (int64_t)t->n_cu * wg_per_cu));
+    int key_shift = 0;      // keys are edge counts of b's lineage below the meeting node
+    while ((t->info.depth >> key_shift) >= kWalkSortBuckets) key_shift++;
+    auto kern = k_walk_sorted<Q, Src>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWalkSortBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, key_shift);
+    return hipGetLastError();
 }
 
 template <typename Src>
@@ -240,13 +263,11 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
 {
     const WalkParams P = walk_params(t);
     if (out_d.any() && n >= kWalkSortedMinPairs && walk_sorted_ready(t)) {
-        constexpr int64_t tile = (int64_t)kWalkSortQ * kWalkSortBlock;
-        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + tile - 1) / tile, (int64_t)t->n_cu * 2));
-        int key_shift = 0;      // keys are edge counts of b's lineage below the meeting node
-        while ((t->info.depth >> key_shift) >= kWalkSortBuckets) key_shift++;
-        hipLaunchKernelGGL((k_walk_sorted<kWalkSortQ, Src>), dim3((unsigned)blocks), dim3(kWalkSortBlock),
-                           walk_sort_scratch_bytes(kWalkSortQ), stream, P, src, (long long)n, out_d, out_m, fault, key_shift);
-        return hipGetLastError();
+        static const int forced = std::getenv("SUCHTREE_AMD_WALK_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_WALK_SORT_Q")) : 0;   // tuning experiments
+        const int q = forced ? forced : t->has_canopy ? 4 : 2;
+        if (q == 4) return launch_walk_sorted<4>(t, P, src, n, out_d, out_m, fault, stream);
+        if (q == 2) return launch_walk_sorted<2>(t, P, src, n, out_d, out_m, fault, stream);
+        return launch_walk_sorted<1>(t, P, src, n, out_d, out_m, fault, stream);
     }
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);

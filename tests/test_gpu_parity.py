@@ -211,7 +211,7 @@ def test_walk_only_tree_with_sparse_table_and_lineage_sums():
 
 @pytest.mark.parametrize("which", ["walk_only", "ml"])
 def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
-    """k_walk_sorted (batches >= 32768 pairs on trees with the sparse table and both lineage tables) and
+    """k_walk_sorted (batches >= 524288 pairs on trees with the sparse table and both lineage tables) and
     every table it builds on, switched on and off in all combinations: tile sort, crown (shared portal
     blocks + crown sparse table), lineage lengths, whole-tree sparse table.  A walk-only tree (the canopy
     family refuses it) and ml.tree with the walk family forced.  Leaves and internal nodes, near pairs,
@@ -231,7 +231,7 @@ def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
     assert dev.info()["lineage_entries"] > n
     O = OracleTree(parent, dist)
     a = rng.integers(0, n - 30, 20_000)
-    allp = np.concatenate([rng.integers(0, n, (70_001, 2)), np.stack([a, a + rng.integers(0, 30, a.size)], 1),
+    allp = np.concatenate([rng.integers(0, n, (540_001, 2)), np.stack([a, a + rng.integers(0, 30, a.size)], 1),
                            np.stack([a[:2000], a[:2000]], 1)]).astype(np.int64)
     cores = len(os.sched_getaffinity(0))
     want_d, want_m = O.distances_mt(allp, cores), O.mrca_bulk(allp)
