@@ -156,3 +156,40 @@ def test_quartet_topologies_restatement():
     # the output row is a permutation of the input row, by the table at :1319-1320
     q = np.array([[L["B"], L["D"], L["A"], L["E"]]])
     assert O.quartets(q)[0].tolist() == [L["B"], L["A"], L["D"], L["E"]]
+
+
+def test_spectral_properties_csv_gopher_lice():
+    """A reference-held number for the two-tree graph Laplacian that does not depend on node numbering:
+    data/spectral_properties.csv of the reference (written in 2017 by docs/old_notebooks/example_3.ipynb with real
+    dendropy) holds, for "Gopher, Lice" at additions = deletions = swaps = 0, skew and kurtosis of a Gaussian
+    KDE of the Laplacian's spectrum on linspace(-0.5, 1.5, 100) and the gap between its two largest eigenvalues.
+    That code base counted the resolved-polytomy edges (length epsilon) in the mean edge length that weights
+    the links; today's reference masks them (MuchTree.pyx:3120-3121), and so does the oracle.  With that one
+    difference applied, the oracle's adjacency (trees from this repo's Newick ingest, gopher-louse fixtures)
+    reproduces all three numbers to the 12 digits the file prints (scripts/spectral_pins.py tries every study)."""
+    import pandas as pd
+    from scipy.stats import gaussian_kde, kurtosis, skew
+    from oracle import oracle as orc
+    from suchtree_amd import SuchTree
+    from suchtree_amd.linked import SuchLinkedTrees
+    d = golden_path("gopher_louse")
+    A, B = SuchTree(d + "/gopher.tree"), SuchTree(d + "/lice.tree")
+    SLT = SuchLinkedTrees(A, B, pd.read_csv(d + "/links.csv", index_col=0))
+    assert (A.num_leaves, B.num_leaves, SLT.n_links) == (15, 17, 17)          # the row's n_hosts, n_guests, n_links
+    fa, fb = A._flat, B._flat
+    aj = orc.linked_adjacency((fa.parent, fa.left, fa.right, fa.distance), (fb.parent, fb.left, fb.right, fb.distance),
+                              SLT.linklist, SLT.subset_a_root, SLT.subset_b_root, A.polytomy_epsilon, B.polytomy_epsilon)
+    na = A.size
+    ta = orc.tree_adjacency(fa.parent, fa.left, fa.right, fa.distance, A.root_node, A.polytomy_epsilon)[0]
+    tb = orc.tree_adjacency(fb.parent, fb.left, fb.right, fb.distance, B.root_node, B.polytomy_epsilon)[0]
+    is_link = np.zeros_like(aj, dtype=bool)
+    is_link[:na, na:] = aj[:na, na:] > 0
+    is_link[na:, :na] = aj[na:, :na] > 0
+    assert is_link.sum() == 2 * 17
+    aj[is_link] = (ta[ta > 0].mean() / ta.max() + tb[tb > 0].mean() / tb.max()) / 2.0      # the 2017 link weight
+    lam = np.linalg.eigvalsh(orc.linked_laplacian(aj))
+    sd = gaussian_kde(lam).pdf(np.linspace(-0.5, 1.5, 100))
+    assert abs((lam[-1] - lam[-2]) - 0.351291850306) < 1e-11
+    assert abs(skew(sd) - (-0.285380791319)) < 1e-11
+    assert abs(kurtosis(sd) - (-0.801738279906)) < 1e-11
+
