@@ -12,6 +12,7 @@ What is written (all of it DATA -- inputs and expected outputs -- never source):
   known_answers.json       the values printed in the reference docs, with citations
   gopher_louse/, fish_worm/  the two-tree co-phylogeny data sets of BASELINE config 5 and
                            the notebooks' printed answers (data/gopher-louse, data/fish-worm)
+  ml_nj_leaf_map.npz        for every leaf of ml.tree (leaf_ids order) the id of the same taxon in nj.tree
   ml_tree.npz / nj_tree.npz  flat arrays (parent:int32, distance:float32, leaf ids)
                            of data/bigtrees/{ml,nj}.tree produced by
                            suchtree_amd.newick -- BASELINE config 2's tree, shipped as
@@ -97,8 +98,10 @@ def main():
         json.dump(known, fh, indent=1, sort_keys=True)
 
     digests = {}
+    leaves_of = {}
     for name in ("ml", "nj"):
         t = flat_tree_from_newick(open(os.path.join(REF, "data/bigtrees/%s.tree" % name)).read())
+        leaves_of[name] = dict(t.leaves)
         leaf_ids = np.array(list(t.leaves.values()), dtype=np.int32)
         np.savez_compressed(os.path.join(OUT, "%s_tree.npz" % name), parent=t.parent, distance=t.distance,
                             leaf_ids=leaf_ids, depth=np.int32(t.depth), root=np.int32(t.root))
@@ -111,6 +114,11 @@ def main():
             "parent_sha256": digest(t.parent), "distance_sha256": digest(t.distance),
             "dist_sha256": digest(O.distances(pairs)), "mrca_sha256": digest(O.mrca_bulk(pairs)),
         }
+    # the same taxa in both trees (docs/examples/SuchTree_examples.md:296-352 compares their distances by name):
+    # for every leaf of ml.tree, in the order of ml_tree.npz's leaf_ids, the id of the leaf of that name in nj.tree
+    assert set(leaves_of["ml"]) == set(leaves_of["nj"])
+    np.savez_compressed(os.path.join(OUT, "ml_nj_leaf_map.npz"),
+                        nj_id_of_ml_leaf=np.array([leaves_of["nj"][k] for k in leaves_of["ml"]], dtype=np.int32))
     t = flat_tree_from_newick(open(os.path.join(OUT, "test.tree")).read())
     O = OracleTree(t.parent, t.distance, t.left, t.right, t.support)
     allp = np.array([(a, b) for a in range(t.size) for b in range(t.size)], dtype=np.int64)

@@ -193,3 +193,25 @@ def test_spectral_properties_csv_gopher_lice():
     assert abs(skew(sd) - (-0.285380791319)) < 1e-11
     assert abs(kurtosis(sd) - (-0.801738279906)) < 1e-11
 
+
+
+def test_docs_correlations_between_ml_and_nj_tree(ml_arrays, nj_arrays):
+    """A reference-held number for config 2's trees: docs/examples/SuchTree_examples.md:296-352 draws one
+    million random pairs of taxon names, takes their distances in data/bigtrees/ml.tree and nj.tree with
+    distances_by_name and prints Spearman's rs 0.961, Kendall's tau 0.824, Pearson's r 0.969 (real dendropy,
+    unseeded pairs, three decimals).  Here: the flat-array fixtures of both trees (this repo's parser), the
+    committed taxon map between them, 300,000 seeded pairs through the oracle.  Sampling noise at that size is
+    below 1e-3; the bar is the printed precision."""
+    import os
+    from scipy.stats import kendalltau, pearsonr, spearmanr
+    p1, d1, leaves1 = ml_arrays
+    p2, d2, _ = nj_arrays
+    nj_of = np.load(golden_path("ml_nj_leaf_map.npz"))["nj_id_of_ml_leaf"].astype(np.int64)
+    assert len(nj_of) == len(leaves1) == 54327 and len(set(nj_of.tolist())) == 54327
+    idx = np.random.default_rng(11).integers(0, len(leaves1), (300_000, 2))
+    cores = len(os.sched_getaffinity(0))
+    D1 = OracleTree(p1, d1).distances_mt(leaves1[idx], cores)
+    D2 = OracleTree(p2, d2).distances_mt(nj_of[idx], cores)
+    assert abs(spearmanr(D1, D2)[0] - 0.961) < 0.0015
+    assert abs(kendalltau(D1, D2)[0] - 0.824) < 0.0015
+    assert abs(pearsonr(D1, D2)[0] - 0.969) < 0.0015
