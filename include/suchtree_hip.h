@@ -245,6 +245,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "walk_crown": 1 (default) = the walk family reads the long upper part of that stream from the
  * block of the node's portal (shared by all nodes below it: a cache-resident hot set) and takes
  * meeting nodes of different portals from the crown's own sparse table; 0 = own block, whole-tree table.
+ * "walk_ladder": 1 (default) = where the crown is small enough (<= 8192 nodes) the tile-sorted walk kernel keeps
+ * its ladder form in LDS and climbs the upper part of the second node's side there (three edges per 16-byte LDS
+ * read) instead of streaming it; 0 = it streams it from the portal's block.
  * "walk_sort": 1 (default) = batches of >= 524288 pairs on trees with the sparse table and both lineage
  * tables run the tile-sorted walk kernel (a wave's 64 pairs have streams of similar length); 0 = k_walk.
  * "rec_a4": 1 (default) = on trees whose leaves sit in portal-uniform aligned blocks of leaf slots (balanced

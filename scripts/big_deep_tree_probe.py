@@ -27,11 +27,12 @@ pairs = torch.from_numpy(pairs_h).cuda()
 out_d = torch.empty(n, dtype=torch.float64, device="cuda")
 out_m = torch.empty(n, dtype=torch.int32, device="cuda")
 O = OracleTree(parent, dist)
-for on, lens, srt, crown in ((1, 1, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0)):
+for on, lens, srt, crown, lad in ((1, 1, 1, 1, 1), (1, 1, 1, 1, 0), (1, 1, 0, 1, 0), (1, 1, 1, 0, 0), (1, 1, 0, 0, 0), (1, 0, 0, 0, 0), (0, 0, 0, 0, 0)):
     tree.set_option("tree_rmq", on)
     tree.set_option("lineage_lens", lens)
     tree.set_option("walk_sort", srt)
     tree.set_option("walk_crown", crown)
+    tree.set_option("walk_ladder", lad)
     times = []
     for _ in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,4 +45,4 @@ for on, lens, srt, crown in ((1, 1, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (1, 1, 0,
     k = 20000
     ok = (np.array_equal(out_d[:k].cpu().numpy().view(np.int64), O.distances(pairs_h[:k]).view(np.int64))
           and np.array_equal(out_m[:k].cpu().numpy(), O.mrca_bulk(pairs_h[:k])))
-    print("tree_rmq=%d lineage_lens=%d walk_sort=%d walk_crown=%d  median %.3f ms  %.3e pairs/s  parity %s" % (on, lens, srt, crown, float(np.median(times)), n / np.median(times) * 1e3, "ok" if ok else "MISMATCH"), flush=True)
+    print("tree_rmq=%d lineage_lens=%d walk_sort=%d walk_crown=%d walk_ladder=%d  median %.3f ms  %.3e pairs/s  parity %s" % (on, lens, srt, crown, lad, float(np.median(times)), n / np.median(times) * 1e3, "ok" if ok else "MISMATCH"), flush=True)

@@ -92,9 +92,23 @@ static bool mrca_ranks_ready(const st_tree *t)
     return t->strategy == ST_STRATEGY_CANOPY && t->mrca_ranks && t->d_rec_r && t->d_rmq64;
 }
 
+// Deep-canopy trees whose canopy image leaves the tile-sorted canopy kernel only small tiles (nj.tree: 9111
+// canopy nodes = 146 KiB, 1024-pair tiles) are served faster by the tile-sorted WALK kernel once its crown
+// ladder exists: a crown of <= 5120 nodes, 4096-pair tiles (nj.tree, 1e7 pairs: 1.73e10 against 1.60e10
+// pairs/s; ml.tree keeps the canopy kernel: 2.15e10 against 1.73e10).  Large batches with distances only.
+static bool walk_sorted_ready(const st_tree *t);
+constexpr int64_t kWalkSortedMinPairs = 524288;
+static bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
+{
+    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || !want_dist || n < kWalkSortedMinPairs) return false;
+    const int q = sorted_q(t);
+    return q > 0 && q < 4 && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
+}
+
 static bool wants_device_stage(const st_tree *t, int64_t m)
 {
     if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
+    if (prefers_walk_sorted(t, m, true)) return false;      // (that kernel reads every pair once and stores coalesced)
     return m >= (canopy_min_pairs(t) == kSortedMinPairs ? kSortedMinPairsHost : kCanopyMinPairs);
 }
 
@@ -211,6 +225,7 @@ static WalkParams walk_params(const st_tree *t)
     P.stride = t->d_stride;
     P.rmq = t->tree_rmq ? t->d_tree_rmq : nullptr;
     P.n_nodes = t->n_nodes;
+    P.crown_ladder = nullptr;
     if (t->d_lineage && t->d_lineage_node_rec && t->lineage_sums) {
         P.lineage.node_rec = t->d_lineage_node_rec;
         P.lineage.sums = t->d_lineage;
@@ -219,6 +234,7 @@ static WalkParams walk_params(const st_tree *t)
         if (t->walk_crown && t->d_crown_rmq) {
             P.lineage.crown_rmq = t->d_crown_rmq;
             P.lineage.crown_nodes = t->crown_nodes;
+            if (t->walk_ladder) P.crown_ladder = t->d_crown_ladder;
         }
     }
     return P;
@@ -229,8 +245,7 @@ static WalkParams walk_params(const st_tree *t)
 // 1e5 pairs 4.9e9 / 1.3e9, 4e5 8.0e9 / 5.3e9, 8e5 9.1e9 / 1.03e10, 3.2e6 1.0e10 / 1.08e10, 1e7 1.1e10 /
 // 1.35e10).  Tiles: 4096 pairs on trees with canopy tables, 2048 on trees only the walk family serves
 // (1e6-leaf depth-338 tree, 1e7 / 4e7 pairs: 5.93e9 / 6.43e9 against 5.76e9 / 5.90e9 with 4096;
-// ml.tree: 1.28e10 / 1.34e10 against 1.32e10 / 1.41e10).
-constexpr int64_t kWalkSortedMinPairs = 524288;
+// ml.tree: 1.28e10 / 1.34e10 against 1.32e10 / 1.41e10).  (kWalkSortedMinPairs = 524288, above.)
 
 static bool walk_sorted_ready(const st_tree *t)
 {
@@ -238,17 +253,17 @@ static bool walk_sorted_ready(const st_tree *t)
            t->lineage_lens && t->d_lineage_len;
 }
 
-template <int Q, typename Src>
+template <int Q, bool LADDER, typename Src>
 static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, const Src &src, int64_t n, DistSink out_d,
                                      int32_t *out_m, Fault *fault, hipStream_t stream)
 {
     constexpr int64_t tile = (int64_t)Q * kWalkSortBlock;
-    const size_t lds = walk_sort_scratch_bytes(Q);
+    const size_t lds = walk_sort_scratch_bytes(Q) + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
     const int wg_per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / lds)));
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + tile - 1) / tile, (int64_t)t->n_cu * wg_per_cu));
     int key_shift = 0;      // keys are edge counts of b's lineage below the meeting node
     while ((t->info.depth >> key_shift) >= kWalkSortBuckets) key_shift++;
-    auto kern = k_walk_sorted<Q, Src>;
+    auto kern = k_walk_sorted<Q, LADDER, Src>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -264,10 +279,20 @@ static hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistS
     const WalkParams P = walk_params(t);
     if (out_d.any() && n >= kWalkSortedMinPairs && walk_sorted_ready(t)) {
         static const int forced = std::getenv("SUCHTREE_AMD_WALK_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_WALK_SORT_Q")) : 0;   // tuning experiments
+        if (P.crown_ladder) {
+            // the crown's ladder in LDS: the largest tile that fits beside it
+            const size_t image = (size_t)P.lineage.crown_nodes * 16;
+            const int q = forced ? forced : image + walk_sort_scratch_bytes(4) <= 160 * 1024 ? 4 : image + walk_sort_scratch_bytes(2) <= 160 * 1024 ? 2 : 1;
+            if (image + walk_sort_scratch_bytes(q) <= 160 * 1024) {
+                if (q == 4) return launch_walk_sorted<4, true>(t, P, src, n, out_d, out_m, fault, stream);
+                if (q == 2) return launch_walk_sorted<2, true>(t, P, src, n, out_d, out_m, fault, stream);
+                return launch_walk_sorted<1, true>(t, P, src, n, out_d, out_m, fault, stream);
+            }
+        }
         const int q = forced ? forced : t->has_canopy ? 4 : 2;
-        if (q == 4) return launch_walk_sorted<4>(t, P, src, n, out_d, out_m, fault, stream);
-        if (q == 2) return launch_walk_sorted<2>(t, P, src, n, out_d, out_m, fault, stream);
-        return launch_walk_sorted<1>(t, P, src, n, out_d, out_m, fault, stream);
+        if (q == 4) return launch_walk_sorted<4, false>(t, P, src, n, out_d, out_m, fault, stream);
+        if (q == 2) return launch_walk_sorted<2, false>(t, P, src, n, out_d, out_m, fault, stream);
+        return launch_walk_sorted<1, false>(t, P, src, n, out_d, out_m, fault, stream);
     }
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
@@ -293,7 +318,7 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, in
     const bool ranks_only = !d_out.any() && d_mrca && mrca_ranks_ready(t) && n >= kCanopyMinPairs;
     const bool canopy = ranks_only ||
                         (t->strategy == ST_STRATEGY_CANOPY && n >= canopy_min_pairs(t) &&
-                         (allow_sorted || !(t->tile_sort && sorted_q(t) > 0)));
+                         (allow_sorted || !(t->tile_sort && sorted_q(t) > 0)) && !prefers_walk_sorted(t, n, d_out.any()));
     const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, fault, stream)
                                 : launch_walk(t, src, n, d_out, d_mrca, fault, stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

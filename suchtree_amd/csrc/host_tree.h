@@ -63,6 +63,8 @@ struct st_tree {
     float *d_lineage_len = nullptr;           // lineage lengths (same blocks as d_lineage), else NULL
     uint32_t *d_lineage_node_rec = nullptr;   // {depth, lineage offset, portal's lineage offset, nb | portal rank << 8} by node id
     uint64_t *d_crown_rmq = nullptr;          // sparse table over the walk family's crown (in-order ids), else NULL
+    LadderEntry *d_crown_ladder = nullptr;    // ladder form of the crown by rank (crowns that fit LDS), else NULL
+    int walk_ladder = 1;      // tuning: 0 = k_walk_sorted streams the crown part of b's side from the portal's block instead of climbing it in LDS
     int32_t crown_nodes = 0;
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the

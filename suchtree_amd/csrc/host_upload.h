@@ -30,6 +30,20 @@ static int64_t crown_hot_budget()
     return std::max<int64_t>(1, kb) << 10;
 }
 
+// Largest crown (nodes) the tile-sorted walk kernel keeps in LDS as a ladder, 16 bytes per node beside
+// the sort scratch.  Trees only the walk family serves: as large as LDS allows (8192 nodes + a 1024-pair
+// tile, or ~6100 nodes + 2048 pairs) -- there the short streams below the portals are what counts (1e6-leaf
+// depth-338 tree: 7.37e9 pairs/s with 8192 or 6144, 7.04e9 with 4096, 6.67e9 with 2048).  Deep-canopy trees
+// (the walk family is their second family): 5120 nodes, so that 4096-pair tiles fit (ml.tree 1.71e10, nj.tree
+// 1.74e10; with 8192: 1.53e10 / 1.40e10).  profiles/walk_ladder_sweep_r03.log.
+// SUCHTREE_AMD_CROWN_LADDER_NODES: tuning experiments (0 = never).
+static int crown_ladder_nodes(bool has_canopy)
+{
+    int nodes = has_canopy ? 5120 : 8192;
+    if (const char *env = std::getenv("SUCHTREE_AMD_CROWN_LADDER_NODES")) nodes = std::atoi(env);
+    return std::max(0, std::min(nodes, 8704));
+}
+
 static int build_tables_impl(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
 {
     std::string err;
@@ -56,7 +70,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
                 // a's side of every pair from one read (tree_prep.h: lineage sums), b's side of the walk
                 // family as a stream (lineage lengths); 4 bytes per node and level each, so only while
                 // the table stays below kMaxLineageEntries
-                if (prepare_lineage_sums(B.T, kMaxLineageEntries)) (void)prepare_walk_crown(B.T, crown_hot_budget());
+                if (prepare_lineage_sums(B.T, kMaxLineageEntries)) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(true));
             }
         }
     }
@@ -78,7 +92,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
             // sums + lens when both fit, else the sums alone
             if (!prepare_walk_lineage(B.T, std::min<int64_t>(budget / 8, kMaxWalkLineageEntries), true))
                 (void)prepare_walk_lineage(B.T, std::min<int64_t>(budget / 4, kMaxWalkLineageEntries), false);
-            if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget());
+            if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(false));
         }
     }
     return ST_OK;
@@ -157,7 +171,10 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
             return;
         }
         (void)upload_optional(&t->d_lineage_len, T.lineage_len, &bytes);
-        if (upload_optional(&t->d_crown_rmq, T.crown_rmq, &bytes)) t->crown_nodes = T.crown_nodes;
+        if (upload_optional(&t->d_crown_rmq, T.crown_rmq, &bytes)) {
+            t->crown_nodes = T.crown_nodes;
+            (void)upload_optional(&t->d_crown_ladder, T.crown_ladder, &bytes);
+        }
     };
     if (rc == ST_OK && !B.canopy_ok) upload_walk_lineage();
     if (rc == ST_OK && B.canopy_ok) {

@@ -15,6 +15,7 @@ struct WalkParams {
     const uint64_t *rmq;     // whole-tree sparse table for the meeting node, or NULL
     long long n_nodes;
     LineageView lineage;     // a's side in one read (deep trees with lineage sums), else empty
+    const LadderEntry *crown_ladder;   // ladder form of the crown by rank (k_walk_sorted stages it into LDS), or NULL
 };
 
 template <typename Src>
@@ -61,11 +62,22 @@ __host__ __device__ constexpr size_t walk_sort_scratch_bytes(int q)
     return (size_t)q * kWalkSortBlock * 18 + (size_t)kWalkSortBuckets * 4 + 64;
 }
 
-template <int Q, typename Src>
+// LADDER: the crown is small enough for LDS (tree_prep.h: crown_ladder): its ladder form is staged in
+// front of the scratch and the crown part of every b side is climbed there, three edges per 16-byte LDS
+// read; only the nodes below the portal are streamed from global memory.
+template <int Q, bool LADDER, typename Src>
 __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Src src, long long n, DistSink out_d,
                                                                  int *__restrict__ out_m, Fault *fault, int key_shift)
 {
-    extern __shared__ __align__(16) unsigned char walk_lds[];
+    extern __shared__ __align__(16) unsigned char walk_lds_all[];
+    const LadderEntry *LAD = reinterpret_cast<const LadderEntry *>(walk_lds_all);
+    unsigned char *walk_lds = walk_lds_all + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
+    if (LADDER) {
+        uint4 *dst = reinterpret_cast<uint4 *>(walk_lds_all);
+        const uint4 *from = reinterpret_cast<const uint4 *>(P.crown_ladder);
+        for (int k = threadIdx.x; k < P.lineage.crown_nodes; k += blockDim.x) dst[k] = from[k];
+        __syncthreads();
+    }
     constexpr int kTile = Q * kWalkSortBlock;
     uint32_t *HIST = reinterpret_cast<uint32_t *>(walk_lds);     // [kWalkSortBuckets] counts, then exclusive starts
     uint32_t *WSUM = HIST + kWalkSortBuckets;                    // [4] scan carries, [4] = pairs to stream
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Sr
                 KB[j] = kb | ((kb_[q].nb_rank & 0xFFu) << 24);      // (k_b < 2^24: the lineage tables exist)
                 SIDE[j] = side_[q];
                 OFFB[j] = kb_[q].off;
-                OFFP[j] = kb_[q].portal_off;
+                OFFP[j] = LADDER ? (kb_[q].nb_rank >> 8) : kb_[q].portal_off;      // (ladder: the portal's rank = its ladder index)
                 const uint32_t k = kb >> key_shift;
                 key[q] = k < (uint32_t)kWalkSortBuckets - 1 ? k : (uint32_t)kWalkSortBuckets - 1;
                 rank[q] = atomicAdd(&HIST[key[q]], 1u);
@@ -178,7 +190,9 @@ __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Sr
             const int j = PERM[pos];
             const int32_t kb = (int32_t)(KB[j] & 0xFFFFFFu), nb = (int32_t)(KB[j] >> 24);
             float s = SIDE[j];
-            if (!lin.shared_blocks || kb <= nb) {
+            if (LADDER) {
+                s = stream_b_ladder(lin.lens, LAD, OFFB[j], (uint32_t)nb, OFFP[j], s, kb);
+            } else if (!lin.shared_blocks || kb <= nb) {
                 s = stream_sum(lin.lens + OFFB[j], s, kb);
             } else {      // below the portal from b's own block, above it from the portal's (shared, cache resident)
                 s = stream_sum(lin.lens + OFFB[j], s, nb);

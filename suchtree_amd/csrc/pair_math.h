@@ -159,6 +159,30 @@ ST_HD float stream_b(const LineageView &lin, const NodeKey &kb, float s, int32_t
     return stream_sum(lin.lens + kb.portal_off, s, k - nb);
 }
 
+// The same with the crown part climbed on the crown's ladder (tree_prep.h: crown_ladder, indexed by rank;
+// LDS on the device) instead of streamed: k edges of b's lineage = its first min(k, nb) lineage lengths,
+// then k - nb ladder edges from its portal, three per 16-byte entry, in lineage order.
+template <typename LadPtr>
+ST_HD float stream_b_ladder(const float *__restrict__ lens, LadPtr lad, uint32_t off_b, uint32_t nb, uint32_t portal_rank,
+                            float s, int32_t k)
+{
+    if (k <= (int32_t)nb) return stream_sum(lens + off_b, s, k);
+    s = stream_sum(lens + off_b, s, (int32_t)nb);
+    uint32_t left = (uint32_t)k - nb, v = portal_rank;
+    while (left >= 3) {
+        const LadderEntry e = lad[v];
+        s += e.d0; s += e.d1; s += e.d2;
+        v = e.link & 0xFFFFu;
+        left -= 3;
+    }
+    if (left) {
+        const LadderEntry e = lad[v];
+        s += e.d0;
+        if (left == 2) s += e.d1;
+    }
+    return s;
+}
+
 ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
                            const Stride3 *__restrict__ stride, int32_t a, int32_t b,
                            const uint64_t *__restrict__ rmq = nullptr, int64_t n_nodes = 0,

@@ -258,6 +258,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_lineage_len);
         (void)hipFree(t->d_lineage_node_rec);
         (void)hipFree(t->d_crown_rmq);
+        (void)hipFree(t->d_crown_ladder);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
@@ -325,6 +326,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "rec_a4") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "rec_a4 must be 0 or 1");
         t->rec_a4 = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "walk_ladder") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_ladder must be 0 or 1");
+        t->walk_ladder = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "walk_crown") == 0) {

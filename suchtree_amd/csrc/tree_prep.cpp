@@ -455,10 +455,11 @@ bool prepare_walk_lineage(TreeTables &T, int64_t max_entries, bool with_lens)
     return true;
 }
 
-bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes)
+bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes, int max_ladder_nodes)
 {
     T.lineage_node_rec.clear();
     T.crown_rmq.clear();
+    T.crown_ladder.clear();
     T.crown_nodes = T.crown_levels = T.crown_height = 0;
     T.crown_hot_bytes = 0;
     const int64_t n = T.n;
@@ -473,6 +474,19 @@ bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes)
     int32_t H = 0;
     const int32_t h_top = std::min(hmax - 1, 255);
     while (H < h_top && bytes_ge[(size_t)H + 1] > hot_bytes) H++;
+    bool want_ladder = false;
+    if (max_ladder_nodes > 0 && T.inorder_ids) {
+        // a crown that fits LDS: the smallest H (shortest streams below the portals) with few enough nodes
+        std::vector<int64_t> count_ge((size_t)hmax + 2, 0);
+        for (int64_t i = 0; i < n; i++) count_ge[(size_t)T.height[(size_t)i]]++;
+        for (int32_t h = hmax - 1; h >= 0; h--) count_ge[(size_t)h] += count_ge[(size_t)h + 1];
+        int32_t HL = 0;
+        while (HL < h_top && count_ge[(size_t)HL + 1] > max_ladder_nodes) HL++;
+        if (count_ge[(size_t)HL + 1] <= max_ladder_nodes && count_ge[(size_t)HL + 1] <= 65535) {
+            H = HL;
+            want_ladder = true;
+        }
+    }
     T.crown_height = H;
     T.crown_hot_bytes = bytes_ge[(size_t)H + 1];
     // crown nodes by id, their ranks
@@ -500,6 +514,24 @@ bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes)
         r[1] = T.lineage_node_off[(size_t)x];
         r[2] = T.lineage_node_off[(size_t)p];
         r[3] = (uint32_t)nb[(size_t)x] | ((uint32_t)rank[(size_t)p] << 8);
+    }
+    if (want_ladder) {
+        // rank numbering: entry r describes the crown node of rank r; root: parent and third ancestor clamp to itself
+        std::vector<int32_t> node_of((size_t)C);
+        for (int64_t x = 0; x < n; x++)
+            if (rank[(size_t)x] >= 0) node_of[(size_t)rank[(size_t)x]] = (int32_t)x;
+        T.crown_ladder.assign((size_t)C, LadderEntry{0.0f, 0.0f, 0.0f, 0u});
+        for (int64_t r = 0; r < C; r++) {
+            const int32_t x = node_of[(size_t)r];
+            const int32_t q1 = T.nodes[(size_t)x].parent >= 0 ? T.nodes[(size_t)x].parent : x;
+            const int32_t q2 = T.nodes[(size_t)q1].parent >= 0 ? T.nodes[(size_t)q1].parent : q1;
+            const int32_t q3 = T.nodes[(size_t)q2].parent >= 0 ? T.nodes[(size_t)q2].parent : q2;
+            LadderEntry &e = T.crown_ladder[(size_t)r];
+            e.d0 = T.nodes[(size_t)x].parent >= 0 ? T.nodes[(size_t)x].dist : 0.0f;
+            e.d1 = (q1 != x && T.nodes[(size_t)q1].parent >= 0) ? T.nodes[(size_t)q1].dist : 0.0f;
+            e.d2 = (q2 != q1 && T.nodes[(size_t)q2].parent >= 0) ? T.nodes[(size_t)q2].dist : 0.0f;
+            e.link = (uint32_t)rank[(size_t)q3] | ((uint32_t)rank[(size_t)q1] << 16);
+        }
     }
     if (T.inorder_ids) {
         int32_t levels = 1;

@@ -177,6 +177,11 @@ struct TreeTables {
     // instead of the whole-tree table's hundreds of MB); equal portals use the whole-tree form.
     std::vector<uint32_t> lineage_node_rec;   // [4 * n] or empty
     std::vector<uint64_t> crown_rmq;          // [crown_levels * crown_nodes] or empty
+    // Ladder form of the crown, indexed by RANK (ladder entries only name parents and third ancestors,
+    // so any numbering serves): when the crown is small enough for LDS (prepare_walk_crown's
+    // max_ladder_nodes) the tile-sorted walk kernel climbs the crown part of b's side there -- three
+    // edges per 16-byte LDS read, no cache line at all -- and streams only the nodes below the portal.
+    std::vector<LadderEntry> crown_ladder;    // [crown_nodes] or empty
     int32_t crown_nodes = 0, crown_levels = 0, crown_height = 0;
     int64_t crown_hot_bytes = 0;              // lineage-length bytes of the crown's blocks
 };
@@ -215,7 +220,9 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries, bool with_lens = t
 
 // node_rec + crown tables for the walk family (see TreeTables); needs lineage_node_off (either
 // prepare_*lineage* function fills it).  hot_bytes: budget of the crown's lineage-length blocks.
-bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes);
+// max_ladder_nodes > 0: when some H <= 255 leaves at most that many nodes in the crown, that H is taken
+// (instead of the one from hot_bytes) and crown_ladder is built as well.
+bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes, int max_ladder_nodes = 0);
 
 // Entries of a node's block in the lineage tables.
 ST_HD int64_t lineage_block(int32_t depth) { return ((int64_t)depth + 1 + 15) & ~(int64_t)15; }

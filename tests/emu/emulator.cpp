@@ -41,16 +41,19 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
         std::vector<uint32_t> node_rec;
         std::vector<uint64_t> crown_rmq;
         int32_t crown_nodes = 0;
+        std::vector<LadderEntry> ladder;
     };
     std::vector<WalkTables> walk_tables;
     if (strategy == 1) {
         for (const int64_t hot : {(int64_t)2048, (int64_t)4 << 20}) {
             TreeTables C = T;
-            if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27) && prepare_walk_crown(C, hot))
-                walk_tables.push_back({C.lineage_sum, C.lineage_len, C.lineage_node_rec, C.crown_rmq, C.crown_nodes});
+            // (the larger budget also asks for a ladder over a crown of at most 300 nodes)
+            const int ladder_nodes = hot > 4096 ? 300 : 0;
+            if (prepare_canopy(parent, distance, C) && prepare_lineage_sums(C, (int64_t)1 << 27) && prepare_walk_crown(C, hot, ladder_nodes))
+                walk_tables.push_back({C.lineage_sum, C.lineage_len, C.lineage_node_rec, C.crown_rmq, C.crown_nodes, C.crown_ladder});
             TreeTables W = T;
-            if (prepare_walk_lineage(W, (int64_t)1 << 27) && prepare_walk_crown(W, hot))
-                walk_tables.push_back({W.lineage_sum, W.lineage_len, W.lineage_node_rec, W.crown_rmq, W.crown_nodes});
+            if (prepare_walk_lineage(W, (int64_t)1 << 27) && prepare_walk_crown(W, hot, ladder_nodes))
+                walk_tables.push_back({W.lineage_sum, W.lineage_len, W.lineage_node_rec, W.crown_rmq, W.crown_nodes, W.crown_ladder});
         }
     }
     if (strategy == 2) {
@@ -87,6 +90,19 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
             // own block, or streamed from its own block and then its portal's; the meeting node by
             // climbing, from the whole-tree table, or from the crown's table
             for (const WalkTables &W : walk_tables) {
+                if (!W.ladder.empty()) {      // k_walk_sorted's ladder mode: a's side from the sums, b's crown part climbed on the ladder
+                    LineageView lin;
+                    lin.node_rec = W.node_rec.data();
+                    const NodeKey ka = lineage_key(lin, (int32_t)a), kb = lineage_key(lin, (int32_t)b);
+                    int32_t dm;
+                    (void)pair_walk_mrca(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b, &dm);
+                    float s = W.sums[(size_t)ka.off + (size_t)((int32_t)ka.depth - dm)];
+                    s = stream_b_ladder(W.lens.data(), W.ladder.data(), kb.off, kb.nb_rank & 0xFFu, kb.nb_rank >> 8, s, (int32_t)kb.depth - dm);
+                    if (std::memcmp(&s, &r.dist, 4) != 0) {
+                        g_err = "walk: ladder form of the crown part disagrees with the climb";
+                        return 16;
+                    }
+                }
                 for (int form = 0; form < 16; form++) {
                     const bool use_rmq = form & 1, use_lens = form & 2, shared = form & 4, crown = form & 8;
                     if (use_rmq && T.tree_rmq.empty()) continue;

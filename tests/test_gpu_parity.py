@@ -213,7 +213,7 @@ def test_walk_only_tree_with_sparse_table_and_lineage_sums():
 def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
     """k_walk_sorted (batches >= 524288 pairs on trees with the sparse table and both lineage tables) and
     every table it builds on, switched on and off in all combinations: tile sort, crown (shared portal
-    blocks + crown sparse table), lineage lengths, whole-tree sparse table.  A walk-only tree (the canopy
+    blocks + crown sparse table), the crown's ladder in LDS, lineage lengths, whole-tree sparse table.  A walk-only tree (the canopy
     family refuses it) and ml.tree with the walk family forced.  Leaves and internal nodes, near pairs,
     (x, x), a batch that is no multiple of the tile, device buffers and the host path."""
     import itertools
@@ -238,16 +238,18 @@ def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
     t = torch.from_numpy(allp).cuda()
     out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
     out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
-    for srt, crown, lens, rmq in itertools.product((1, 0), repeat=4):
-        for name, v in (("walk_sort", srt), ("walk_crown", crown), ("lineage_lens", lens), ("tree_rmq", rmq)):
+    for srt, crown, lens, rmq, lad in itertools.product((1, 0), repeat=5):
+        if lad and not (srt and crown and lens):
+            continue                      # the ladder form only exists inside the sorted kernel with crown and lengths on
+        for name, v in (("walk_sort", srt), ("walk_crown", crown), ("lineage_lens", lens), ("tree_rmq", rmq), ("walk_ladder", lad)):
             dev.set_option(name, v)
-        what = "sort=%d crown=%d lens=%d rmq=%d" % (srt, crown, lens, rmq)
+        what = "sort=%d crown=%d lens=%d rmq=%d ladder=%d" % (srt, crown, lens, rmq, lad)
         out_d.fill_(-1.0)
         dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
         dev.fault_check()
         assert_bits_equal(out_d.cpu().numpy(), want_d, what)
         assert np.array_equal(out_m.cpu().numpy(), want_m), what
-    for name in ("walk_sort", "walk_crown", "lineage_lens", "tree_rmq"):
+    for name in ("walk_sort", "walk_crown", "lineage_lens", "tree_rmq", "walk_ladder"):
         dev.set_option(name, 1)
     # distances only / MRCA ids only, float32 sink, the host path (pinned staging read once, coalesced stores)
     dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), 0)
