@@ -14,6 +14,8 @@ struct BuiltTables {
 // sparse table, lineage sums, lineage lengths), in bytes: SUCHTREE_AMD_WALK_TABLE_MB (default 12288;
 // 0 = build none of them: the walk kernel then climbs).  They are aids, never requirements: a table
 // over budget, or one that later does not fit the device, is simply left out.
+constexpr int kLineageEntriesPerNode = 2048;
+
 static int64_t walk_table_budget()
 {
     int64_t mb = 12288;
@@ -85,13 +87,16 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
         // lock-step climb of both lineages matters most exactly there (large, deep trees) -- and the
         // lineage tables with offsets by node id (a's side in one read, b's side as a stream), all
         // within walk_table_budget()
+        // ... and of at most kLineageEntriesPerNode table entries per node: a 30,000-leaf caterpillar (mean depth
+        // 15,000) would otherwise get 7 GB of lineage tables for 2 MB of tree; it climbs instead
         int64_t budget = walk_table_budget();
+        const int64_t by_size = (int64_t)kLineageEntriesPerNode * n_nodes;
         if (B.T.tree_rmq.empty() && budget > 0) (void)build_tree_rmq(B.T, std::min<int64_t>(budget, kMaxTreeRmqBytesWalkOnly));
         if (budget > 0) {
             budget -= (int64_t)B.T.tree_rmq.size() * 8;
             // sums + lens when both fit, else the sums alone
-            if (!prepare_walk_lineage(B.T, std::min<int64_t>(budget / 8, kMaxWalkLineageEntries), true))
-                (void)prepare_walk_lineage(B.T, std::min<int64_t>(budget / 4, kMaxWalkLineageEntries), false);
+            if (!prepare_walk_lineage(B.T, std::min<int64_t>({budget / 8, kMaxWalkLineageEntries, by_size}), true))
+                (void)prepare_walk_lineage(B.T, std::min<int64_t>({budget / 4, kMaxWalkLineageEntries, by_size}), false);
             if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(false));
         }
     }

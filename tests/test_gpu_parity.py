@@ -174,6 +174,8 @@ def test_tree_too_deep_for_the_canopy_falls_back_to_walk():
     pairs = rng.integers(0, len(parent), (3000, 2))
     info = _check(parent, dist, pairs, strategy="auto")
     assert info["strategy"] == "walk" and info["depth"] == 40_000
+    # mean depth 20,000: lineage tables would take 13 GB for a 2 MB tree -- capped at 2048 entries per node, it climbs
+    assert info["lineage_entries"] == 0 and info["device_bytes"] < 64 << 20
 
 
 def test_walk_only_tree_with_sparse_table_and_lineage_sums():
