@@ -105,10 +105,20 @@ static bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
     return q > 0 && q < 4 && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
 }
 
+// In lineage-sum mode the tile-sorted canopy kernel reads every pair once (key phase; shared-portal pairs, rare,
+// a second time) and all its stores are coalesced: it may work on the host path's pinned slots directly.
+// SUCHTREE_AMD_SORTED_ZERO_COPY=0 puts the device staging back (measurement).
+static bool sorted_zero_copy(const st_tree *t)
+{
+    static const bool on = !(std::getenv("SUCHTREE_AMD_SORTED_ZERO_COPY") && std::getenv("SUCHTREE_AMD_SORTED_ZERO_COPY")[0] == '0');
+    return on && sorted_shape(t).sums;
+}
+
 static bool wants_device_stage(const st_tree *t, int64_t m)
 {
     if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
     if (prefers_walk_sorted(t, m, true)) return false;      // (that kernel reads every pair once and stores coalesced)
+    if (sorted_zero_copy(t)) return false;
     return m >= (canopy_min_pairs(t) == kSortedMinPairs ? kSortedMinPairsHost : kCanopyMinPairs);
 }
 
@@ -318,7 +328,8 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, in
     const bool ranks_only = !d_out.any() && d_mrca && mrca_ranks_ready(t) && n >= kCanopyMinPairs;
     const bool canopy = ranks_only ||
                         (t->strategy == ST_STRATEGY_CANOPY && n >= canopy_min_pairs(t) &&
-                         (allow_sorted || !(t->tile_sort && sorted_q(t) > 0)) && !prefers_walk_sorted(t, n, d_out.any()));
+                         (allow_sorted || !(t->tile_sort && sorted_q(t) > 0) || sorted_zero_copy(t)) &&
+                         !prefers_walk_sorted(t, n, d_out.any()));
     const hipError_t e = canopy ? launch_canopy(t, src, n, d_out, d_mrca, fault, stream)
                                 : launch_walk(t, src, n, d_out, d_mrca, fault, stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
