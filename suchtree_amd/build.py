@@ -13,21 +13,29 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsuchtree_hip.so")
-SOURCES = [os.path.join(CSRC, "suchtree_hip.hip"), os.path.join(CSRC, "tree_prep.cpp"),
-           os.path.join(CSRC, "newick_parse.cpp")]
+# Four HIP translation units (each kernel family with its launch functions + the C ABI and host side) and two
+# host-only C++ files: compiled to objects in parallel, then linked.
+HIP_SOURCES = [os.path.join(CSRC, f) for f in ("suchtree_hip.hip", "launch_walk.hip", "launch_canopy.hip",
+                                               "launch_canopy_sorted.hip")]
+CPP_SOURCES = [os.path.join(CSRC, "tree_prep.cpp"), os.path.join(CSRC, "newick_parse.cpp")]
+SOURCES = HIP_SOURCES + CPP_SOURCES
+# (source, extra flags, object name): launch_canopy_sorted.hip holds the slowest instantiations and is compiled
+# in three parts, two pair sources each
+UNITS = [(src, [], os.path.basename(src) + ".o") for src in SOURCES if not src.endswith("launch_canopy_sorted.hip")]
+UNITS = [(os.path.join(CSRC, "launch_canopy_sorted.hip"), ["-DST_SORTED_PART=%d" % k], "launch_canopy_sorted.%d.o" % k)
+         for k in range(3)] + UNITS
+OBJ_DIR = os.path.join(HERE, "build")
 MICRO_LIB = os.path.join(HERE, "libst_microbench.so")      # measurement helpers for bench.py, not the product
 MICRO_SRC = os.path.join(CSRC, "microbench.hip")
-HEADERS = [os.path.join(CSRC, "tree_prep.h"), os.path.join(CSRC, "pair_math.h"),
-           os.path.join(CSRC, "host_pipe.h"), os.path.join(CSRC, "host_copy.h"),
-           os.path.join(CSRC, "device_common.h"), os.path.join(CSRC, "kernels_walk.h"),
-           os.path.join(CSRC, "kernels_canopy.h"), os.path.join(CSRC, "kernels_misc.h"),
-           os.path.join(CSRC, "host_tree.h"), os.path.join(CSRC, "host_launch.h"),
-           os.path.join(CSRC, "host_path.h"), os.path.join(CSRC, "host_upload.h"),
-           os.path.join(HERE, "..", "include", "suchtree_hip.h")]
+HEADERS = [os.path.join(CSRC, h) for h in (
+    "tree_prep.h", "pair_math.h", "host_pipe.h", "host_copy.h", "device_common.h", "launch_geometry.h", "st_tree.h",
+    "launch_policy.h", "launch_decl.h", "launch_canopy_sorted.h", "kernels_walk.h", "kernels_canopy.h",
+    "kernels_canopy_sorted.h", "kernels_misc.h", "host_tree.h", "host_launch.h", "host_path.h", "host_upload.h")]
+HEADERS.append(os.path.join(HERE, "..", "include", "suchtree_hip.h"))
 
 FLAGS = [
     "--offload-arch=gfx950",
-    "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-O3", "-std=c++17", "-fPIC",
     # float32 adds must stay single, ordered adds (reference accumulates in C float)
     "-ffp-contract=off", "-fno-fast-math",
     "-Wall", "-Wno-unused-result",
@@ -85,12 +93,27 @@ def build_names_ext(force=False, verbose=False):
 
 
 def build(force=False, verbose=False, extra=()):
+    """Compile every translation unit (in parallel) and link libsuchtree_hip.so."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-I", os.path.join(HERE, "..", "include"),
-                                            "-o", LIB] + SOURCES + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    include = ["-I", os.path.join(HERE, "..", "include")]
+
+    def compile_one(unit):
+        src, unit_flags, name = unit
+        obj = os.path.join(OBJ_DIR, name)
+        cmd = [hipcc()] + FLAGS + list(extra) + unit_flags + include + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), max(1, os.cpu_count() or 2))) as pool:
+        objs = list(pool.map(compile_one, UNITS))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 

@@ -1,5 +1,4 @@
-// device_common.h -- part of libsuchtree_hip.so's single translation unit (included by suchtree_hip.hip,
-// in this order: device_common.h, kernels_walk.h, kernels_canopy.h, kernels_misc.h).
+// device_common.h -- included first by every translation unit of libsuchtree_hip.so.
 // Fault word, pair sources (where pair i of a launch comes from), result sinks.
 #pragma once
 

@@ -1,5 +1,5 @@
-// host_path.h -- part of libsuchtree_hip.so's single translation unit (included by suchtree_hip.hip after
-// the kernels, in this order: host_tree.h, host_launch.h, host_path.h, host_upload.h).
+// host_path.h -- part of suchtree_hip.hip (included in this order: host_tree.h, host_launch.h, host_path.h,
+// host_upload.h).
 // The host-buffer path: chunking, the small-batch mailbox, copy kernels, the slot pipeline, multi-device dealing.
 #pragma once
 
@@ -98,17 +98,14 @@ static int small_batch(st_tree *t, const Id *pairs, int64_t n, int64_t stride0, 
                                        std::to_string(t->n_nodes) + ")");
     }
     char *d_base = static_cast<char *>(t->mb_dev);
-    const WalkParams P = walk_params(t);
     double *d_dist = reinterpret_cast<double *>(d_base + (size_t)kMailboxPairs * 16);
     int32_t *d_mrca = reinterpret_cast<int32_t *>(d_base + (size_t)kMailboxPairs * 24);
     unsigned *d_done = reinterpret_cast<unsigned *>(d_base + (size_t)kMailboxPairs * 28);
     volatile unsigned *h_done = reinterpret_cast<volatile unsigned *>(static_cast<char *>(t->mb_host) + (size_t)kMailboxPairs * 28);
     unsigned seq = ++t->mb_seq;
     if (seq == 0) seq = ++t->mb_seq;     // (0 is the word's initial value)
-    hipLaunchKernelGGL(k_walk_mailbox, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, t->mb_stream, P,
-                       reinterpret_cast<const long long *>(d_base), (int)n, out_dist ? d_dist : nullptr,
-                       out_mrca ? d_mrca : nullptr, reinterpret_cast<unsigned *>(t->d_fault_mb), d_done, seq);
-    ST_HIP(hipGetLastError());
+    ST_HIP(launch_walk_mailbox(t, reinterpret_cast<const long long *>(d_base), (int)n, out_dist ? d_dist : nullptr,
+                               out_mrca ? d_mrca : nullptr, reinterpret_cast<unsigned *>(t->d_fault_mb), d_done, seq, t->mb_stream));
     // poll the completion word (pinned host memory); if it does not show up within a few
     // milliseconds something is wrong: let the runtime report it
     {
@@ -199,8 +196,7 @@ static HostOut make_host_out(double *out_dist, int32_t *out_mrca, int64_t n)
 
 // The tile-sorted kernel reads every pair twice and stores results in sorted order: fine in
 // HBM, ruinous over PCIe (scattered 4-byte writes).  For trees that use it the host path keeps
-// the slot in device memory and moves it with the copy kernel above.
-static bool wants_device_stage(const st_tree *t, int64_t m);
+// the slot in device memory and moves it with the copy kernel above (launch_policy.h: wants_device_stage).
 
 // One chunk of a host-path call on slot s: `make_src(in)` builds the pair source from the
 // chunk's input pointer (NULL for generated sources), results go to the slot's pinned arrays.

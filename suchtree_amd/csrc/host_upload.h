@@ -1,5 +1,5 @@
-// host_upload.h -- part of libsuchtree_hip.so's single translation unit (included by suchtree_hip.hip after
-// the kernels, in this order: host_tree.h, host_launch.h, host_path.h, host_upload.h).
+// host_upload.h -- part of suchtree_hip.hip (included in this order: host_tree.h, host_launch.h, host_path.h,
+// host_upload.h).
 // Table construction (tree_prep.cpp) and upload of a tree to one device.
 #pragma once
 

@@ -1,5 +1,4 @@
-// kernels_misc.h -- part of libsuchtree_hip.so's single translation unit (included by suchtree_hip.hip,
-// in this order: device_common.h, kernels_walk.h, kernels_canopy.h, kernels_misc.h).
+// kernels_misc.h -- included by suchtree_hip.hip (after device_common.h).
 // k nearest candidates per row, dense graph matrices, (see also the copy kernels next to the host pipe).
 #pragma once
 

@@ -1,7 +1,7 @@
-// kernels_walk.h -- part of libsuchtree_hip.so's single translation unit (included by suchtree_hip.hip,
-// in this order: device_common.h, kernels_walk.h, kernels_canopy.h, kernels_misc.h).
-// Walk family: k_walk, the mailbox kernel, the quartet kernels.
+// kernels_walk.h -- walk family: k_walk, k_walk_sorted, the mailbox kernel, the quartet kernels
+// (launch_walk.hip).  Include after device_common.h and pair_math.h.
 #pragma once
+#include "launch_geometry.h"
 
 namespace st {
 
@@ -55,12 +55,7 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
 // distances leave together in input order, coalesced.  Every pair is read once and every store is
 // coalesced, so the kernel may also work on pinned host memory.  Same operands, same order of
 // additions as k_walk.
-constexpr int kWalkSortBlock = 1024;
-constexpr int kWalkSortBuckets = 256;
-__host__ __device__ constexpr size_t walk_sort_scratch_bytes(int q)
-{
-    return (size_t)q * kWalkSortBlock * 18 + (size_t)kWalkSortBuckets * 4 + 64;
-}
+// (tile scratch: launch_geometry.h::walk_sort_scratch_bytes)
 
 // LADDER: the crown is small enough for LDS (tree_prep.h: crown_ladder): its ladder form is staged in
 // front of the scratch and the crown part of every b side is climbed there, three edges per 16-byte LDS

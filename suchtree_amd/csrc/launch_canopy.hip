@@ -1,0 +1,123 @@
+// launch_canopy.hip -- translation unit of the canopy family's plain kernels (k_canopy, k_canopy_ilp, k_mrca_ranks)
+// and of launch_canopy<Src>, the family's one entry point (the tile-sorted kernel sits behind it in
+// launch_canopy_sorted.hip).  Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#define ST_LAUNCH_UNIT 1
+#include "device_common.h"
+#include "pair_math.h"
+#include "tree_prep.h"
+#include "st_tree.h"
+#include "launch_decl.h"
+#include "launch_policy.h"
+#include "kernels_canopy.h"
+#include "launch_canopy_sorted.h"
+
+namespace st {
+
+template <typename Kern, typename Src>
+static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
+                                  const Src &src, int64_t n, DistSink out_d, int32_t *out_m,
+                                  Fault *fault, hipStream_t stream, size_t lds = 0)
+{
+    if (lds == 0) lds = canopy_lds_bytes(t);
+    if (lds > 64 * 1024) {
+        // dynamic LDS above 64 KiB has to be granted per kernel (cheap host-side call)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // one or two 1024-lane workgroups per CU, whatever the LDS image allows
+    const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int64_t tile = (int64_t)kCanopyBlock * ppl;
+    int64_t blocks = (n + tile - 1) / tile;
+    blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * wg_per_cu);
+    blocks = std::max<int64_t>(blocks, 1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src,
+                       (long long)n, out_d, out_m, fault);
+    return hipGetLastError();
+}
+
+template <int CAP, typename Src>
+static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
+                                  DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
+{
+    // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
+    if (t->tile_sort && sorted_q(t) > 0)
+        return launch_canopy_sorted<CAP>(t, P, src, n, out_d, out_m, fault, stream);
+    if constexpr (CAP == 0) {
+        return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+    } else {
+        if (t->pairs_per_lane == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+        // two pairs per lane: a measured-equal variant kept selectable for explicit pair arrays only
+        if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
+            if (t->pairs_per_lane == 2)
+                return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, fault, stream);
+        }
+        // explicit pair arrays on trees with the four-byte a side: 4-byte gathers from a table half the size
+        if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
+            if (P.rec_a4 && P.leaf_blocks)
+                return launch_canopy_k(k_canopy_ilp<CAP, 1, Src, true>, 1, t, P, src, n, out_d, out_m, fault, stream,
+                                       canopy_lds_bytes(t) + leaf_block_image_bytes(P.leaf_block_count));
+        }
+        return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+    }
+}
+
+template <typename Src>
+hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
+                                int32_t *out_m, Fault *fault, hipStream_t stream)
+{
+    CanopyParams P;
+    P.canopy = t->d_canopy;
+    P.canopy_id = t->d_canopy_id;
+    P.ladder = t->d_ladder;
+    P.cdepth = t->d_cdepth;
+    P.cpos = t->d_cpos;
+    P.rmq = t->d_rmq;
+    P.rec_a = t->d_rec_a;
+    P.rec_a4 = t->rec_a4 ? t->d_rec_a4 : nullptr;
+    P.leaf_blocks = t->rec_a4 ? t->d_leaf_blocks : nullptr;
+    P.leaf_block_shift = t->leaf_block_shift;
+    P.leaf_block_count = t->leaf_block_count;
+    P.rec_b = t->d_rec_b;
+    P.rec_i = t->d_rec_i;
+    P.rec_p = t->d_rec_p;
+    P.rmq64 = t->d_rmq64;
+    P.rec_r = t->d_rec_r;
+    P.lineage = t->d_lineage;
+    P.n_nodes = t->n_nodes;
+    P.n_leaves = t->n_leaves;
+    P.canopy_nodes = t->canopy_nodes;
+    P.rec_bytes = t->rec_bytes;
+    P.parity = t->parity;
+    if (!out_d.any() && out_m && P.rec_r && P.rmq64 && t->mrca_ranks) {
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)t->n_cu * 8));
+        hipLaunchKernelGGL(k_mrca_ranks<Src>, dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault);
+        return hipGetLastError();
+    }
+    // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
+    // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
+    if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 &&
+        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq, sorted_shape(t).sums) > 80 * 1024)
+        return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
+    switch (t->rec_cap) {
+        case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream);
+        case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream);
+        case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, fault, stream);
+        case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, fault, stream);
+        default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, fault, stream);
+    }
+}
+
+
+#define ST_INSTANTIATE_CANOPY(S) \
+    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);
+ST_FOR_EACH_SRC(ST_INSTANTIATE_CANOPY)
+
+}  // namespace st

@@ -1,0 +1,118 @@
+// launch_policy.h -- host-only decisions shared by suchtree_hip.hip and the launch units: LDS budgets of a
+// tree's launches, which form of the tile-sorted kernels fits, the batch-size thresholds between families.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+
+#include "launch_geometry.h"
+#include "st_tree.h"
+
+namespace st {
+
+static inline size_t canopy_lds_bytes(const st_tree *t)
+{
+    return (size_t)((t->canopy_nodes + 1) / 2) * 16;
+}
+
+// Shape of the tile-sorted launch: pairs per lane (2 when image + scratch fit half the LDS, i.e.
+// two workgroups per CU; else 4 with one workgroup per CU) and whether the meeting nodes come
+// from the sparse table (in-order ids, and the extra 4 bytes per pair of scratch still leave
+// room for the same tile) or from the lock-step search.  q = 0: the ladder image does not fit.
+struct SortedShape {
+    int q;
+    bool rmq;
+    bool sums;   // a's side from the lineage-sum table (needs rmq and 4 more bytes of scratch per pair)
+};
+
+static inline SortedShape sorted_shape(const st_tree *t)
+{
+    const size_t image = ladder_image_bytes(t->canopy_nodes);
+    static const int forced = std::getenv("SUCHTREE_AMD_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_SORT_Q")) : 0;   // tuning experiments
+    const bool table = t->d_rmq != nullptr;
+    const bool lineage = table && t->d_lineage != nullptr && t->lineage_sums;
+    struct Mode { bool rmq, sums; };
+    // lineage sums first (they are worth a smaller tile), then the sparse table alone, then
+    // the lock-step search; within a mode the largest tile that fits, two workgroups per CU if possible
+    for (const Mode m : {Mode{true, true}, Mode{true, false}, Mode{false, false}}) {
+        if ((m.rmq && !table) || (m.sums && !lineage)) continue;
+        if ((forced == 1 || forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, m.rmq, m.sums) <= 160 * 1024)
+            return {forced, m.rmq, m.sums};
+        // two workgroups per CU where that is possible -- except with lineage sums: that form of the
+        // kernel needs more than 64 VGPRs, so only one workgroup fits a CU anyway, and the larger
+        // tile wins (caterpillar of 2048 leaves: 1.35e10 pairs/s with 4096-pair tiles, 9.8e9 with 2048)
+        if (!m.sums && image + sort_scratch_bytes(2, m.rmq, m.sums) <= 80 * 1024) return {2, m.rmq, m.sums};
+        // (measured on nj.tree, 9111 canopy nodes: lineage sums with 1024-pair tiles 1.37e10 pairs/s,
+        // lock-step search with 2048-pair tiles 1.19e10, sparse table alone with 2048-pair tiles 1.03e10)
+        for (const int q : {4, 2, 1}) {
+            if (q == 1 && !m.sums) continue;
+            if (q == 2 && m.rmq && !m.sums) continue;
+            if (image + sort_scratch_bytes(q, m.rmq, m.sums) <= 160 * 1024) return {q, m.rmq, m.sums};
+        }
+    }
+    return {0, false, false};
+}
+
+static inline int sorted_q(const st_tree *t) { return sorted_shape(t).q; }
+
+// Smallest batch the canopy kernels take.  The tile-sorted kernel has a fixed cost (every
+// workgroup stages a ladder image of up to 150 KiB, sorts, and on the host path its slot is
+// staged through device memory), and with lineage sums the walk kernel does 8e9 pairs/s on deep
+// trees: 10,000 pairs of ml.tree through the host path 73 us sorted, 40 us walked.
+constexpr int64_t kCanopyMinPairs = 4096;
+constexpr int64_t kSortedMinPairs = 32768;        // deep canopies with lineage sums: below this the walk kernel wins
+constexpr int64_t kSortedMinPairsHost = 131072;   // ... on the host path, where the tile-sorted kernel also needs its slot staged in device memory
+
+static inline int64_t canopy_min_pairs(const st_tree *t)
+{
+    return t->tile_sort && t->d_lineage && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
+}
+
+static inline bool mrca_ranks_ready(const st_tree *t)
+{
+    return t->strategy == ST_STRATEGY_CANOPY && t->mrca_ranks && t->d_rec_r && t->d_rmq64;
+}
+
+// Deep-canopy trees whose canopy image leaves the tile-sorted canopy kernel only small tiles (nj.tree: 9111
+// canopy nodes = 146 KiB, 1024-pair tiles) are served faster by the tile-sorted WALK kernel once its crown
+// ladder exists: a crown of <= 5120 nodes, 4096-pair tiles (nj.tree, 1e7 pairs: 1.73e10 against 1.60e10
+// pairs/s; ml.tree keeps the canopy kernel: 2.15e10 against 1.73e10).  Large batches with distances only.
+static inline bool walk_sorted_ready(const st_tree *t);
+constexpr int64_t kWalkSortedMinPairs = 524288;
+static inline bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
+{
+    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || !want_dist || n < kWalkSortedMinPairs) return false;
+    const int q = sorted_q(t);
+    return q > 0 && q < 4 && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
+}
+
+// In lineage-sum mode the tile-sorted canopy kernel reads every pair once (key phase; shared-portal pairs, rare,
+// a second time) and all its stores are coalesced: it may work on the host path's pinned slots directly.
+// SUCHTREE_AMD_SORTED_ZERO_COPY=0 puts the device staging back (measurement).
+static inline bool sorted_zero_copy(const st_tree *t)
+{
+    static const bool on = !(std::getenv("SUCHTREE_AMD_SORTED_ZERO_COPY") && std::getenv("SUCHTREE_AMD_SORTED_ZERO_COPY")[0] == '0');
+    return on && sorted_shape(t).sums;
+}
+
+static inline bool wants_device_stage(const st_tree *t, int64_t m)
+{
+    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
+    if (prefers_walk_sorted(t, m, true)) return false;      // (that kernel reads every pair once and stores coalesced)
+    if (sorted_zero_copy(t)) return false;
+    return m >= (canopy_min_pairs(t) == kSortedMinPairs ? kSortedMinPairsHost : kCanopyMinPairs);
+}
+
+// Smallest batch the tile-sorted walk kernel takes: below it k_walk's finer grain wins (a 1e5-pair
+// batch is 25 tiles of 4096 pairs on 256 CUs; measured on ml.tree, pairs per second unsorted / sorted:
+// 1e5 pairs 4.9e9 / 1.3e9, 4e5 8.0e9 / 5.3e9, 8e5 9.1e9 / 1.03e10, 3.2e6 1.0e10 / 1.08e10, 1e7 1.1e10 /
+// 1.35e10).  Tiles: 4096 pairs on trees with canopy tables, 2048 on trees only the walk family serves
+// (1e6-leaf depth-338 tree, 1e7 / 4e7 pairs: 5.93e9 / 6.43e9 against 5.76e9 / 5.90e9 with 4096;
+// ml.tree: 1.28e10 / 1.34e10 against 1.32e10 / 1.41e10).  (kWalkSortedMinPairs = 524288, above.)
+
+static inline bool walk_sorted_ready(const st_tree *t)
+{
+    return t->walk_sort && t->tree_rmq && t->d_tree_rmq && t->lineage_sums && t->d_lineage && t->d_lineage_node_rec &&
+           t->lineage_lens && t->d_lineage_len;
+}
+
+}  // namespace st

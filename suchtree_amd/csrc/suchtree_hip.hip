@@ -21,11 +21,12 @@
 // SrcTriangle / SrcGrid / SrcQuartet): an explicit (n,2) array, or pairs derived from their
 // index (all-pairs triangle, rows x columns grid, the six pairs of a quartet).
 //
-// The kernels live in headers included below, in this order: device_common.h (fault word, pair
-// sources, result sinks), kernels_walk.h, kernels_canopy.h, kernels_misc.h; this file holds the
-// error plumbing and the C ABI; the host side in between is in host_tree.h (handle), host_launch.h
-// (kernel choice, enqueueing, faults), host_path.h (host-buffer pipeline, mailbox, copy kernels)
-// and host_upload.h (tables -> device).
+// Four translation units (compiled in parallel, build.py): launch_walk.hip (kernels_walk.h), launch_canopy.hip
+// (kernels_canopy.h), launch_canopy_sorted.hip (kernels_canopy_sorted.h) -- each a kernel family with its launch
+// functions, exported through launch_decl.h -- and this file: error plumbing, the C ABI and the host side in
+// between: st_tree.h / host_tree.h (handle, pipe registry), launch_policy.h + host_launch.h (which family a
+// request gets, enqueueing, faults), host_path.h (host-buffer pipeline, mailbox, copy kernels), host_upload.h
+// (tables -> device), kernels_misc.h (k nearest, graph matrices).
 //
 // Host side of the C ABI: tree upload to one or several GPUs (tree_prep.cpp builds the
 // tables), the zero-copy host path (host_pipe.h, host_copy.h: kernels read and write pinned
@@ -106,8 +107,6 @@ private:
 }  // namespace st
 
 #include "device_common.h"
-#include "kernels_walk.h"
-#include "kernels_canopy.h"
 #include "kernels_misc.h"
 
 
@@ -685,7 +684,6 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("host staging allocation: ") + hipGetErrorString(e));
     }
     if (begin_host_faults(t, pipe.slot[0].stream) != ST_OK) return ST_ERR_HIP;
-    const WalkParams P = walk_params(t);
     const bool canopy = t->strategy == ST_STRATEGY_CANOPY && 6 * chunk >= canopy_min_pairs(t);
     if (canopy && t->q_tmp_cap < kPipeSlots * chunk) {      // six MRCA ids per quartet, per slot
         (void)hipFree(t->q_tmp);
@@ -725,22 +723,18 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
         });
         e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * 32, hipMemcpyHostToDevice, s.stream);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
-        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((m + 255) / 256, (int64_t)t->n_cu * 16));
         if (canopy && 6 * m >= canopy_min_pairs(t)) {
             // six MRCA ids per quartet out of the canopy / rank-table kernels, then the pick
             int32_t *tmp = static_cast<int32_t *>(t->q_tmp) + (size_t)slot_index * (size_t)chunk * 6;
             const int rc = enqueue_src(t, SrcQuartet{static_cast<const long long *>(s.d_in)}, 6 * m,
                                        DistSink{nullptr, nullptr}, tmp, t->d_fault_host, s.stream);
             if (rc != ST_OK) return bail(rc, g_last_error);
-            hipLaunchKernelGGL(k_quartet_pick, dim3((unsigned)blocks), dim3(256), 0, s.stream,
-                               static_cast<const long long *>(s.d_in), static_cast<const int *>(tmp),
-                               (long long)m, reinterpret_cast<long long *>(out_of(s)));
+            e = launch_quartet_pick(t, static_cast<const long long *>(s.d_in), static_cast<const int *>(tmp), m,
+                                    reinterpret_cast<long long *>(out_of(s)), s.stream);
         } else {
-            hipLaunchKernelGGL(k_quartets, dim3((unsigned)blocks), dim3(256), 0, s.stream, P,
-                               static_cast<const long long *>(s.d_in), (long long)m, 4LL, 1LL,
-                               reinterpret_cast<long long *>(out_of(s)), t->d_fault_host);
+            e = launch_quartets_walk(t, static_cast<const long long *>(s.d_in), m, reinterpret_cast<long long *>(out_of(s)),
+                                     t->d_fault_host, s.stream);
         }
-        e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(s.done, s.stream);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("quartet pipeline: ") + hipGetErrorString(e));
         s.busy = true;
