@@ -66,7 +66,7 @@ hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const S
 // The instantiations are the slowest part of the build (~50 s in one piece): the file is compiled three times,
 // -DST_SORTED_PART=0 / 1 / 2, each part with two of the six pair sources (build.py).
 #ifndef ST_SORTED_PART
-#error "compile with -DST_SORTED_PART=0, 1 and 2 (suchtree_amd/build.py)"
+ST_FOR_EACH_SRC(ST_INSTANTIATE_SORTED)      // (one piece: a plain `hipcc -c` of this file still works)
 #elif ST_SORTED_PART == 0
 ST_INSTANTIATE_SORTED(SrcContig)
 ST_INSTANTIATE_SORTED(SrcContig32)
