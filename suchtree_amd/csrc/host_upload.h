@@ -221,7 +221,11 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
         if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
         if (rc == ST_OK && !T.rec_r.empty()) {
-            rc = upload(&t->d_rec_r, T.rec_r, &bytes);
+            // the MRCA-only kernel needs the rank alone: 2 bytes per node, so that the leaves' half of the
+            // table (2 MB for 2^20 leaves) stays in an XCD's L2 (4-byte entries: 4.4e10 ids/s)
+            std::vector<uint16_t> ranks(T.rec_r.size());
+            for (size_t k = 0; k < ranks.size(); k++) ranks[k] = (uint16_t)(T.rec_r[k] & 0xFFFFu);
+            rc = upload(&t->d_rec_r, ranks, &bytes);
             if (rc == ST_OK) rc = upload(&t->d_rmq64, T.canopy_rmq64, &bytes);
         }
         if (rc == ST_OK && t->d_rmq && t->d_rmq64 && !T.lineage_sum.empty()) {

@@ -24,7 +24,7 @@ struct CanopyParams {
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
     const uint8_t *rec_p;          // [n_nodes * 8]            {portal rank | depth << 16, lineage offset | chunks << 28}; NULL without lineage sums
     const uint64_t *rmq64;         // [levels * canopy_nodes] sparse table with node ids (tree_prep.h); in-order ids only
-    const uint32_t *rec_r;         // [n_nodes] portal rank | depth << 16 (MRCA-only queries); in-order ids only
+    const uint16_t *rec_r;         // [n_nodes] rank of the node's portal (MRCA-only queries); in-order ids only
     const float *lineage;          // lineage sums (tree_prep.h): a's whole side of a pair in one read
     long long n_nodes;
     long long n_leaves;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, lon
             continue;
         }
         const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-        const uint32_t ra = P.rec_r[sa] & 0xFFFFu, rb = P.rec_r[sb] & 0xFFFFu;
+        const uint32_t ra = P.rec_r[sa], rb = P.rec_r[sb];
         if (ra != rb) {
             out_m[i] = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
         } else {      // shared portal: the MRCA is the portal or lies in the understory

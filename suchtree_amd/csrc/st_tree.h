@@ -39,7 +39,7 @@ struct st_tree {
     int rec_a4 = 1;           // tuning: 0 = the predicated canopy kernel reads the 8-byte rec_a entries even when the four-byte form exists
     uint8_t *d_rec_p = nullptr;       // lineage sums (deep canopies with a sparse table), else NULL
     uint64_t *d_rmq64 = nullptr;
-    uint32_t *d_rec_r = nullptr;      // MRCA-only queries (in-order ids), else NULL
+    uint16_t *d_rec_r = nullptr;      // rank of every node's portal: MRCA-only queries (in-order ids), else NULL
     float *d_lineage = nullptr;
     float *d_lineage_len = nullptr;           // lineage lengths (same blocks as d_lineage), else NULL
     uint32_t *d_lineage_node_rec = nullptr;   // {depth, lineage offset, portal's lineage offset, nb | portal rank << 8} by node id
