@@ -47,8 +47,8 @@ def test_bench_line_contract():
         assert "error" not in oc[key], oc[key]
     for key in ("config2_ml_tree", "config2_nj_tree"):
         c = oc[key]
-        assert c["canopy"]["bit_exact_on_sample"] and c["walk"]["bit_exact_on_sample"] and c["host_path"]["bit_exact_on_sample"]
-        assert c["canopy"]["pairs_per_s"] > 1e9 and c["walk"]["pairs_per_s"] > 1e9 and c["algorithmic_bytes_per_pair"] > 500
+        assert c["default"]["bit_exact_on_sample"] and c["walk"]["bit_exact_on_sample"] and c["host_path"]["bit_exact_on_sample"]
+        assert c["default"]["pairs_per_s"] > 1e9 and c["walk"]["pairs_per_s"] > 1e9 and c["algorithmic_bytes_per_pair"] > 500
     t = oc["config4_triangle_100k"]
     assert t["pairs"] == 4_999_950_000 and t["bit_exact_on_sample"] and t["canopy"]["pairs_per_s"] > 1e10
     assert t["streamed_to_host"]["pairs"] == 1 << 30 and t["streamed_to_host"]["pairs_per_s"] > 1e9
