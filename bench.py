@@ -507,9 +507,13 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
 def closing_wait(dg, rank, timeout_s, release=False):
     """While rank 0 runs the CPU baseline and the side legs (a minute or two) the peers wait on the
     process group's key-value store -- on the host, with a generous timeout -- instead of inside an
-    RCCL barrier kernel that spins on their GPUs and is subject to the collective timeout."""
+    RCCL barrier kernel that spins on their GPUs and is subject to the collective timeout.  (Without
+    access to the store -- a torch that does not expose it -- the closing barrier itself is the wait.)"""
     import datetime
-    store = dg.distributed_c10d._get_default_store()
+    try:
+        store = dg.distributed_c10d._get_default_store()
+    except Exception:      # noqa: BLE001 -- private API: fall back to the barrier in main()
+        return
     if rank == 0:
         if release:
             store.set("suchtree_bench_rank0_done", "1")
