@@ -164,3 +164,34 @@ def test_weak_mode_line_on_gloo():
     d = json.loads(res[0][1])
     assert d["scaling"] == "weak" and d["config"]["pairs_per_step"] == 1002 and "gather_ms" not in d
     assert d["parity"]["distances_bit_exact"] and all(len(r[2]) == 2 for r in res)
+
+
+def _worker_closing(rank, world, port, q):
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t0 = time.time()
+    if rank == 0:
+        time.sleep(1.5)                                  # rank 0 is still busy with its CPU legs
+        bench.closing_wait(dist, rank, 60, release=True)
+    else:
+        bench.closing_wait(dist, rank, 60)               # what run_job's peers do after the timed region
+    waited = time.time() - t0
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, waited))
+
+
+def test_peers_wait_on_the_store_until_rank_0_has_printed_its_line():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_closing, args=(r, 3, port, q)) for r in range(3)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[1] >= 1.2 and res[2] >= 1.2 and max(res.values()) < 30
