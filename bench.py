@@ -469,6 +469,16 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     if traffic and traffic.get("hbm_bytes_per_launch"):
         roof["traffic"] = traffic["hbm_bytes_per_launch"] * (pairs_this_rank / plan.chunks) / traffic.get("pairs_per_launch", 1e8)
         roof["traffic_source"] = traffic_file
+        c = traffic.get("counters_mean_per_launch", {})
+        if c.get("TCC_HIT_sum") and c.get("TCC_MISS_sum"):
+            roof["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])       # same PMC passes
+    if info["strategy"] == "canopy":
+        # SURVEY 8d asks for the achieved occupancy next to the fraction: the canopy kernels run one 1024-lane
+        # workgroup per CU when the LDS image exceeds 80 KiB (two below that)
+        image = ((info["canopy_nodes"] + 1) // 2) * 16
+        wg = 1 if image > 80 * 1024 else 2
+        roof["occupancy"] = {"waves_per_cu": 16 * wg, "max_waves_per_cu": 32, "lds_image_bytes": image,
+                             "why": "%d workgroup(s) of 1024 lanes per CU beside a canopy image of %d KiB in LDS" % (wg, image // 1024)}
     line = {
         "metric": METRIC,
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
