@@ -323,6 +323,12 @@ class HipBackend:
                         "ceiling_Greads_per_s": ceil, "ceiling_table_MiB": hw["table"]["MiB"],
                         "ceiling_shape": hw["table"].get("best_shape"),
                         "frac": rate / 1e9 / ceil,
+                        # the record tables the kernel gathers from (rec_b 32 B + rec_a4 4 B or rec_a 8 B per leaf) lie
+                        # between the two table sizes measured: the same rate against the smaller table's (higher) ceiling
+                        "ceiling_half_table_Greads_per_s": hw["table_half"]["Greads_per_s"],
+                        "ceiling_half_table_MiB": hw["table_half"]["MiB"],
+                        "frac_of_half_table_ceiling": rate / 1e9 / hw["table_half"]["Greads_per_s"],
+                        "gather_footprint_MiB": foot / 2**20,
                         "source": "requests: rocprofv3 TCC_EA0_RDREQ_sum in %s; ceiling: suchtree_amd/csrc/microbench.hip "
                                   "run in this process (random 32-byte reads, one per 64-byte sector; best of a sweep over "
                                   "unroll and grid shape)" % traffic_file}
