@@ -5,6 +5,8 @@
 //   A  every lane: random 128-byte line, sector 0 (4 x 16 B), then sector 1 (4 x 16 B)      [streams today]
 //   B  lane pair (2k, 2k+1): one random line, lane 2k sector 0, lane 2k+1 sector 1, same instructions
 //   C  every lane: one sector (4 x 16 B) of a random line                                     [reference]
+//   D  every lane: one 16-byte quad of a random line (with the L1 counters: does C's sector cost one L1 -> L2
+//      request or four?)
 // Tables: 32 MiB (Infinity Cache) and 2 GiB (HBM).  Rates in G sectors/s.
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/micro/bin/sector_pair scripts/micro/sector_pair.hip
 #include <hip/hip_runtime.h>
@@ -27,6 +29,9 @@ __global__ __launch_bounds__(256) void k(const uint8_t *__restrict__ table, uint
             const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
             const uint4 e = p[4], f = p[5], g = p[6], h = p[7];
             acc += a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w;
+        } else if (MODE == 3) {      // D: one 16-byte quad of a random line (how many L1 -> L2 requests does C's sector cost?)
+            const uint4 a = *reinterpret_cast<const uint4 *>(line);
+            acc += a.x + a.w;
         } else {
             const uint4 *p = reinterpret_cast<const uint4 *>(line + (MODE == 1 ? (tid & 1) * 64 : 0));
             const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -44,13 +49,14 @@ int main()
         uint8_t *t; CK(hipMalloc(&t, bytes)); CK(hipMemset(t, 1, bytes));
         const uint32_t mask = (uint32_t)(bytes / 128 - 1);
         const int blocks = 256 * 8, iters = 256;
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 4; mode++) {
             float best = 1e30f;
             for (int rep = 0; rep < 4; rep++) {
                 CK(hipEventRecord(e0));
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, t, mask, iters, d_out);
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, t, mask, iters, d_out);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, t, mask, iters, d_out);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, t, mask, iters, d_out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 if (rep && ms < best) best = ms;
@@ -58,7 +64,7 @@ int main()
             const double lanes = (double)blocks * 256 * iters;
             const double sectors = mode == 0 ? 2 * lanes : lanes;
             printf("table %5zu MiB  %s  %7.3f ms  %6.1f G sectors/s  %5.2f TB/s\n", bytes >> 20,
-                   mode == 0 ? "A one lane, both sectors in turn " : mode == 1 ? "B lane pair, one sector each     " : "C one lane, one sector           ",
+                   mode == 0 ? "A one lane, both sectors in turn " : mode == 1 ? "B lane pair, one sector each     " : mode == 2 ? "C one lane, one sector           " : "D one lane, one 16-byte quad     ",
                    best, sectors / best / 1e6, sectors * 64 / best / 1e9);
         }
         CK(hipFree(t));
