@@ -57,7 +57,16 @@ public:
         n_ = std::max(1, n_threads);
         quit_.store(false);
         const uint64_t born = generation_.load();     // (a restarted pool does not start from zero)
-        for (int i = 0; i < n_ - 1; i++) workers_.emplace_back([this, i, born] { loop(i + 1, born); });
+        const int want = n_;
+        try {
+            workers_.reserve((size_t)want);
+            for (int i = 0; i < want - 1; i++) workers_.emplace_back([this, i, born] { loop(i + 1, born); });
+        } catch (...) {
+            // (thread limit reached, out of memory: the pool works with the threads it has -- the phases
+            // are split into n_ parts and wait for n_ - 1 workers, so n_ must be what actually runs)
+            stop();
+            n_ = 1;
+        }
     }
 
     void stop()

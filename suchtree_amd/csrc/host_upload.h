@@ -141,6 +141,19 @@ static bool upload_optional(P **dst, const V &v, int64_t *bytes)
     return true;
 }
 
+// Destroys a handle that is still under construction, on every way out but success; the error message survives.
+struct TreeOwner {
+    st_tree *t;
+    ~TreeOwner()
+    {
+        if (!t) return;
+        std::string keep;
+        try { keep = g_last_error; } catch (...) {}
+        st_tree_destroy(t);
+        try { g_last_error = keep; } catch (...) {}
+    }
+};
+
 static int upload_tree(BuiltTables &B, int device, st_tree **out)
 {
     TreeTables &T = B.T;
@@ -155,6 +168,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
 
     st_tree *t = new (std::nothrow) st_tree();
     if (!t) return fail(ST_ERR_NOMEM, "out of host memory");
+    TreeOwner owner{t};      // (a std::bad_alloc below unwinds to the C ABI's catch: the half-built handle goes with it)
     t->device = device;
     t->dp = pipe_acquire(device);
     t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -246,12 +260,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
         if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
         else t->d_fault_host = t->d_fault + 1;
     }
-    if (rc != ST_OK) {
-        std::string keep = g_last_error;
-        st_tree_destroy(t);
-        g_last_error = keep;
-        return rc;
-    }
+    if (rc != ST_OK) return rc;      // (owner destroys t and keeps the message)
     t->strategy = B.canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
     t->info.n_nodes = T.n;
     t->info.n_leaves = T.n_leaves;
@@ -264,6 +273,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->info.n_devices = 1;
     t->info.device_bytes = bytes;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
+    owner.t = nullptr;
     *out = t;
     return ST_OK;
 }

@@ -70,6 +70,25 @@ static int fail(int code, const std::string &msg)
     return code;
 }
 
+// Nothing may be thrown through the C ABI (the callers are ctypes, cgo, JNI ...): every int-returning export is
+// a function-try-block that ends in ST_CATCH_ALL.
+static int on_exception() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        try { g_last_error = "out of host memory"; } catch (...) {}
+        return ST_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        try { g_last_error = std::string("internal error: ") + e.what(); } catch (...) {}
+        return ST_ERR_HIP;
+    } catch (...) {
+        try { g_last_error = "internal error"; } catch (...) {}
+        return ST_ERR_HIP;
+    }
+}
+#define ST_CATCH_ALL catch (...) { return st::on_exception(); }
+
 #define ST_HIP(call)                                                              \
     do {                                                                          \
         hipError_t e_ = (call);                                                   \
@@ -125,7 +144,7 @@ extern "C" {
 const char *st_last_error(void) { return g_last_error.c_str(); }
 
 int st_device_count(int *count)
-{
+try {
     if (!count) return fail(ST_ERR_ARG, "count is NULL");
     *count = 0;
     int c = 0;
@@ -136,10 +155,10 @@ int st_device_count(int *count)
     }
     *count = c;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths, int32_t *out_tree_depth)
-{
+try {
     if (!parent || n_nodes <= 0) return fail(ST_ERR_ARG, "parent is NULL or n_nodes <= 0");
     std::vector<float> zeros((size_t)n_nodes, 0.0f);
     TreeTables T;
@@ -148,20 +167,20 @@ int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths, 
     if (out_depths) std::memcpy(out_depths, T.depth.data(), (size_t)n_nodes * 4);
     if (out_tree_depth) *out_tree_depth = T.tree_depth;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_host_chunk_plan(int64_t n, int n_devices, int64_t *chunk_pairs, int64_t *n_chunks)
-{
+try {
     if (n < 0 || n_devices < 1) return fail(ST_ERR_ARG, "n < 0 or n_devices < 1");
     const int64_t chunk = host_chunk_pairs(n, n_devices);
     if (chunk_pairs) *chunk_pairs = chunk;
     if (n_chunks) *n_chunks = (n + chunk - 1) / chunk;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_host_chunk_owner(int64_t n, int n_devices, int64_t chunk_index, int *device_index,
                         int64_t *first_pair, int64_t *n_pairs)
-{
+try {
     if (n < 0 || n_devices < 1 || chunk_index < 0) return fail(ST_ERR_ARG, "bad arguments");
     const int64_t chunk = host_chunk_pairs(n, n_devices);
     if (chunk_index * chunk >= n) return fail(ST_ERR_ARG, "chunk index past the end of the batch");
@@ -170,7 +189,7 @@ int st_host_chunk_owner(int64_t n, int n_devices, int64_t chunk_index, int *devi
     if (first_pair) *first_pair = chunk_index * chunk;
     if (n_pairs) *n_pairs = std::min(chunk, n - chunk_index * chunk);
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 static int check_create_args(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, st_tree **out)
 {
@@ -184,18 +203,18 @@ static int check_create_args(const int32_t *parent, const float *distance, int64
 
 int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes, int device,
                    int strategy, st_tree **out)
-{
+try {
     int rc = check_create_args(parent, distance, n_nodes, strategy, out);
     if (rc != ST_OK) return rc;
     BuiltTables B;
     rc = build_tables(parent, distance, n_nodes, strategy, B);
     if (rc != ST_OK) return rc;
     return upload_tree(B, device, out);
-}
+} ST_CATCH_ALL
 
 int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n_nodes,
                          const int *devices, int n_devices, int strategy, st_tree **out)
-{
+try {
     int rc = check_create_args(parent, distance, n_nodes, strategy, out);
     if (rc != ST_OK) return rc;
     if (!devices || n_devices < 1) return fail(ST_ERR_ARG, "devices is NULL or n_devices < 1");
@@ -212,21 +231,19 @@ int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n
     st_tree *primary = nullptr;
     rc = upload_tree(B, devices[0], &primary);
     if (rc != ST_OK) return rc;
+    TreeOwner owner{primary};      // (destroys the primary and the peers it holds unless every replica was built)
+    primary->peers.reserve((size_t)n_devices);
     for (int i = 1; i < n_devices; i++) {
         st_tree *peer = nullptr;
         rc = upload_tree(B, devices[i], &peer);
-        if (rc != ST_OK) {
-            std::string keep = g_last_error;
-            st_tree_destroy(primary);
-            g_last_error = keep;
-            return rc;
-        }
+        if (rc != ST_OK) return rc;
         primary->peers.push_back(peer);
     }
     primary->info.n_devices = n_devices;
+    owner.t = nullptr;
     *out = primary;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 void st_tree_destroy(st_tree *t)
 {
@@ -269,25 +286,25 @@ void st_tree_destroy(st_tree *t)
 }
 
 int st_tree_info_get(const st_tree *t, st_tree_info *info)
-{
+try {
     if (!t || !info) return fail(ST_ERR_ARG, "tree or info is NULL");
     *info = t->info;
     info->strategy = t->strategy;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_tree_devices(const st_tree *t, int *devices, int capacity, int *n_devices)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     const int n = 1 + (int)t->peers.size();
     if (n_devices) *n_devices = n;
     if (devices)
         for (int i = 0; i < n && i < capacity; i++) devices[i] = i == 0 ? t->device : t->peers[(size_t)i - 1]->device;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_tree_set_strategy(st_tree *t, int strategy)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     if (strategy == ST_STRATEGY_AUTO) strategy = t->has_canopy ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
     if (strategy == ST_STRATEGY_CANOPY && !t->has_canopy)
@@ -297,7 +314,7 @@ int st_tree_set_strategy(st_tree *t, int strategy)
     t->strategy = strategy;
     for (st_tree *p : t->peers) p->strategy = strategy;
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 static int set_option_one(st_tree *t, const char *name, int64_t value)
 {
@@ -360,17 +377,17 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
 }
 
 int st_tree_set_option(st_tree *t, const char *name, int64_t value)
-{
+try {
     if (!t || !name) return fail(ST_ERR_ARG, "tree or name is NULL");
     int rc = set_option_one(t, name, value);
     for (st_tree *p : t->peers)
         if (rc == ST_OK) rc = set_option_one(p, name, value);
     return rc;
-}
+} ST_CATCH_ALL
 
 int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0,
                         int64_t stride1, double *d_out_dist, int32_t *d_out_mrca, void *stream)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     if (n < 0) return fail(ST_ERR_ARG, "n < 0");
     if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
@@ -378,11 +395,11 @@ int st_distances_device(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s
     ST_DEVICE(t->device);
     return enqueue(t, d_pairs, n, stride0, stride1, DistSink{d_out_dist, nullptr}, d_out_mrca,
                    reinterpret_cast<hipStream_t>(stream));
-}
+} ST_CATCH_ALL
 
 int st_distances_device_f32(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0,
                             int64_t stride1, float *d_out_dist, int32_t *d_out_mrca, void *stream)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     if (n < 0) return fail(ST_ERR_ARG, "n < 0");
     if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
@@ -390,17 +407,17 @@ int st_distances_device_f32(st_tree *t, const int64_t *d_pairs, int64_t n, int64
     ST_DEVICE(t->device);
     return enqueue(t, d_pairs, n, stride0, stride1, DistSink{nullptr, d_out_dist}, d_out_mrca,
                    reinterpret_cast<hipStream_t>(stream));
-}
+} ST_CATCH_ALL
 
 int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     ST_DEVICE(t->device);
     Fault f;
     const int rc = fetch_fault(t->d_fault, reinterpret_cast<hipStream_t>(stream), f);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
-}
+} ST_CATCH_ALL
 
 }  // extern "C"
 
@@ -489,15 +506,15 @@ extern "C" {
 
 int st_distances_host(st_tree *t, const int64_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
                       double *out_dist, int32_t *out_mrca, int64_t *bad_id)
-{
+try {
     return distances_host_impl(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
-}
+} ST_CATCH_ALL
 
 int st_distances_host_i32(st_tree *t, const int32_t *pairs, int64_t n, int64_t stride0, int64_t stride1,
                           double *out_dist, int32_t *out_mrca, int64_t *bad_id)
-{
+try {
     return distances_host_impl(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
-}
+} ST_CATCH_ALL
 
 static int triangle_args(st_tree *t, const int64_t *ids, int64_t m, int64_t k_begin, int64_t k_count,
                          const void *out_d, const void *out_m)
@@ -515,18 +532,18 @@ static int triangle_args(st_tree *t, const int64_t *ids, int64_t m, int64_t k_be
 int st_triangle_device(st_tree *t, const int64_t *d_ids, int64_t m, int64_t id_stride,
                        int64_t k_begin, int64_t k_count, double *d_out_dist, int32_t *d_out_mrca,
                        void *stream)
-{
+try {
     int rc = triangle_args(t, d_ids, m, k_begin, k_count, d_out_dist, d_out_mrca);
     if (rc != ST_OK) return rc;
     ST_DEVICE(t->device);
     const SrcTriangle src{reinterpret_cast<const long long *>(d_ids), (long long)id_stride, (long long)k_begin};
     return enqueue_src(t, src, k_count, DistSink{d_out_dist, nullptr}, d_out_mrca, t->d_fault,
                        reinterpret_cast<hipStream_t>(stream));
-}
+} ST_CATCH_ALL
 
 int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_stride, int64_t k_begin,
                      int64_t k_count, double *out_dist, int32_t *out_mrca, int64_t *bad_id)
-{
+try {
     int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
@@ -560,7 +577,7 @@ int st_triangle_host(st_tree *t, const int64_t *ids, int64_t m, int64_t id_strid
     rc = for_each_replica(t, k_count, fault, work);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, fault, bad_id);
-}
+} ST_CATCH_ALL
 
 static int grid_args(st_tree *t, const int64_t *rows, int64_t n_rows, const int64_t *cols, int64_t n_cols,
                      int64_t e_begin, int64_t e_count, const void *out_d, const void *out_m)
@@ -577,7 +594,7 @@ static int grid_args(st_tree *t, const int64_t *rows, int64_t n_rows, const int6
 int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64_t *col_ids, int64_t n_cols,
                  int symmetric, int64_t e_begin, int64_t e_count, double *out_dist, int32_t *out_mrca,
                  int64_t *bad_id)
-{
+try {
     int rc = grid_args(t, row_ids, n_rows, col_ids, n_cols, e_begin, e_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (symmetric && (n_rows != n_cols)) return fail(ST_ERR_ARG, "symmetric grid needs n_rows == n_cols");
@@ -606,11 +623,11 @@ int st_grid_host(st_tree *t, const int64_t *row_ids, int64_t n_rows, const int64
     rc = for_each_replica(t, e_count, fault, work);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, fault, bad_id);
-}
+} ST_CATCH_ALL
 
 int st_knn_host(st_tree *t, const int64_t *queries, int64_t n_queries, const int64_t *cands, int64_t n_cands,
                 int k, int skip_self, int64_t *out_index, double *out_dist, int64_t *bad_id)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     if (n_queries < 0 || n_cands < 0) return fail(ST_ERR_ARG, "negative size");
     if (k < 1 || k > kKnnMaxK) return fail(ST_ERR_ARG, "k must be in [1, " + std::to_string(kKnnMaxK) + "]");
@@ -661,11 +678,11 @@ int st_knn_host(st_tree *t, const int64_t *queries, int64_t n_queries, const int
     cleanup();
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
-}
+} ST_CATCH_ALL
 
 int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t stride0, int64_t stride1,
                      int64_t *out_topologies, int64_t *bad_id)
-{
+try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
     if (n < 0) return fail(ST_ERR_ARG, "n < 0");
     if (n > 0 && (!quartets || !out_topologies)) return fail(ST_ERR_ARG, "quartets or output is NULL");
@@ -751,11 +768,11 @@ int st_quartets_host(st_tree *t, const int64_t *quartets, int64_t n, int64_t str
     const int rc = end_host_faults(t, pipe.slot[0].stream, f);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
-}
+} ST_CATCH_ALL
 
 int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t *u, const int32_t *v,
                            const double *w, double *out_adjacency, double *out_laplacian)
-{
+try {
     if (n <= 0 || n_edges < 0) return fail(ST_ERR_ARG, "bad sizes");
     if (n_edges > 0 && (!u || !v || !w)) return fail(ST_ERR_ARG, "edge arrays are NULL");
     if (!out_adjacency && !out_laplacian) return fail(ST_ERR_ARG, "both outputs are NULL");
@@ -827,57 +844,57 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
     }
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("graph matrices: ") + hipGetErrorString(e));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_host_alloc(int64_t bytes, void **out)
-{
+try {
     if (!out || bytes < 0) return fail(ST_ERR_ARG, "bad arguments");
     *out = nullptr;
     // portable: addressable by every GPU of the process (multi-device handles write into it too)
     ST_HIP(hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocPortable));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_host_free(void *ptr)
-{
+try {
     if (ptr) ST_HIP(hipHostFree(ptr));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_device_malloc(int device, int64_t bytes, void **out)
-{
+try {
     if (!out || bytes < 0) return fail(ST_ERR_ARG, "bad arguments");
     ST_DEVICE(device);
     ST_HIP(hipMalloc(out, (size_t)std::max<int64_t>(bytes, 16)));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_device_free(int device, void *ptr)
-{
+try {
     ST_DEVICE(device);
     ST_HIP(hipFree(ptr));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_memcpy_h2d(int device, void *dst, const void *src, int64_t bytes)
-{
+try {
     ST_DEVICE(device);
     ST_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_memcpy_d2h(int device, void *dst, const void *src, int64_t bytes)
-{
+try {
     ST_DEVICE(device);
     ST_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 int st_device_synchronize(int device)
-{
+try {
     ST_DEVICE(device);
     ST_HIP(hipDeviceSynchronize());
     return ST_OK;
-}
+} ST_CATCH_ALL
 
 }  // extern "C"
