@@ -248,8 +248,12 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "walk_ladder": 1 (default) = where the crown is small enough (<= 8192 nodes) the tile-sorted walk kernel keeps
  * its ladder form in LDS and climbs the upper part of the second node's side there (three edges per 16-byte LDS
  * read) instead of streaming it; 0 = it streams it from the portal's block.
- * "walk_sort": 1 (default) = batches of >= 524288 pairs on trees with the sparse table and both lineage
+ * "walk_sort": 1 (default) = batches of >= 262144 pairs on trees with the sparse table and both lineage
  * tables run the tile-sorted walk kernel (a wave's 64 pairs have streams of similar length); 0 = k_walk.
+ * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
+ * "sort_tile": tile of both tile-sorted kernels in units of 1024 pairs: 1, 2 or 4 (taken when it fits LDS and the
+ * kernel's form has that tile), 0 (default) = the largest tile LDS admits, cut finer for batches that would
+ * otherwise leave CUs without a tile.
  * "rec_a4": 1 (default) = on trees whose leaves sit in portal-uniform aligned blocks of leaf slots (balanced
  * and near-balanced trees) the predicated canopy kernel gathers 4 bytes for the first node of a pair
  * (its understory sum; the portal comes from a block table in LDS) instead of the 8-byte entry; 0 = 8 bytes.

@@ -27,7 +27,7 @@ hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const S
                                        DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
 {
     const SortedShape shape = sorted_shape(t);
-    const int q = shape.q;
+    const int q = batch_tile_q(shape.q, shape.sums ? 1 : 2, t->sort_tile, n, t->n_cu);      // (instantiated: 1, 2, 4 with lineage sums, else 2, 4)
     const size_t lds = ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(q, shape.rmq, shape.sums);
     CanopyParams Pk = P;
     if (!shape.rmq) { Pk.cpos = nullptr; Pk.rmq = nullptr; }

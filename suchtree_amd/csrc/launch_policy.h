@@ -27,7 +27,6 @@ struct SortedShape {
 static inline SortedShape sorted_shape(const st_tree *t)
 {
     const size_t image = ladder_image_bytes(t->canopy_nodes);
-    static const int forced = std::getenv("SUCHTREE_AMD_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_SORT_Q")) : 0;   // tuning experiments
     const bool table = t->d_rmq != nullptr;
     const bool lineage = table && t->d_lineage != nullptr && t->lineage_sums;
     struct Mode { bool rmq, sums; };
@@ -35,8 +34,6 @@ static inline SortedShape sorted_shape(const st_tree *t)
     // the lock-step search; within a mode the largest tile that fits, two workgroups per CU if possible
     for (const Mode m : {Mode{true, true}, Mode{true, false}, Mode{false, false}}) {
         if ((m.rmq && !table) || (m.sums && !lineage)) continue;
-        if ((forced == 1 || forced == 2 || forced == 4) && image + sort_scratch_bytes(forced, m.rmq, m.sums) <= 160 * 1024)
-            return {forced, m.rmq, m.sums};
         // two workgroups per CU where that is possible -- except with lineage sums: that form of the
         // kernel needs more than 64 VGPRs, so only one workgroup fits a CU anyway, and the larger
         // tile wins (caterpillar of 2048 leaves: 1.35e10 pairs/s with 4096-pair tiles, 9.8e9 with 2048)
@@ -54,13 +51,29 @@ static inline SortedShape sorted_shape(const st_tree *t)
 
 static inline int sorted_q(const st_tree *t) { return sorted_shape(t).q; }
 
+// Tile of one launch of a tile-sorted kernel, in units of 1024 pairs: q_max is what LDS admits (the tile of
+// large batches: fewer image stagings, better sorted groups); a batch that would leave CUs without a tile at
+// that size is cut finer, down to q_min (the smallest instantiated tile of the mode) -- a 262,144-pair batch on
+// ml.tree is 64 tiles of 4096 pairs (45 us on a quarter of the CUs) or 256 of 1024 (22 us).  `forced`: the
+// sort_tile option.  profiles/midsize_r03.log.
+static inline int batch_tile_q(int q_max, int q_min, int forced, int64_t n, int n_cu)
+{
+    if ((forced == 1 || forced == 2 || forced == 4) && forced >= q_min && forced <= q_max) return forced;
+    int q = q_max;
+    while (q > q_min && (n + (int64_t)q * 1024 - 1) / ((int64_t)q * 1024) < (int64_t)n_cu) q >>= 1;
+    return q;
+}
+
 // Smallest batch the canopy kernels take.  The tile-sorted kernel has a fixed cost (every
 // workgroup stages a ladder image of up to 150 KiB, sorts, and on the host path its slot is
 // staged through device memory), and with lineage sums the walk kernel does 8e9 pairs/s on deep
 // trees: 10,000 pairs of ml.tree through the host path 73 us sorted, 40 us walked.
 constexpr int64_t kCanopyMinPairs = 4096;
-constexpr int64_t kSortedMinPairs = 32768;        // deep canopies with lineage sums: below this the walk kernel wins
-constexpr int64_t kSortedMinPairsHost = 131072;   // ... on the host path, where the tile-sorted kernel also needs its slot staged in device memory
+// deep canopies with lineage sums: below this the walk kernel wins (device-resident batches, us per call,
+// k_walk / tile-sorted canopy kernel with 1024-pair tiles: ml.tree 32768 pairs 11.0 / 13.7, 65536 14.4 / 16.3,
+// 131072 19.7 / 19.1, 262144 31.0 / 22.3; nj.tree 9.6 / 13.3, 12.8 / 17.0, 17.9 / 19.6, 26.9 / 23.2;
+// profiles/midsize_r03.log)
+constexpr int64_t kSortedMinPairs = 131072;
 
 static inline int64_t canopy_min_pairs(const st_tree *t)
 {
@@ -75,12 +88,14 @@ static inline bool mrca_ranks_ready(const st_tree *t)
 // Deep-canopy trees whose canopy image leaves the tile-sorted canopy kernel only small tiles (nj.tree: 9111
 // canopy nodes = 146 KiB, 1024-pair tiles) are served faster by the tile-sorted WALK kernel once its crown
 // ladder exists: a crown of <= 5120 nodes, 4096-pair tiles (nj.tree, 1e7 pairs: 1.73e10 against 1.60e10
-// pairs/s; ml.tree keeps the canopy kernel: 2.15e10 against 1.73e10).  Large batches with distances only.
+// pairs/s; ml.tree keeps the canopy kernel: 2.15e10 against 1.73e10).  Batches of 524288 pairs and more (below,
+// the canopy kernel's 1024-pair tiles are the right size anyway: 262144 pairs 23.2 us either way).
 static inline bool walk_sorted_ready(const st_tree *t);
-constexpr int64_t kWalkSortedMinPairs = 524288;
+constexpr int64_t kWalkSortedMinPairs = 262144;
+static inline int64_t walk_sorted_min_pairs(const st_tree *t) { return t->walk_sort_min > 0 ? t->walk_sort_min : kWalkSortedMinPairs; }
 static inline bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
 {
-    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || !want_dist || n < kWalkSortedMinPairs) return false;
+    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || !want_dist || n < std::max<int64_t>(walk_sorted_min_pairs(t), 524288)) return false;
     const int q = sorted_q(t);
     return q > 0 && q < 4 && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
 }
@@ -99,15 +114,15 @@ static inline bool wants_device_stage(const st_tree *t, int64_t m)
     if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
     if (prefers_walk_sorted(t, m, true)) return false;      // (that kernel reads every pair once and stores coalesced)
     if (sorted_zero_copy(t)) return false;
-    return m >= (canopy_min_pairs(t) == kSortedMinPairs ? kSortedMinPairsHost : kCanopyMinPairs);
+    return m >= canopy_min_pairs(t);
 }
 
-// Smallest batch the tile-sorted walk kernel takes: below it k_walk's finer grain wins (a 1e5-pair
-// batch is 25 tiles of 4096 pairs on 256 CUs; measured on ml.tree, pairs per second unsorted / sorted:
-// 1e5 pairs 4.9e9 / 1.3e9, 4e5 8.0e9 / 5.3e9, 8e5 9.1e9 / 1.03e10, 3.2e6 1.0e10 / 1.08e10, 1e7 1.1e10 /
-// 1.35e10).  Tiles: 4096 pairs on trees with canopy tables, 2048 on trees only the walk family serves
-// (1e6-leaf depth-338 tree, 1e7 / 4e7 pairs: 5.93e9 / 6.43e9 against 5.76e9 / 5.90e9 with 4096;
-// ml.tree: 1.28e10 / 1.34e10 against 1.32e10 / 1.41e10).  (kWalkSortedMinPairs = 524288, above.)
+// Smallest batch the tile-sorted walk kernel takes: below it k_walk's finer grain wins.  With tiles by batch
+// size (batch_tile_q), us per call on ml.tree, k_walk / k_walk_sorted: 131072 pairs 19.7 / 22.8, 262144 31.0 /
+// 25.2, 524288 62.7 / 37.5, 1048576 112 / 62; nj.tree 17.8 / 21.2, 26.7 / 23.2, 54.7 / 35.4, 100 / 62
+// (profiles/midsize_r03.log).  Largest tiles: 4096 pairs on trees with canopy tables, 2048 on trees only the walk
+// family serves (1e6-leaf depth-338 tree, 1e7 / 4e7 pairs: 5.93e9 / 6.43e9 against 5.76e9 / 5.90e9 with 4096;
+// ml.tree: 1.28e10 / 1.34e10 against 1.32e10 / 1.41e10).  (kWalkSortedMinPairs = 262144, above.)
 
 static inline bool walk_sorted_ready(const st_tree *t)
 {

@@ -65,19 +65,20 @@ hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out
                               int32_t *out_m, Fault *fault, hipStream_t stream)
 {
     const WalkParams P = walk_params(t);
-    if (out_d.any() && n >= kWalkSortedMinPairs && walk_sorted_ready(t)) {
-        static const int forced = std::getenv("SUCHTREE_AMD_WALK_SORT_Q") ? std::atoi(std::getenv("SUCHTREE_AMD_WALK_SORT_Q")) : 0;   // tuning experiments
+    if (out_d.any() && n >= walk_sorted_min_pairs(t) && walk_sorted_ready(t)) {
         if (P.crown_ladder) {
-            // the crown's ladder in LDS: the largest tile that fits beside it
+            // the crown's ladder in LDS: the largest tile that fits beside it, cut finer for batches that would
+            // leave CUs idle (launch_policy.h: batch_tile_q)
             const size_t image = (size_t)P.lineage.crown_nodes * 16;
-            const int q = forced ? forced : image + walk_sort_scratch_bytes(4) <= 160 * 1024 ? 4 : image + walk_sort_scratch_bytes(2) <= 160 * 1024 ? 2 : 1;
-            if (image + walk_sort_scratch_bytes(q) <= 160 * 1024) {
+            const int q_max = image + walk_sort_scratch_bytes(4) <= 160 * 1024 ? 4 : image + walk_sort_scratch_bytes(2) <= 160 * 1024 ? 2 : 1;
+            if (image + walk_sort_scratch_bytes(q_max) <= 160 * 1024) {
+                const int q = batch_tile_q(q_max, 1, t->sort_tile, n, t->n_cu);
                 if (q == 4) return launch_walk_sorted<4, true>(t, P, src, n, out_d, out_m, fault, stream);
                 if (q == 2) return launch_walk_sorted<2, true>(t, P, src, n, out_d, out_m, fault, stream);
                 return launch_walk_sorted<1, true>(t, P, src, n, out_d, out_m, fault, stream);
             }
         }
-        const int q = forced ? forced : t->has_canopy ? 4 : 2;
+        const int q = batch_tile_q(t->has_canopy ? 4 : 2, 1, t->sort_tile, n, t->n_cu);
         if (q == 4) return launch_walk_sorted<4, false>(t, P, src, n, out_d, out_m, fault, stream);
         if (q == 2) return launch_walk_sorted<2, false>(t, P, src, n, out_d, out_m, fault, stream);
         return launch_walk_sorted<1, false>(t, P, src, n, out_d, out_m, fault, stream);

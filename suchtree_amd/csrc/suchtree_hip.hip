@@ -349,6 +349,16 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->walk_ladder = (int)value;
         return ST_OK;
     }
+    if (std::strcmp(name, "sort_tile") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(ST_ERR_ARG, "sort_tile must be 0, 1, 2 or 4");
+        t->sort_tile = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "walk_sort_min") == 0) {
+        if (value < 0) return fail(ST_ERR_ARG, "walk_sort_min must be >= 0");
+        t->walk_sort_min = value;
+        return ST_OK;
+    }
     if (std::strcmp(name, "walk_crown") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_crown must be 0 or 1");
         t->walk_crown = (int)value;

@@ -213,7 +213,7 @@ def test_walk_only_tree_with_sparse_table_and_lineage_sums():
 
 @pytest.mark.parametrize("which", ["walk_only", "ml"])
 def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
-    """k_walk_sorted (batches >= 524288 pairs on trees with the sparse table and both lineage tables) and
+    """k_walk_sorted (batches >= 262144 pairs on trees with the sparse table and both lineage tables) and
     every table it builds on, switched on and off in all combinations: tile sort, crown (shared portal
     blocks + crown sparse table), the crown's ladder in LDS, lineage lengths, whole-tree sparse table.  A walk-only tree (the canopy
     family refuses it) and ml.tree with the walk family forced.  Leaves and internal nodes, near pairs,
@@ -253,6 +253,20 @@ def test_tile_sorted_walk_kernel_and_its_tables(which, ml_arrays):
         assert np.array_equal(out_m.cpu().numpy(), want_m), what
     for name in ("walk_sort", "walk_crown", "lineage_lens", "tree_rmq", "walk_ladder"):
         dev.set_option(name, 1)
+    # every tile size (the default picks one by batch size), with and without the ladder; a batch just above the
+    # kernel's smallest
+    for tile, lad in itertools.product((1, 2, 4), (1, 0)):
+        dev.set_option("sort_tile", tile)
+        dev.set_option("walk_ladder", lad)
+        for n_dev in (len(allp), 262_144 + 77):
+            out_d.fill_(-1.0)
+            dev.distances_device(t.data_ptr(), n_dev, out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d[:n_dev].cpu().numpy(), want_d[:n_dev], "sort_tile=%d ladder=%d n=%d" % (tile, lad, n_dev))
+            assert np.array_equal(out_m[:n_dev].cpu().numpy(), want_m[:n_dev])
+            assert out_d[n_dev:n_dev + 64].eq(-1.0).all() or n_dev == len(allp)
+    dev.set_option("sort_tile", 0)
+    dev.set_option("walk_ladder", 1)
     # distances only / MRCA ids only, float32 sink, the host path (pinned staging read once, coalesced stores)
     dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), 0)
     assert_bits_equal(out_d.cpu().numpy(), want_d, "distances only")
@@ -561,8 +575,17 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
                 assert np.array_equal(m, want_m[:n_host])
             m_only = dev.distances_host(allp[:9_000], False, True)[1]
             assert np.array_equal(m_only, want_m[:9_000])
-            if on:      # either side of the walk / tile-sorted switch: 32768 pairs in HBM, 131072 from the host
-                for n_dev in (32767, 32768, 32769):
+            # every tile size the tile-sorted kernel is built with (the default picks one by batch size)
+            for tile in (1, 2, 4, 0):
+                dev.set_option("sort_tile", tile)
+                out_d.fill_(-5.0)
+                out_m.fill_(-5)
+                dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+                dev.fault_check()
+                assert_bits_equal(out_d.cpu().numpy(), want_d, "lineage_sums=%d sort_tile=%d" % (on, tile))
+                assert np.array_equal(out_m.cpu().numpy(), want_m)
+            if on:      # either side of the walk / tile-sorted switch: 131072 pairs, in HBM and from the host
+                for n_dev in (131071, 131072, 131073):
                     out_d.fill_(-5.0)
                     dev.distances_device(t.data_ptr(), n_dev, out_d.data_ptr(), out_m.data_ptr())
                     dev.fault_check()
