@@ -11,8 +11,15 @@ sys.path.insert(0, ROOT)
 from suchtree_amd import _capi   # noqa: E402
 
 for name in sys.argv[1:] or ("ml", "nj"):
-    z = np.load(os.path.join(ROOT, "tests", "golden", "%s_tree.npz" % name))
-    parent, dist = z["parent"], z["distance"]
+    if name.startswith("balanced"):
+        from suchtree_amd import synth
+        parent, dist = synth.balanced_tree(int(name[8:]))
+    elif name.startswith("random"):
+        from suchtree_amd import synth
+        parent, dist = synth.random_binary_tree(1 << int(name[6:]), seed=3)
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "%s_tree.npz" % name))
+        parent, dist = z["parent"], z["distance"]
     leaves = np.flatnonzero(np.bincount(parent[parent >= 0], minlength=len(parent)) == 0)
     rng = np.random.default_rng(3)
     nmax = 1 << 22
@@ -28,7 +35,7 @@ for name in sys.argv[1:] or ("ml", "nj"):
         trees[strategy] = _capi.DeviceTree(parent, dist)
         if strategy == "walk":
             trees[strategy].set_strategy("walk")
-    for sh in range(15, 23):
+    for sh in range(int(os.environ.get('MIDSIZE_FIRST', '15')), 23):
         n = 1 << sh
         line = "%9d " % n
         for strategy, q, wmin in cols:
