@@ -23,6 +23,9 @@ def main():
     z = np.load(os.path.join(ROOT, "tests", "golden", "ml_tree.npz"))
     trees = [(z["parent"], z["distance"]), synth.balanced_tree(16), synth.random_binary_tree(30000, seed=3),
              synth.caterpillar_tree(2500)]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _random_shape_tree
+    trees.append(_random_shape_tree(np.random.default_rng(7), 120_000, 0.97))      # only the walk family serves it
     devs = [_capi.DeviceTree(p, d) for p, d in trees]
     oracles = [OracleTree(p, d) for p, d in trees]
     stop = time.time() + args.seconds
@@ -57,6 +60,14 @@ def main():
                         dev.set_option("tile_sort", int(rng.integers(0, 2)))
                         dev.set_option("lineage_sums", int(rng.integers(0, 2)))
                     dev.set_option("mrca_ranks", int(rng.integers(0, 2)))
+                    dev.set_option("sort_tile", int(rng.choice([0, 0, 1, 2, 4])))
+                    dev.set_option("rec_a4", int(rng.integers(0, 2)))
+                    if k in (0, 4):
+                        for name in ("walk_sort", "walk_ladder", "walk_crown", "lineage_lens"):
+                            dev.set_option(name, int(rng.random() < 0.8))
+                        dev.set_option("walk_sort_min", int(rng.choice([0, 40000])))
+                        if k == 0:
+                            dev.set_strategy("walk" if rng.random() < 0.3 else "canopy")
                 if rng.random() < 0.2:
                     view = np.ascontiguousarray(view).astype(np.int32)      # the int32 entry point
                 d, m = dev.distances_host(view, want_d, want_m)
