@@ -60,7 +60,16 @@ typedef struct st_tree_info {
     int32_t n_devices;        /* GPUs holding a replica (1 unless st_tree_create_multi) */
     int64_t device_bytes;     /* HBM held by this tree */
     int64_t lineage_entries;  /* float32 entries of the lineage-sum table (deep canopies, in-order ids), else 0 */
+    int32_t big_batch_kernel; /* kernel of large distance batches: ST_KERNEL_* below */
+    int32_t tuned;            /* 1 = that kernel was chosen by timing the candidates when the tree was created */
 } st_tree_info;
+
+/* st_tree_info.big_batch_kernel */
+#define ST_KERNEL_WALK            0   /* k_walk / k_walk_sorted: trees the canopy family does not serve */
+#define ST_KERNEL_CANOPY          1   /* predicated canopy kernel (one pair per lane, chain in registers) */
+#define ST_KERNEL_CANOPY_SCALAR   2   /* branchy canopy kernel */
+#define ST_KERNEL_CANOPY_SORTED   3   /* tile-sorted canopy kernel (ladder form of the canopy in LDS) */
+#define ST_KERNEL_WALK_SORTED     4   /* tile-sorted walk kernel on a tree that also has canopy tables */
 
 /* Last error message of the calling thread ("" if none). */
 const char *st_last_error(void);
@@ -250,6 +259,10 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * read) instead of streaming it; 0 = it streams it from the portal's block.
  * "walk_sort": 1 (default) = batches of >= 262144 pairs on trees with the sparse table and both lineage
  * tables run the tile-sorted walk kernel (a wave's 64 pairs have streams of similar length); 0 = k_walk.
+ * "prefer_walk_sorted": 1 = distance batches of >= 524288 pairs on a canopy-strategy tree that also has the walk
+ * family's tables (deep trees) go to the tile-sorted walk kernel; 0 = they stay with the canopy kernels.  Like
+ * "tile_sort" and "pairs_per_lane" its default is set when the tree is created, on deep trees by timing the candidate
+ * kernels on a sample of random leaf pairs (st_tree_info.tuned; SUCHTREE_AMD_AUTOTUNE=0: by a fixed rule).
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
  * "sort_tile": tile of both tile-sorted kernels in units of 1024 pairs: 1, 2 or 4 (taken when it fits LDS and the
  * kernel's form has that tile), 0 (default) = the largest tile LDS admits, cut finer for batches that would

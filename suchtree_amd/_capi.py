@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsuchtree_hip.so")
 ST_OK, ST_ERR_ARG, ST_ERR_HIP, ST_ERR_BOUNDS, ST_ERR_NOMEM, ST_ERR_TREE = 0, 1, 2, 3, 4, 5
 STRATEGY = {"auto": 0, "walk": 1, "canopy": 2}
 STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
+BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 2: "canopy_scalar", 3: "canopy_sorted", 4: "walk_sorted"}      # ST_KERNEL_*
 
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
@@ -44,11 +45,14 @@ class TreeInfo(ctypes.Structure):
         ("n_devices", ctypes.c_int32),
         ("device_bytes", ctypes.c_int64),
         ("lineage_entries", ctypes.c_int64),
+        ("big_batch_kernel", ctypes.c_int32),
+        ("tuned", ctypes.c_int32),
     ]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_}
         d["strategy"] = STRATEGY_NAME.get(d["strategy"], str(d["strategy"]))
+        d["big_batch_kernel"] = BIG_BATCH_KERNEL.get(d["big_batch_kernel"], str(d["big_batch_kernel"]))
         return d
 
 

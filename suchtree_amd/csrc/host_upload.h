@@ -174,7 +174,6 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     t->n_nodes = T.n;
     t->n_leaves = T.n_leaves;
-    if (B.deep) { t->pairs_per_lane = 0; t->tile_sort = 1; }
     int64_t bytes = 0;
     int rc = upload(&t->d_nodes, T.nodes, &bytes);
     if (rc == ST_OK) rc = upload(&t->d_depth, T.depth, &bytes);
@@ -273,6 +272,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->info.n_devices = 1;
     t->info.device_bytes = bytes;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
+    if (B.deep) tune_deep_tree(t, T);      // (host_tune.h: the kernel of large batches, by timing the candidates)
     owner.t = nullptr;
     *out = t;
     return ST_OK;

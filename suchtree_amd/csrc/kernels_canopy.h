@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
                                                              DistSink out_d,
                                                              int *__restrict__ out_m, Fault *fault)
 {
-    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "register-resident chains only");
+    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15 || ((CAP == 31 || CAP == 63) && PPL == 1), "register-resident chains only");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const unsigned long long *can = reinterpret_cast<const unsigned long long *>(lds_raw);
     const uint16_t *BLK = reinterpret_cast<const uint16_t *>(lds_raw + (size_t)((P.canopy_nodes + 1) / 2) * 16);

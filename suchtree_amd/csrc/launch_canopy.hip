@@ -49,9 +49,15 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
 {
     // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
     if (t->tile_sort && sorted_q(t) > 0)
-        return launch_canopy_sorted<CAP>(t, P, src, n, out_d, out_m, fault, stream);
+        return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+    } else if constexpr (CAP == 31 || CAP == 63) {
+        // 256- and 512-byte records (large trees of random shape: 2^22 leaves, depth 57, understories of up to 31
+        // nodes; 1e6 leaves with some skew: up to 63): the predicated kernel with the chain in 31 / 63 registers,
+        // one pair per lane; pairs_per_lane = 0: the scalar kernel that reads the chain through a pointer
+        if (t->pairs_per_lane == 0) return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+        return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     } else {
         if (t->pairs_per_lane == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
         // two pairs per lane: a measured-equal variant kept selectable for explicit pair arrays only
@@ -111,6 +117,8 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
         case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream);
         case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, fault, stream);
         case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, fault, stream);
+        case 31: return launch_canopy_t<31>(t, P, src, n, out_d, out_m, fault, stream);
+        case 63: return launch_canopy_t<63>(t, P, src, n, out_d, out_m, fault, stream);
         default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, fault, stream);
     }
 }

@@ -85,19 +85,29 @@ static inline bool mrca_ranks_ready(const st_tree *t)
     return t->strategy == ST_STRATEGY_CANOPY && t->mrca_ranks && t->d_rec_r && t->d_rmq64;
 }
 
-// Deep-canopy trees whose canopy image leaves the tile-sorted canopy kernel only small tiles (nj.tree: 9111
-// canopy nodes = 146 KiB, 1024-pair tiles) are served faster by the tile-sorted WALK kernel once its crown
-// ladder exists: a crown of <= 5120 nodes, 4096-pair tiles (nj.tree, 1e7 pairs: 1.73e10 against 1.60e10
-// pairs/s; ml.tree keeps the canopy kernel: 2.15e10 against 1.73e10).  Batches of 524288 pairs and more (below,
-// the canopy kernel's 1024-pair tiles are the right size anyway: 262144 pairs 23.2 us either way).
+// Which kernel large distance batches of a deep tree get is decided when the tree is created (host_tune.h): the
+// candidates -- tile-sorted canopy kernel, predicated canopy kernel, tile-sorted walk kernel -- are timed on a
+// sample of random leaf pairs and the handle's defaults (tile_sort, pairs_per_lane, prefer_walk_sorted) follow the
+// fastest; nothing else separates them reliably (ml.tree: 2.2e10 / 5.7e9 / 1.7e10 pairs/s in that order, a 1e6-leaf
+// tree of depth 252: 5.2e9 / 1.1e10 / 6.8e9, a 1e5-leaf tree of depth 423: 3.8e9 / 5.7e9 / 1.1e10;
+// profiles/kernel_choice_r03.log).  Batches of 524288 pairs and more (below, the canopy kernels' finer tiles are the
+// right size anyway).
 static inline bool walk_sorted_ready(const st_tree *t);
 constexpr int64_t kWalkSortedMinPairs = 262144;
 static inline int64_t walk_sorted_min_pairs(const st_tree *t) { return t->walk_sort_min > 0 ? t->walk_sort_min : kWalkSortedMinPairs; }
 static inline bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
 {
-    if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || !want_dist || n < std::max<int64_t>(walk_sorted_min_pairs(t), 524288)) return false;
+    if (t->strategy != ST_STRATEGY_CANOPY || !t->prefer_walk_sorted || !want_dist || n < std::max<int64_t>(walk_sorted_min_pairs(t), 524288)) return false;
+    return t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
+}
+
+// The rule used when the candidates are not timed (SUCHTREE_AMD_AUTOTUNE=0): deep-canopy trees whose canopy image
+// leaves the tile-sorted canopy kernel only small tiles (nj.tree: 9111 canopy nodes = 146 KiB, 1024-pair tiles) go to
+// the tile-sorted walk kernel once its crown ladder exists (a crown of <= 5120 nodes, 4096-pair tiles).
+static inline bool walk_sorted_by_rule(const st_tree *t)
+{
     const int q = sorted_q(t);
-    return q > 0 && q < 4 && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
+    return t->strategy == ST_STRATEGY_CANOPY && t->tile_sort && q > 0 && q < 4 && t->d_crown_ladder && walk_sorted_ready(t);
 }
 
 // In lineage-sum mode the tile-sorted canopy kernel reads every pair once (key phase; shared-portal pairs, rare,

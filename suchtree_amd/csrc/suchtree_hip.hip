@@ -137,6 +137,7 @@ using namespace st;
 #include "host_tree.h"
 #include "host_launch.h"
 #include "host_path.h"
+#include "host_tune.h"
 #include "host_upload.h"
 
 extern "C" {
@@ -290,6 +291,7 @@ try {
     if (!t || !info) return fail(ST_ERR_ARG, "tree or info is NULL");
     *info = t->info;
     info->strategy = t->strategy;
+    info->big_batch_kernel = big_batch_kernel_of(t);      // (follows the handle's current options)
     return ST_OK;
 } ST_CATCH_ALL
 
@@ -347,6 +349,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "walk_ladder") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_ladder must be 0 or 1");
         t->walk_ladder = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "prefer_walk_sorted") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "prefer_walk_sorted must be 0 or 1");
+        t->prefer_walk_sorted = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "sort_tile") == 0) {

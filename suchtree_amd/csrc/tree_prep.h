@@ -233,5 +233,6 @@ ST_HD int64_t lineage_block(int32_t depth) { return ((int64_t)depth + 1 + 15) & 
 // max_canopy_nodes <= 0: the LDS limit (kMaxCanopyNodes); smaller values trade a longer
 // understory (bigger records) for a smaller LDS image, i.e. more workgroups per CU.
 bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T, int max_canopy_nodes = 0);
+constexpr int kShallowCanopyDepth = 100;   // canopies deeper than this (edges) are "deep": tile-sorted kernels, tuned at creation
 
 }  // namespace st

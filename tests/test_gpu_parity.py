@@ -617,6 +617,58 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
         dev.close()
 
 
+def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch):
+    """Deep trees: the handle times its candidate kernels when it is created and makes the fastest its default
+    (st_tree_info.tuned / big_batch_kernel); every candidate, forced by options, gives the same bits.  512-byte
+    records (63-slot chains in registers in the predicated kernel), a batch large enough for every kernel."""
+    import torch
+    rng = np.random.default_rng(5)
+    parent, dist = _random_shape_tree(rng, 54_000, 0.95)
+    n = len(parent)
+    O = OracleTree(parent, dist)
+    pairs = rng.integers(0, n, (600_000, 2))
+    a = rng.integers(0, n - 70, 40_000)
+    allp = np.concatenate([pairs, np.stack([a, a + rng.integers(0, 70, a.size)], 1), np.stack([a[:2000], a[:2000]], 1)]).astype(np.int64)
+    cores = len(os.sched_getaffinity(0))
+    want_d, want_m = O.distances_mt(allp, cores), O.mrca_bulk(allp)
+    t = torch.from_numpy(allp).cuda()
+    out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+    out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+
+    def run(dev, what):
+        out_d.fill_(-1.0)
+        out_m.fill_(-1)
+        dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+        dev.fault_check()
+        assert_bits_equal(out_d.cpu().numpy(), want_d, what)
+        assert np.array_equal(out_m.cpu().numpy(), want_m), what
+
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert info["strategy"] == "canopy" and info["record_bytes"] == 512 and info["lineage_entries"] > 0, info
+    assert info["tuned"] == 1 and info["big_batch_kernel"] in ("canopy", "canopy_sorted", "walk_sorted"), info
+    run(dev, "default (%s)" % info["big_batch_kernel"])
+    seen = set()
+    for sort, ppl, walk in ((1, 0, 0), (0, 1, 0), (0, 0, 0), (1, 0, 1)):
+        dev.set_option("tile_sort", sort)
+        dev.set_option("pairs_per_lane", ppl)
+        dev.set_option("prefer_walk_sorted", walk)
+        kernel = dev.info()["big_batch_kernel"]
+        seen.add(kernel)
+        run(dev, kernel)
+        d, m = dev.distances_host(allp[:300_000], True, True)
+        assert_bits_equal(d, want_d[:300_000], "host path, " + kernel)
+        assert np.array_equal(m, want_m[:300_000])
+    assert seen == {"canopy_sorted", "canopy", "canopy_scalar", "walk_sorted"}, seen
+    dev.close()
+    monkeypatch.setenv("SUCHTREE_AMD_AUTOTUNE", "0")
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert info["tuned"] == 0 and info["big_batch_kernel"] in ("canopy", "walk_sorted"), info      # (the fixed rule)
+    run(dev, "rule (%s)" % info["big_batch_kernel"])
+    dev.close()
+
+
 def test_mrca_only_requests_from_the_rank_table(ml_arrays):
     """MRCA ids without distances on trees with in-order ids: k_mrca_ranks (rank of either portal
     + sparse table; shared-portal pairs through the understory records).  Shallow and deep tree,
