@@ -261,12 +261,22 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
                 Db[j][0] = __uint_as_float(q.y);
             } else {
                 uint32_t w[CAP + 1];
+                // the first 128-byte line of the chain at once; of a 63-slot chain's second line only the 16-byte
+                // chunks that hold slots in use, once the length is there (mean understory of a 1e6-leaf tree
+                // with 512-byte records: 34 nodes; 43 % of its leaves need no second line, the rest a part of it)
+                constexpr int kChunks = (CAP + 1) / 4, kEager = kChunks < 8 ? kChunks : 8;
 #pragma unroll
-                for (int q = 0; q < (CAP + 1) / 4; q++) {
+                for (int q = 0; q < kEager; q++) {
                     const uint4 x = reinterpret_cast<const uint4 *>(rb)[q];
                     w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
                 }
                 wb = w[0];
+#pragma unroll
+                for (int q = kEager; q < kChunks; q++) {
+                    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                    if ((uint32_t)(4 * q) <= (wb >> 16)) x = reinterpret_cast<const uint4 *>(rb)[q];      // slots 4q-1 .. 4q+2
+                    w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+                }
 #pragma unroll
                 for (int q = 0; q < CAP; q++) Db[j][q] = __uint_as_float(w[q + 1]);
             }
