@@ -342,7 +342,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
         for (int j = 0; j < PPL; j++) {
             if (pa[j] == pb[j]) {
                 const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
-                const PairResult r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
+                PairResult r;
+                if constexpr (CAP <= 15) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
+                else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
                 s[j] = r.dist;
                 m[j] = r.mrca;
             }

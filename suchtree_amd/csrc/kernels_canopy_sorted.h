@@ -224,8 +224,14 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                     } else {     // shared portal
                         long long a, b;
                         src.load(base + j, a, b);
-                        const PairResult r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
-                                                                           record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
+                        PairResult r;
+                        if constexpr (CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15) {      // chains in registers, no dependent loads
+                            const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
+                            r = pair_same_portal_regs<CAP>(P.canopy_id, R, record_slot(a, parity, P.n_leaves), record_slot(b, parity, P.n_leaves));
+                        } else {
+                            r = canopy_pair_scalar<CAP, true>(P, lds_raw, record_slot(a, parity, P.n_leaves),
+                                                              record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
+                        }
                         dist = r.dist;
                         if (out_m) out_m[base + j] = r.mrca;
                     }

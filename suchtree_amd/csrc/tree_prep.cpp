@@ -277,11 +277,13 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
                 uint32_t pnb = pw0 >> 16;
                 nb = pnb + 1;
                 std::memcpy(D + 1, prb + 4, 4 * (size_t)pnb);
-                std::memcpy(I + 1, pri + 4, 4 * (size_t)pnb);
+                // ids sit at the END of their slots (slot cap - 1 = the portal's child): the parent's ids stay where
+                // they are, the node's own id goes in front of them
+                std::memcpy(I + (cap - (int32_t)pnb), pri + 4 + 4 * (size_t)(cap - (int32_t)pnb), 4 * (size_t)pnb);
             }
             if ((int32_t)nb > cap) return false;   // cannot happen: nb <= H <= cap
             D[0] = distance[x];
-            I[0] = x;
+            I[cap - (int32_t)nb] = x;
             w0 = portal | (nb << 16);
             // the reference's accumulator: d = 0; d += dist[n] up the lineage (pyx:934-938)
             volatile float acc = 0.0f;

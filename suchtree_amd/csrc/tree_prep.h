@@ -70,7 +70,9 @@ static_assert(sizeof(LadderEntry) == 16, "LadderEntry must be 16 bytes");
 //   rec_a  8 bytes  : word0 = portal (canopy index, bits 0..15) | chain length << 16,
 //                     pbot (float32 running sum of the chain from 0)
 //   rec_b  R/2 bytes: word0 again, then cap float32 branch lengths, the node's own first
-//   rec_i  R/2 bytes: pbot again, then the cap int32 node ids of the same chain
+//   rec_i  R/2 bytes: pbot again, then the int32 node ids of the same chain in the LAST slots of the cap
+//                     (slot cap - 1 = the portal's child, slot cap - nb = the node itself): two chains under one
+//                     portal are compared slot by slot from the end, with indices known at compile time
 // A pair reads rec_a[a] (8 B of a table small enough to be partly L2 resident) and
 // rec_b[b]; rec_i is only needed when both lineages share a portal.  R ("record_bytes")
 // is kept as the name of the geometry: rec_b and rec_i have stride R/2.

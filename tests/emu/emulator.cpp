@@ -204,8 +204,22 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                     return 4;
                 }
             }
-            else
+            else {
                 r = pair_canopy_same_portal(T.canopy_id.data(), A, B);
+                // the register form of the predicated kernel (chains of up to 15 slots) must agree bit for bit
+                PairResult q = r;
+                switch (T.record_cap) {
+                    case 1: q = pair_same_portal_regs<1>(T.canopy_id.data(), R, sa, sb); break;
+                    case 3: q = pair_same_portal_regs<3>(T.canopy_id.data(), R, sa, sb); break;
+                    case 7: q = pair_same_portal_regs<7>(T.canopy_id.data(), R, sa, sb); break;
+                    case 15: q = pair_same_portal_regs<15>(T.canopy_id.data(), R, sa, sb); break;
+                    default: break;
+                }
+                if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
+                    g_err = "same portal: the register form disagrees with the loop form";
+                    return 18;
+                }
+            }
         }
         if (out_d) out_d[i] = (double)r.dist;
         if (out_m) out_m[i] = r.mrca;
