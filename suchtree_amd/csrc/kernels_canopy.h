@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             if (pa[j] == pb[j]) {
                 const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
                 PairResult r;
-                if constexpr (CAP <= 15) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
+                if constexpr (CAP <= 31) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
                 else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
                 s[j] = r.dist;
                 m[j] = r.mrca;
@@ -364,7 +364,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 // below the same portal it is a canopy node -- two 4-byte reads (rank of either portal) and two
 // entries of the 64-bit sparse table (depth << 32 | node id).  No LDS, no understory records:
 // 4.8e10 ids/s on ml.tree where the canopy kernels' MRCA-only mode did 3.0e10.
-template <typename Src>
+// CAP: chain slots of the tree's records when the shared-portal case compares them in registers (1 ... 31), 0: by
+// the loop (longer chains).
+template <int CAP, typename Src>
 __global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, long long n, int *__restrict__ out_m, Fault *fault)
 {
     const bool parity = P.parity != 0;
@@ -382,8 +384,9 @@ __global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, lon
         if (ra != rb) {
             out_m[i] = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
         } else {      // shared portal: the MRCA is the portal or lies in the understory
-            const RecTables R{P.rec_a, P.rec_b, P.rec_i, P.rec_bytes / 2};
-            out_m[i] = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
+            const RecTables R{P.rec_a, P.rec_b, P.rec_i, CAP > 0 ? 4 * (CAP + 1) : P.rec_bytes / 2};
+            if constexpr (CAP > 0) out_m[i] = mrca_same_portal_regs<CAP>(P.canopy_id, R, sa, sb);
+            else out_m[i] = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
         }
     }
 }

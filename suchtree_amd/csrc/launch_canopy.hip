@@ -104,7 +104,14 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
     P.parity = t->parity;
     if (!out_d.any() && out_m && P.rec_r && P.rmq64 && t->mrca_ranks) {
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)t->n_cu * 8));
-        hipLaunchKernelGGL(k_mrca_ranks<Src>, dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault);
+        switch (t->rec_cap) {      // (chains of up to 31 slots: the shared-portal case compares them in registers)
+            case 1: hipLaunchKernelGGL((k_mrca_ranks<1, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
+            case 3: hipLaunchKernelGGL((k_mrca_ranks<3, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
+            case 7: hipLaunchKernelGGL((k_mrca_ranks<7, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
+            case 15: hipLaunchKernelGGL((k_mrca_ranks<15, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
+            case 31: hipLaunchKernelGGL((k_mrca_ranks<31, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
+            default: hipLaunchKernelGGL((k_mrca_ranks<0, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
+        }
         return hipGetLastError();
     }
     // 31-slot chains are register resident only in the tile-sorted kernel when it runs one

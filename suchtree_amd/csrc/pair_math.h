@@ -524,25 +524,54 @@ ST_HD float word_as_float(uint32_t u)
     return c.f;
 }
 
+// Common part: length of the common portal-end run of two id chains (ids in words 1..CAP, slot CAP - 1 - k = the
+// k-th node below the portal) and the last id of that run.
+template <int CAP>
+ST_HD uint32_t common_chain_run(const uint32_t (&IA)[CAP + 1], const uint32_t (&IB)[CAP + 1], uint32_t na, uint32_t nb, uint32_t &last)
+{
+    // first slot from the portal end at which the chains differ (selects with short-lived conditions: a chain of
+    // boolean flags carried through the loop kept a 64-bit lane mask alive per step and spilled scalar registers)
+    uint32_t first = (uint32_t)CAP;
+#pragma unroll
+    for (int k = CAP - 1; k >= 0; k--) first = IA[CAP - k] != IB[CAP - k] ? (uint32_t)k : first;
+    const uint32_t shorter = na < nb ? na : nb;
+    const uint32_t c = first < shorter ? first : shorter;
+    last = 0;
+#pragma unroll
+    for (int k = 0; k < CAP; k++) last = c == (uint32_t)(k + 1) ? IA[CAP - k] : last;
+    return c;
+}
+
 template <int CAP>
 ST_HD PairResult pair_same_portal_regs(const int32_t *__restrict__ canopy_id, const RecTables &R, int64_t sa, int64_t sb)
 {
-    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15, "chains in registers");
-    uint32_t IA[CAP + 1], IB[CAP + 1], DA[CAP + 1], DB[CAP + 1];
-    load_half_record<CAP>(R.i + sa * (int64_t)R.half, IA);
-    load_half_record<CAP>(R.i + sb * (int64_t)R.half, IB);
-    load_half_record<CAP>(R.b + sa * (int64_t)R.half, DA);
-    load_half_record<CAP>(R.b + sb * (int64_t)R.half, DB);
-    const uint32_t na = DA[0] >> 16, nb = DB[0] >> 16;
-    // ids: word 1 + slot; slot CAP - 1 - k = the k-th node below the portal
-    uint32_t c = 0, last = 0;
-    bool run = true;
-#pragma unroll
-    for (int k = 0; k < CAP; k++) {
-        const bool eq = run && (uint32_t)k < na && (uint32_t)k < nb && IA[CAP - k] == IB[CAP - k];
-        c += eq ? 1u : 0u;
-        last = eq ? IA[CAP - k] : last;
-        run = eq;
+    static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15 || CAP == 31, "chains in registers");
+    uint32_t c, last, na, nb, portal;
+    uint32_t DA[CAP + 1], DB[CAP + 1];
+    if (CAP <= 15) {      // everything in one round trip
+        uint32_t IA[CAP + 1], IB[CAP + 1];
+        load_half_record<CAP>(R.i + sa * (int64_t)R.half, IA);
+        load_half_record<CAP>(R.i + sb * (int64_t)R.half, IB);
+        load_half_record<CAP>(R.b + sa * (int64_t)R.half, DA);
+        load_half_record<CAP>(R.b + sb * (int64_t)R.half, DB);
+        na = DA[0] >> 16;
+        nb = DB[0] >> 16;
+        portal = DA[0] & 0xFFFFu;
+        c = common_chain_run<CAP>(IA, IB, na, nb, last);
+    } else {              // 31 slots: the ids first, the lengths after them (64 registers at a time, not 128)
+        const uint32_t wa = *reinterpret_cast<const uint32_t *>(R.a + sa * 8), wb = *reinterpret_cast<const uint32_t *>(R.a + sb * 8);
+        na = wa >> 16;
+        nb = wb >> 16;
+        portal = wa & 0xFFFFu;
+        {
+            uint32_t IA[CAP + 1], IB[CAP + 1];
+            load_half_record<CAP>(R.i + sa * (int64_t)R.half, IA);
+            load_half_record<CAP>(R.i + sb * (int64_t)R.half, IB);
+            c = common_chain_run<CAP>(IA, IB, na, nb, last);
+        }
+        asm volatile("" ::: "memory");      // (keeps the second pair of loads behind the comparison)
+        load_half_record<CAP>(R.b + sa * (int64_t)R.half, DA);
+        load_half_record<CAP>(R.b + sb * (int64_t)R.half, DB);
     }
     const uint32_t ia = na - c, ib = nb - c;
     float s = 0.0f;
@@ -558,8 +587,21 @@ ST_HD PairResult pair_same_portal_regs(const int32_t *__restrict__ canopy_id, co
     }
     PairResult r;
     r.dist = s;
-    r.mrca = c ? (int32_t)last : canopy_id[DA[0] & 0xFFFFu];
+    r.mrca = c ? (int32_t)last : canopy_id[portal];
     return r;
+}
+
+// The MRCA id alone (k_mrca_ranks): the two id chains and the two 8-byte a entries.
+template <int CAP>
+ST_HD int32_t mrca_same_portal_regs(const int32_t *__restrict__ canopy_id, const RecTables &R, int64_t sa, int64_t sb)
+{
+    uint32_t IA[CAP + 1], IB[CAP + 1];
+    load_half_record<CAP>(R.i + sa * (int64_t)R.half, IA);
+    load_half_record<CAP>(R.i + sb * (int64_t)R.half, IB);
+    const uint32_t wa = *reinterpret_cast<const uint32_t *>(R.a + sa * 8), wb = *reinterpret_cast<const uint32_t *>(R.a + sb * 8);
+    uint32_t last;
+    const uint32_t c = common_chain_run<CAP>(IA, IB, wa >> 16, wb >> 16, last);
+    return c ? (int32_t)last : canopy_id[wa & 0xFFFFu];
 }
 
 }  // namespace st

@@ -213,7 +213,21 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                     case 3: q = pair_same_portal_regs<3>(T.canopy_id.data(), R, sa, sb); break;
                     case 7: q = pair_same_portal_regs<7>(T.canopy_id.data(), R, sa, sb); break;
                     case 15: q = pair_same_portal_regs<15>(T.canopy_id.data(), R, sa, sb); break;
+                    case 31: q = pair_same_portal_regs<31>(T.canopy_id.data(), R, sa, sb); break;
                     default: break;
+                }
+                int32_t qm = r.mrca;
+                switch (T.record_cap) {
+                    case 1: qm = mrca_same_portal_regs<1>(T.canopy_id.data(), R, sa, sb); break;
+                    case 3: qm = mrca_same_portal_regs<3>(T.canopy_id.data(), R, sa, sb); break;
+                    case 7: qm = mrca_same_portal_regs<7>(T.canopy_id.data(), R, sa, sb); break;
+                    case 15: qm = mrca_same_portal_regs<15>(T.canopy_id.data(), R, sa, sb); break;
+                    case 31: qm = mrca_same_portal_regs<31>(T.canopy_id.data(), R, sa, sb); break;
+                    default: break;
+                }
+                if (qm != r.mrca) {
+                    g_err = "same portal: the register form of the MRCA id disagrees with the loop form";
+                    return 18;
                 }
                 if (q.mrca != r.mrca || std::memcmp(&q.dist, &r.dist, 4) != 0) {
                     g_err = "same portal: the register form disagrees with the loop form";
