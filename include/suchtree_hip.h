@@ -234,10 +234,11 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
 /* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the canopy
- * kernel keeps in flight: 1 (default) or 2 (explicit pair arrays only); 0 = scalar, branchy
- * form (default for deep canopies).
- * "tile_sort": 1 (default for deep canopies) = every workgroup sorts its tile of pairs by
- * expected climb length so that a wave's lanes finish together; 0 = pairs in input order.
+ * kernel keeps in flight: 1 (default) or 2 (explicit pair arrays only, chains of up to 15 slots); 0 = scalar,
+ * branchy form (chains read through a pointer).
+ * "tile_sort": 1 = every workgroup sorts its tile of pairs by expected climb length so that a wave's lanes
+ * finish together (deep canopies: the default where it measured fastest when the tree was created, see
+ * "prefer_walk_sorted" below); 0 = pairs in input order.
  * "tree_rmq": 1 (default) = the walk family takes the meeting node from the whole-tree sparse table
  * where the tree has one (in-order ids; up to 64 MB, more -- within SUCHTREE_AMD_WALK_TABLE_MB -- when
  * the canopy family is not available); 0 = it searches it by climbing both lineages.
