@@ -9,6 +9,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export SUCHTREE_AMD_AUTOTUNE=0      # (the timing launches of host_tune.h would count as launches of the profiled kernel)
 T=${PMC_TIMEOUT:-240}
 timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/scripts/tune_gpu.py --pairs $PAIRS --rounds 4 "$@" > $OUT/trace.log 2>&1
 echo "trace rc=$?"
