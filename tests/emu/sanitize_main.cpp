@@ -74,6 +74,20 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
             std::printf("mismatch leaves=%d skew=%g pair (%lld,%lld)\n", n_leaves, skew, (long long)a, (long long)b);
             return 3;
         }
+        if (A.portal == B.portal) {      // the register forms of the shared-portal case read whole half records
+            const int64_t sa = record_slot(a, T.parity_layout, T.n_leaves), sb = record_slot(b, T.parity_layout, T.n_leaves);
+            PairResult q = c;
+            int32_t qm = c.mrca;
+            switch (T.record_cap) {
+                case 1: q = pair_same_portal_regs<1>(T.canopy_id.data(), R, sa, sb); qm = mrca_same_portal_regs<1>(T.canopy_id.data(), R, sa, sb); break;
+                case 3: q = pair_same_portal_regs<3>(T.canopy_id.data(), R, sa, sb); qm = mrca_same_portal_regs<3>(T.canopy_id.data(), R, sa, sb); break;
+                case 7: q = pair_same_portal_regs<7>(T.canopy_id.data(), R, sa, sb); qm = mrca_same_portal_regs<7>(T.canopy_id.data(), R, sa, sb); break;
+                case 15: q = pair_same_portal_regs<15>(T.canopy_id.data(), R, sa, sb); qm = mrca_same_portal_regs<15>(T.canopy_id.data(), R, sa, sb); break;
+                case 31: q = pair_same_portal_regs<31>(T.canopy_id.data(), R, sa, sb); qm = mrca_same_portal_regs<31>(T.canopy_id.data(), R, sa, sb); break;
+                default: break;
+            }
+            if (q.mrca != w.mrca || qm != w.mrca || std::memcmp(&q.dist, &w.dist, 4) != 0) return 7;
+        }
         if (lineage) {      // the walk with a's side from the lineage sums, and the deep kernel's reads
             if (!crown) return 6;
             LineageView lin;      // every table of the walk family at once: sums, streamed lengths, shared blocks, crown table
