@@ -4,13 +4,13 @@
 // A deep tree (canopy more than kDeepCanopyDepth edges deep) has up to three kernels that produce the same bits:
 // the tile-sorted canopy kernel, the predicated canopy kernel and the tile-sorted walk kernel.  Which one is fastest
 // depends on the shape of the tree in ways no single statistic captured (launch_policy.h has the numbers), and the
-// spread is 2-4x, so the handle times them once on a sample of random leaf pairs -- about 2 ms next to the 0.1-1 s
+// spread is 2-4x, so the handle times them once on a sample of 2^22 random leaf pairs -- some 30 ms next to the 0.2-2 s
 // the tables of such a tree take to build -- and sets its defaults (tile_sort, pairs_per_lane, prefer_walk_sorted)
 // to the fastest.  st_tree_set_option / st_tree_set_strategy still override them.  SUCHTREE_AMD_AUTOTUNE=0: the
 // fixed rule instead.  Never an error: if anything here fails the rule's defaults stay.
 #pragma once
 
-constexpr int64_t kTunePairs = (int64_t)1 << 20;
+constexpr int64_t kTunePairs = (int64_t)1 << 22;      // (large enough for every candidate's largest tiles on every CU: with 2^20 a 13 % gap at 2e7 pairs went unseen)
 
 // What the handle's current settings select for a large batch with distances.
 static int big_batch_kernel_of(const st_tree *t)

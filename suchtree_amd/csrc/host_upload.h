@@ -46,6 +46,26 @@ static int crown_ladder_nodes(bool has_canopy)
     return std::max(0, std::min(nodes, 8704));
 }
 
+// The walk family's tables with offsets by node id: the whole-tree sparse table beyond prepare_basic's 64 MB -- the
+// meeting node in two reads instead of a lock-step climb of both lineages matters most on large, deep trees -- and
+// the lineage tables (a's side in one read, b's side as a stream), all within walk_table_budget() and of at most
+// kLineageEntriesPerNode table entries per node: a 30,000-leaf caterpillar (mean depth 15,000) would otherwise get
+// 7 GB of lineage tables for 2 MB of tree; it climbs instead.  For trees that only the walk family serves (canopy
+// refused, or the caller asked for the walk family) and for deep canopy trees whose lineage tables are too large
+// for the 28-bit offsets of the canopy family's form.
+static void build_walk_only_tables(BuiltTables &B, int64_t n_nodes, bool has_canopy)
+{
+    int64_t budget = walk_table_budget();
+    const int64_t by_size = (int64_t)kLineageEntriesPerNode * n_nodes;
+    if (budget > 0 && (int64_t)B.T.tree_rmq.size() == 0) (void)build_tree_rmq(B.T, std::min<int64_t>(budget, kMaxTreeRmqBytesWalkOnly));
+    if (budget <= 0) return;
+    budget -= (int64_t)B.T.tree_rmq.size() * 8;
+    // sums + lens when both fit, else the sums alone
+    if (!prepare_walk_lineage(B.T, std::min<int64_t>({budget / 8, kMaxWalkLineageEntries, by_size}), true))
+        (void)prepare_walk_lineage(B.T, std::min<int64_t>({budget / 4, kMaxWalkLineageEntries, by_size}), false);
+    if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(has_canopy));
+}
+
 static int build_tables_impl(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
 {
     std::string err;
@@ -72,7 +92,12 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
                 // a's side of every pair from one read (tree_prep.h: lineage sums), b's side of the walk
                 // family as a stream (lineage lengths); 4 bytes per node and level each, so only while
                 // the table stays below kMaxLineageEntries
-                if (prepare_lineage_sums(B.T, kMaxLineageEntries)) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(true));
+                // (tables beyond that: the walk family's own form, offsets by node id -- the walk kernels then serve this
+                // tree as they serve trees without a canopy; the tile-sorted canopy kernel goes without lineage sums)
+                int64_t max_entries = kMaxLineageEntries;
+                if (const char *env = std::getenv("SUCHTREE_AMD_LINEAGE_MAX_ENTRIES")) max_entries = std::min<int64_t>(max_entries, std::max<int64_t>(0, std::atoll(env)));   // tests: force the other form
+                if (prepare_lineage_sums(B.T, max_entries)) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(true));
+                else build_walk_only_tables(B, n_nodes, true);
             }
         }
     }
@@ -81,25 +106,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
     if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
     // four-byte a side for the predicated kernel (shallow canopies): 32 KiB of LDS are left beside a full canopy image
     if (B.canopy_ok && !B.deep && B.T.record_cap <= 15) (void)prepare_leaf_blocks(B.T, 8192);
-    if (!B.canopy_ok) {
-        // a tree that only the walk family serves (canopy refused, or asked for) gets the whole-tree
-        // sparse table beyond prepare_basic's 64 MB -- the meeting node in two reads instead of a
-        // lock-step climb of both lineages matters most exactly there (large, deep trees) -- and the
-        // lineage tables with offsets by node id (a's side in one read, b's side as a stream), all
-        // within walk_table_budget()
-        // ... and of at most kLineageEntriesPerNode table entries per node: a 30,000-leaf caterpillar (mean depth
-        // 15,000) would otherwise get 7 GB of lineage tables for 2 MB of tree; it climbs instead
-        int64_t budget = walk_table_budget();
-        const int64_t by_size = (int64_t)kLineageEntriesPerNode * n_nodes;
-        if (B.T.tree_rmq.empty() && budget > 0) (void)build_tree_rmq(B.T, std::min<int64_t>(budget, kMaxTreeRmqBytesWalkOnly));
-        if (budget > 0) {
-            budget -= (int64_t)B.T.tree_rmq.size() * 8;
-            // sums + lens when both fit, else the sums alone
-            if (!prepare_walk_lineage(B.T, std::min<int64_t>({budget / 8, kMaxWalkLineageEntries, by_size}), true))
-                (void)prepare_walk_lineage(B.T, std::min<int64_t>({budget / 4, kMaxWalkLineageEntries, by_size}), false);
-            if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(false));
-        }
-    }
+    if (!B.canopy_ok) build_walk_only_tables(B, n_nodes, false);
     return ST_OK;
 }
 
@@ -241,7 +248,9 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
             rc = upload(&t->d_rec_r, ranks, &bytes);
             if (rc == ST_OK) rc = upload(&t->d_rmq64, T.canopy_rmq64, &bytes);
         }
-        if (rc == ST_OK && t->d_rmq && t->d_rmq64 && !T.lineage_sum.empty()) {
+        if (rc == ST_OK && T.rec_p.empty() && !T.lineage_sum.empty()) {
+            upload_walk_lineage();      // (lineage tables in the walk family's own form only: build_walk_only_tables)
+        } else if (rc == ST_OK && t->d_rmq && t->d_rmq64 && !T.lineage_sum.empty()) {
             if (upload_optional(&t->d_rec_p, T.rec_p, &bytes)) {
                 if (!upload_optional(&t->d_lineage, T.lineage_sum, &bytes)) {
                     (void)hipFree(t->d_rec_p);

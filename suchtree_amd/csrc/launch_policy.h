@@ -28,7 +28,7 @@ static inline SortedShape sorted_shape(const st_tree *t)
 {
     const size_t image = ladder_image_bytes(t->canopy_nodes);
     const bool table = t->d_rmq != nullptr;
-    const bool lineage = table && t->d_lineage != nullptr && t->lineage_sums;
+    const bool lineage = table && t->d_lineage != nullptr && t->d_rec_p != nullptr && t->lineage_sums;      // (rec_p: the canopy family's offsets into the table)
     struct Mode { bool rmq, sums; };
     // lineage sums first (they are worth a smaller tile), then the sparse table alone, then
     // the lock-step search; within a mode the largest tile that fits, two workgroups per CU if possible
@@ -77,7 +77,7 @@ constexpr int64_t kSortedMinPairs = 131072;
 
 static inline int64_t canopy_min_pairs(const st_tree *t)
 {
-    return t->tile_sort && t->d_lineage && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
+    return t->tile_sort && t->d_lineage && t->d_rec_p && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
 }
 
 static inline bool mrca_ranks_ready(const st_tree *t)

@@ -669,6 +669,52 @@ def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch):
     dev.close()
 
 
+def test_deep_canopy_tree_with_walk_form_lineage_tables(ml_arrays, monkeypatch):
+    """A deep canopy tree whose lineage tables are too large for the canopy family's 28-bit offsets gets them in the
+    walk family's form instead (offsets by node id; forced here on ml.tree by SUCHTREE_AMD_LINEAGE_MAX_ENTRIES): the
+    walk kernels serve it as they serve trees without a canopy, the tile-sorted canopy kernel runs without lineage
+    sums.  Every kernel against the oracle, device pairs and the host path."""
+    import torch
+    monkeypatch.setenv("SUCHTREE_AMD_LINEAGE_MAX_ENTRIES", "1000")
+    parent, dist, leaf_ids = ml_arrays
+    n = len(parent)
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert info["strategy"] == "canopy" and info["lineage_entries"] > n, info
+    O = OracleTree(parent, dist)
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, n - 30, 30_000)
+    allp = np.concatenate([rng.integers(0, n, (560_000, 2)), np.stack([a, a + rng.integers(0, 30, a.size)], 1)]).astype(np.int64)
+    cores = len(os.sched_getaffinity(0))
+    want_d, want_m = O.distances_mt(allp, cores), O.mrca_bulk(allp)
+    t = torch.from_numpy(allp).cuda()
+    out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+    out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+    seen = set()
+    for sort, ppl, walk in ((1, 0, 0), (0, 1, 0), (1, 0, 1)):
+        dev.set_option("tile_sort", sort)
+        dev.set_option("pairs_per_lane", ppl)
+        dev.set_option("prefer_walk_sorted", walk)
+        kernel = dev.info()["big_batch_kernel"]
+        seen.add(kernel)
+        for n_dev in (len(allp), 140_000, 20_000, 3_000):      # sorted kernels, mid-sized batches, k_walk, mailbox size
+            out_d.fill_(-1.0)
+            dev.distances_device(t.data_ptr(), n_dev, out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d[:n_dev].cpu().numpy(), want_d[:n_dev], "%s n=%d" % (kernel, n_dev))
+            assert np.array_equal(out_m[:n_dev].cpu().numpy(), want_m[:n_dev]), kernel
+        d, m = dev.distances_host(allp[:300_000], True, True)
+        assert_bits_equal(d, want_d[:300_000], "host path, " + kernel)
+        assert np.array_equal(m, want_m[:300_000])
+        d, m = dev.distances_host(allp[:2_000], True, True)
+        assert_bits_equal(d, want_d[:2_000], "mailbox, " + kernel)
+    assert seen == {"canopy_sorted", "canopy", "walk_sorted"}, seen
+    dev.set_strategy("walk")
+    dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+    assert_bits_equal(out_d.cpu().numpy(), want_d, "walk family")
+    dev.close()
+
+
 def test_mrca_only_requests_from_the_rank_table(ml_arrays):
     """MRCA ids without distances on trees with in-order ids: k_mrca_ranks (rank of either portal
     + sparse table; shared-portal pairs through the understory records).  Shallow and deep tree,
