@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--levels", type=int, default=20)
-    ap.add_argument("--tree", default="balanced", choices=["balanced", "ml", "nj", "random", "caterpillar", "bigdeep"])
+    ap.add_argument("--tree", default="balanced", help="balanced | ml | nj | random | caterpillar | bigdeep | shape:<leaves>:<skew>")
     ap.add_argument("--pairs", type=int, default=100_000_000)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="name=v1,v2,...")
@@ -38,6 +38,11 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from test_gpu_parity import _random_shape_tree
         parent, dist = _random_shape_tree(np.random.default_rng(5), 1_000_000, 0.9)
+        leaf_ids = np.arange(0, len(parent), 2)
+    elif args.tree.startswith("shape:"):   # tests/test_gpu_parity.py::_random_shape_tree, seed 5 (profiles/kernel_choice_r03.log)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_gpu_parity import _random_shape_tree
+        parent, dist = _random_shape_tree(np.random.default_rng(5), int(args.tree.split(":")[1]), float(args.tree.split(":")[2]))
         leaf_ids = np.arange(0, len(parent), 2)
     elif args.tree == "random":
         parent, dist = synth.random_binary_tree(1 << args.levels, seed=1)
