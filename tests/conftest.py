@@ -80,6 +80,23 @@ def emulator():
     return Emulator()
 
 
+def oracle_both(parent, dist, pairs, threads=None):
+    """(distances, MRCA ids) of the oracle on all host cores: distances by its own pthread entry point, MRCA ids by
+    one OracleTree per Python thread over contiguous chunks (the C call releases the GIL; the visited-list scratch
+    is per instance).  Test infrastructure: the same functions, only faster on deep trees."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import OracleTree
+    pairs = np.asarray(pairs)
+    threads = threads or min(32, len(os.sched_getaffinity(0)))      # (hundreds of threads cost more than they save here)
+    n = len(pairs)
+    k = max(1, min(threads, n // 256))
+    want_d = OracleTree(parent, dist).distances_mt(pairs, k)
+    bounds = [n * i // k for i in range(k + 1)]
+    with ThreadPoolExecutor(k) as ex:
+        parts = list(ex.map(lambda i: OracleTree(parent, dist).mrca_bulk(pairs[bounds[i]:bounds[i + 1]]), range(k)))
+    return want_d, np.concatenate(parts) if parts else np.zeros(0, np.int32)
+
+
 def assert_bits_equal(got, want, what="distances"):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)

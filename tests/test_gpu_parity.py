@@ -10,7 +10,7 @@ import threading
 import numpy as np
 import pytest
 
-from conftest import assert_bits_equal, golden_path
+from conftest import assert_bits_equal, golden_path, oracle_both
 from oracle.oracle import OracleTree
 from suchtree_amd import InvalidNodeError, SuchTree, _capi, synth
 
@@ -34,8 +34,7 @@ def _both(dev, pairs):
 
 
 def _check(parent, dist, pairs, strategy="auto"):
-    O = OracleTree(parent, dist)
-    want_d, want_m = O.distances(pairs), O.mrca_bulk(pairs)
+    want_d, want_m = oracle_both(parent, dist, pairs)
     dev = _capi.DeviceTree(parent, dist, strategy=strategy)
     res = _both(dev, pairs)
     assert res, "no kernel family ran"
@@ -556,10 +555,11 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
             anc = np.where(parent[anc] >= 0, parent[anc], anc)
         lineage = np.concatenate([np.stack([up, anc], 1), np.stack([anc, up], 1), np.stack([up, up], 1)])
         allp = np.concatenate([pairs, near, lineage]).astype(np.int64)
-        want_d, want_m = O.distances(allp), O.mrca_bulk(allp)
+        want_d, want_m = oracle_both(parent, dist, allp)
         ids = rng.choice(n, size=400, replace=False).astype(np.int64)
         i, j = np.tril_indices(len(ids), -1)
         tri = np.stack([ids[j], ids[i]], 1)
+        tri_d, tri_m = oracle_both(parent, dist, tri)
         t = torch.from_numpy(allp).cuda()
         for on in (1, 0, 1):
             dev.set_option("lineage_sums", on)
@@ -607,8 +607,8 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
             dev.fault_check()
             assert_bits_equal(out_d.cpu().numpy(), want_d, "distances only, lineage_sums=%d" % on)
             td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
-            assert_bits_equal(td, O.distances(tri), "triangle lineage_sums=%d" % on)
-            assert np.array_equal(tm, O.mrca_bulk(tri))
+            assert_bits_equal(td, tri_d, "triangle lineage_sums=%d" % on)
+            assert np.array_equal(tm, tri_m)
             bad = allp[:150_000].copy()
             bad[131_337, 0] = n + 5
             with pytest.raises(_capi.InvalidNodeError) as err:
