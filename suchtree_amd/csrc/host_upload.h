@@ -281,7 +281,14 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->info.n_devices = 1;
     t->info.device_bytes = bytes;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
-    if (B.deep) tune_deep_tree(t, T);      // (host_tune.h: the kernel of large batches, by timing the candidates)
+    if (B.deep) {      // (host_tune.h: the kernel of large batches, by timing the candidates; the rule's defaults if that fails)
+        try {
+            tune_deep_tree(t, T);
+        } catch (...) {
+            rule_for_deep_tree(t);
+            t->info.tuned = 0;
+        }
+    }
     owner.t = nullptr;
     *out = t;
     return ST_OK;
