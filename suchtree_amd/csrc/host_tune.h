@@ -4,7 +4,7 @@
 // A deep tree (canopy more than kDeepCanopyDepth edges deep) has up to three kernels that produce the same bits:
 // the tile-sorted canopy kernel, the predicated canopy kernel and the tile-sorted walk kernel.  Which one is fastest
 // depends on the shape of the tree in ways no single statistic captured (launch_policy.h has the numbers), and the
-// spread is 2-4x, so the handle times them once on a sample of 2^22 random leaf pairs -- some 30 ms next to the 0.2-2 s
+// spread is 2-4x, so the handle times them once on a sample of 2^22 random leaf pairs drawn on the device -- 6 ms on ml.tree next to the 0.07-2 s
 // the tables of such a tree take to build -- and sets its defaults (tile_sort, pairs_per_lane, prefer_walk_sorted)
 // to the fastest.  st_tree_set_option / st_tree_set_strategy still override them.  SUCHTREE_AMD_AUTOTUNE=0: the
 // fixed rule instead.  Never an error: if anything here fails the rule's defaults stay.
@@ -46,24 +46,24 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T)
     }
     if (leaves.size() < 2) return;
     const int64_t n = kTunePairs;
-    std::vector<long long> pairs((size_t)n * 2);
-    uint64_t s = 0x9E3779B97F4A7C15ull;
-    for (auto &v : pairs) {
-        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
-        v = leaves[(size_t)((s >> 11) % leaves.size())];
-    }
+    int32_t *d_leaves = nullptr;
     long long *d_pairs = nullptr;
     double *d_dist = nullptr;
     int32_t *d_mrca = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const std::string keep = g_last_error;
-    bool ok = hipMalloc(reinterpret_cast<void **>(&d_pairs), (size_t)n * 16) == hipSuccess &&
+    bool ok = hipMalloc(reinterpret_cast<void **>(&d_leaves), leaves.size() * 4) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&d_pairs), (size_t)n * 16) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&d_dist), (size_t)n * 8) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&d_mrca), (size_t)n * 4) == hipSuccess &&
               hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
-              hipMemcpy(d_pairs, pairs.data(), (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpyAsync(d_leaves, leaves.data(), leaves.size() * 4, hipMemcpyHostToDevice, stream) == hipSuccess;
+    if (ok) {      // the sample is drawn on the device (k_sample_leaf_pairs, kernels_misc.h)
+        hipLaunchKernelGGL(k_sample_leaf_pairs, dim3(1024), dim3(256), 0, stream, d_leaves, (unsigned)leaves.size(), d_pairs, (long long)n);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+    }
     // milliseconds of the fastest of three launches after one warm-up, or a negative number
     auto time_settings = [&](int tile_sort, int ppl, int walk) -> float {
         t->tile_sort = tile_sort;
@@ -109,6 +109,7 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T)
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (stream) (void)hipStreamDestroy(stream);
+    (void)hipFree(d_leaves);
     (void)hipFree(d_pairs);
     (void)hipFree(d_dist);
     (void)hipFree(d_mrca);

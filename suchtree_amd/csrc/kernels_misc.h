@@ -110,4 +110,22 @@ __global__ void k_graph_laplacian(const double *__restrict__ A, const double *__
     }
 }
 
+// Uniform random leaf pairs for the creation-time timing of a deep tree's candidate kernels (host_tune.h): pair i =
+// (leaves[h(2i)], leaves[h(2i + 1)]), h a 32-bit mixer scaled to the leaf count by a multiply-high.
+__global__ __launch_bounds__(256) void k_sample_leaf_pairs(const int *__restrict__ leaves, unsigned n_leaves,
+                                                           long long *__restrict__ pairs, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long v[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            unsigned x = (unsigned)(2 * i + k) * 0x9E3779B9u + 0x7F4A7C15u;
+            x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+            v[k] = leaves[__umulhi(x, n_leaves)];
+        }
+        reinterpret_cast<longlong2 *>(pairs)[i] = make_longlong2(v[0], v[1]);
+    }
+}
+
 }  // namespace st
