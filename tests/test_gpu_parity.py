@@ -617,6 +617,42 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
         dev.close()
 
 
+def test_every_candidate_kernel_on_nj_tree(nj_arrays):
+    """nj.tree (256-byte records: 31-slot chains, the shared-portal case of the predicated kernel in two steps):
+    every candidate kernel forced by options, uniform and nearby pairs, both outputs and MRCA ids alone."""
+    import torch
+    parent, dist, leaf_ids = nj_arrays
+    n = len(parent)
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, n - 40, 150_000)
+    allp = np.concatenate([rng.integers(0, n, (450_000, 2)), np.stack([a, a + rng.integers(0, 40, a.size)], 1)]).astype(np.int64)
+    want_d, want_m = oracle_both(parent, dist, allp)
+    t = torch.from_numpy(allp).cuda()
+    out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+    out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+    dev = _capi.DeviceTree(parent, dist)
+    assert dev.info()["record_bytes"] == 256
+    seen = set()
+    for sort, ppl, walk in ((1, 0, 0), (0, 1, 0), (0, 0, 0), (1, 0, 1)):
+        dev.set_option("tile_sort", sort)
+        dev.set_option("pairs_per_lane", ppl)
+        dev.set_option("prefer_walk_sorted", walk)
+        kernel = dev.info()["big_batch_kernel"]
+        seen.add(kernel)
+        out_d.fill_(-1.0)
+        out_m.fill_(-1)
+        dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+        dev.fault_check()
+        assert_bits_equal(out_d.cpu().numpy(), want_d, kernel)
+        assert np.array_equal(out_m.cpu().numpy(), want_m), kernel
+    assert seen == {"canopy_sorted", "canopy", "canopy_scalar", "walk_sorted"}, seen
+    out_m.fill_(-1)
+    dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())      # k_mrca_ranks<31>
+    dev.fault_check()
+    assert np.array_equal(out_m.cpu().numpy(), want_m)
+    dev.close()
+
+
 def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch):
     """Deep trees: the handle times its candidate kernels when it is created and makes the fastest its default
     (st_tree_info.tuned / big_batch_kernel); every candidate, forced by options, gives the same bits.  512-byte
