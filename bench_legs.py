@@ -104,6 +104,7 @@ def host_path_leg(be, pairs, out_d, out_m):
     what T.distances_bulk(numpy) costs, PCIe inclusive."""
     tree = be.tree
     n = pairs.shape[0]
+    n_nodes_lt_2_24 = tree.info()["n_nodes"] <= 0xFFFFFF
     k2 = min(n, 50_000_000)
     host_pairs = pairs[:k2].cpu().numpy()
     ref_d, ref_m = out_d[:k2].cpu().numpy(), out_m[:k2].cpu().numpy()
@@ -134,6 +135,14 @@ def host_path_leg(be, pairs, out_d, out_m):
     t_32 = time.perf_counter() - t_32
     i32_ok = bool(np.array_equal(h_d.view(np.int64), ref_d.view(np.int64)) and np.array_equal(h_m, ref_m))
     tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+    # distances alone -- what the reference's SuchTree.distances(ids) returns: 4 bytes per pair come back over the link
+    tree.distances_host(host_pairs, True, False, out_dist=h_d)
+    t_d = 1e30
+    for _ in range(2):
+        t = time.perf_counter()
+        tree.distances_host(host_pairs, True, False, out_dist=h_d)
+        t_d = min(t_d, time.perf_counter() - t)
+    d_ok = bool(np.array_equal(h_d.view(np.int64), ref_d.view(np.int64)))
     # opt-in: result arrays from the recycled pinned pool, written by the kernel directly
     tree.pinned_results = True
     p_d, p_m = tree.distances_host(host_pairs, True, True)
@@ -148,18 +157,21 @@ def host_path_leg(be, pairs, out_d, out_m):
         "pairs_per_s": k2 / t_h, "pairs_per_s_fresh_arrays": k2 / t_f,
         "pairs_per_s_call_and_drop_loop": k2 / t_l,
         "pairs_per_s_int32_ids": k2 / t_32,
+        "pairs_per_s_distances_only": k2 / t_d,
         "pairs_per_s_pinned_result_pool": k2 / t_p, "pairs": k2,
-        "link_GBps_each_way": 8.0 * k2 / t_h / 1e9,
+        "link_bytes_per_pair": {"in": 6 if n_nodes_lt_2_24 else 8, "out": 8},
+        "link_GBps_out": 8.0 * k2 / t_h / 1e9,
         "what": "pageable numpy int64 pairs in -> float64 distances + int32 MRCA ids out, PCIe inclusive "
-                "(ids cross as int32, distances as float32, widened on the host); reused result arrays / "
+                "(ids cross as 24 bits each on trees of fewer than 2^24 nodes, else as int32; distances as float32, widened on the host); reused result arrays / "
                 "result arrays allocated by the call, first use of their memory (what a single "
                 "SuchTree.distances_bulk call returns) / the same call in a loop that drops each result "
-                "(blocks recycled by the library, release included) / int32 ids handed over as they are / opt-in "
+                "(blocks recycled by the library, release included) / int32 ids handed over as they are / distances alone, as "
+                "the reference's distances() returns them (reused array) / opt-in "
                 "pinned result pool (float64 + int32 written by the kernel straight into the returned arrays)",
         "matches_device_results": bool(np.array_equal(f_d.view(np.int64), ref_d.view(np.int64))
                                        and np.array_equal(f_m, ref_m)
                                        and np.array_equal(h_d.view(np.int64), ref_d.view(np.int64))
-                                       and np.array_equal(h_m, ref_m) and pooled_ok and loop_ok and i32_ok)}
+                                       and np.array_equal(h_m, ref_m) and pooled_ok and loop_ok and i32_ok and d_ok)}
 
 
 # --------------------------------------------------------------------------------------------

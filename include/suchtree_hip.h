@@ -271,6 +271,8 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "rec_a4": 1 (default) = on trees whose leaves sit in portal-uniform aligned blocks of leaf slots (balanced
  * and near-balanced trees) the predicated canopy kernel gathers 4 bytes for the first node of a pair
  * (its understory sum; the portal comes from a block table in LDS) instead of the 8-byte entry; 0 = 8 bytes.
+ * "wire48": 1 (default) = on trees of fewer than 2^24 nodes the host entry points ship ids over the link as 24 bits
+ * each (6 bytes per pair instead of 8; the packing step then checks the range and keeps the id to report); 0 = int32.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe. */

@@ -32,13 +32,25 @@ struct SrcContig {
 
 // C-order int32 (n,2): what the host path ships over PCIe (node ids always fit in 31 bits;
 // the packing step clamps anything wider so that it still fails the range check).
+// packed48: the narrower wire format of trees with fewer than 2^24 nodes -- 24 bits per id, 6 bytes per pair, three
+// 2-byte loads per lane (consecutive lanes read consecutive bytes; 0xFFFFFF stands for an id out of range, which the
+// host has already judged: host_copy.h::pack_pairs48).  One type for both formats (a wave-uniform branch), so that
+// no kernel is compiled twice for it.
 struct SrcContig32 {
     const int *pairs;
+    int packed48;
     __device__ __forceinline__ void load(long long i, long long &a, long long &b) const
     {
-        const int2 v = reinterpret_cast<const int2 *>(pairs)[i];
-        a = v.x;
-        b = v.y;
+        if (packed48) {
+            const unsigned short *q = reinterpret_cast<const unsigned short *>(pairs) + 3 * i;
+            const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+            a = (long long)(w0 | ((w1 & 0xFFu) << 16));
+            b = (long long)((w1 >> 8) | (w2 << 8));
+        } else {
+            const int2 v = reinterpret_cast<const int2 *>(pairs)[i];
+            a = v.x;
+            b = v.y;
+        }
     }
 };
 

@@ -95,6 +95,51 @@ inline void narrow_pairs_i64(int32_t *dst, const int64_t *src, int64_t m, long l
     _mm_sfence();
 }
 
+// (m,2) ids, element strides s0 / s1 -> 24 bits per id, 6 bytes per pair (the wire format of trees with fewer than
+// 2^24 nodes; device_common.h::SrcContig32::packed48).  `first` = index of the first pair in the destination (the
+// packed stream is written in 8-byte words where it can).  Ids outside [0, n_nodes) become 0xFFFFFF -- out of range
+// for the kernel too, which answers NaN / -1 -- and hi / lo keep the largest id >= n_nodes and the smallest negative
+// one: in this format the host is the judge of the range (the reference's choice of the id to report,
+// MuchTree.pyx:897-903, is made from these).
+template <typename Id>
+inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, int64_t s0, int64_t s1, long long n_nodes,
+                         long long &hi, long long &lo)
+{
+    auto one = [&](int64_t k) -> uint64_t {      // pair k as 48 bits
+        uint64_t w = 0;
+        for (int c = 0; c < 2; c++) {
+            const long long v = (long long)src[k * s0 + c * s1];
+            uint64_t id = (uint64_t)v;
+            if ((unsigned long long)v >= (unsigned long long)n_nodes) {
+                id = 0xFFFFFFu;
+                if (v < 0) { if (v < lo) lo = v; }
+                else if (v > hi) hi = v;
+            }
+            w |= id << (24 * c);
+        }
+        return w;
+    };
+    int64_t k = 0;
+    uint8_t *out = dst + 6 * first;
+    // head: up to the next pair whose byte offset is a multiple of 24 (four pairs = three 8-byte words)
+    for (; k < m && ((first + k) & 3) != 0; k++) {
+        const uint64_t w = one(k);
+        std::memcpy(out + 6 * k, &w, 6);
+    }
+    for (; k + 4 <= m; k += 4) {
+        const uint64_t p0 = one(k), p1 = one(k + 1), p2 = one(k + 2), p3 = one(k + 3);
+        long long *q = reinterpret_cast<long long *>(out + 6 * k);      // 8-byte aligned: dst is 16-byte aligned, 6 (first + k) is a multiple of 24
+        _mm_stream_si64(q + 0, (long long)(p0 | (p1 << 48)));
+        _mm_stream_si64(q + 1, (long long)((p1 >> 16) | (p2 << 32)));
+        _mm_stream_si64(q + 2, (long long)((p2 >> 32) | (p3 << 16)));
+    }
+    for (; k < m; k++) {
+        const uint64_t w = one(k);
+        std::memcpy(out + 6 * k, &w, 6);
+    }
+    _mm_sfence();
+}
+
 // Make [p, p + bytes) resident and writable without taking one page fault per 4 KiB inside
 // the copy loops.  Safe on any memory the caller is about to overwrite anyway.
 inline void populate_for_write(void *p, int64_t bytes)

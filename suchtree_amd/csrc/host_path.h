@@ -201,7 +201,7 @@ static HostOut make_host_out(double *out_dist, int32_t *out_mrca, int64_t n)
 // One chunk of a host-path call on slot s: `make_src(in)` builds the pair source from the
 // chunk's input pointer (NULL for generated sources), results go to the slot's pinned arrays.
 template <typename MakeSrc>
-static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_words_per_pair, const HostOut &out,
+static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_bytes_per_pair, const HostOut &out,
                         MakeSrc make_src)
 {
     if (!wants_device_stage(r, m) || (!out.dist && mrca_ranks_ready(r))) {
@@ -218,8 +218,8 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
     // 2e7 pairs, both outputs: input by copy kernel as well 2.7e9 pairs/s, this way 3.7-4.0e9,
     // both directions by the copy engine 3.3-3.5e9).
     hipError_t e = r->dp->pipe.ensure_device_stage();
-    if (e == hipSuccess && in_words_per_pair)
-        e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * in_words_per_pair * 4, hipMemcpyHostToDevice, s.stream);
+    if (e == hipSuccess && in_bytes_per_pair)
+        e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * in_bytes_per_pair, hipMemcpyHostToDevice, s.stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, out.dist ? static_cast<float *>(s.d_d) : nullptr},
                                out.mrca ? static_cast<int32_t *>(s.d_m) : nullptr, r->d_fault_host, s.stream);

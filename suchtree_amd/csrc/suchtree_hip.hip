@@ -356,6 +356,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->prefer_walk_sorted = (int)value;
         return ST_OK;
     }
+    if (std::strcmp(name, "wire48") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "wire48 must be 0 or 1");
+        t->wire48 = (int)value;
+        return ST_OK;
+    }
     if (std::strcmp(name, "sort_tile") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(ST_ERR_ARG, "sort_tile must be 0, 1, 2 or 4");
         t->sort_tile = (int)value;
@@ -467,10 +472,26 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
         hipStream_t s0 = nullptr;
         std::mutex wide_mutex;
         Fault wide = kFaultInit;
+        // trees with fewer than 2^24 nodes: 24 bits per id on the wire (6 instead of 8 bytes per pair over the link;
+        // the range check is then the host's, host_copy.h::pack_pairs48)
+        const bool wire48 = r->wire48 && r->n_nodes <= 0xFFFFFF;
         auto pack = [&](PipeSlot &s, int64_t off, int64_t m) {
             const Id *src = pairs + off * stride0;
             int32_t *dst = static_cast<int32_t *>(s.h_in);
             const bool c_order = stride0 == 2 && stride1 == 1;
+            if (wire48) {
+                const long long n_nodes = r->n_nodes;
+                pool.parallel_for(m, [&, src, dst, n_nodes](int64_t b, int64_t e) {
+                    long long hi = kFaultInit.max_bad, lo = kFaultInit.min_bad;
+                    pack_pairs48(reinterpret_cast<uint8_t *>(dst), b, src + b * stride0, e - b, stride0, stride1, n_nodes, hi, lo);
+                    if (hi != kFaultInit.max_bad || lo != kFaultInit.min_bad) {
+                        std::lock_guard<std::mutex> g(wide_mutex);
+                        wide.max_bad = std::max(wide.max_bad, hi);
+                        wide.min_bad = std::min(wide.min_bad, lo);
+                    }
+                });
+                return;
+            }
             if (sizeof(Id) == 4 && c_order) {   // int32 C-order: already the wire format
                 pool.parallel_for(m, [=](int64_t b, int64_t e) { copy_stream(dst + 2 * b, src + 2 * b, (e - b) * 8); });
                 return;
@@ -498,8 +519,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
             });
         };
         auto launch = [&](PipeSlot &s, int64_t off, int64_t m) {
-            return launch_chunk(r, s, off, m, 2, out,
-                                [](const void *in) { return SrcContig32{static_cast<const int *>(in)}; });
+            return launch_chunk(r, s, off, m, wire48 ? 6 : 8, out,
+                                [wire48](const void *in) { return SrcContig32{static_cast<const int *>(in), wire48 ? 1 : 0}; });
         };
         {   // (the pipe may not exist yet: ensure() inside run_pipe creates the streams)
             const hipError_t e = r->dp->pipe.ensure(std::max<int64_t>(seq.chunk, 1024));
@@ -510,7 +531,9 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
         if (rc == ST_OK) rc = run_pipe(r, seq, pack, launch, out, fault);
         if (rc != ST_OK) return rc;
         // a clamped id always trips the device check as well; its exact value replaces the clamp
-        if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) merge_fault(fault, wide);
+        // (24-bit wire format: every id out of range was seen, and its exact value kept, by the packing step)
+        if (wire48) fault = wide;
+        else if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) merge_fault(fault, wide);
         return ST_OK;
     };
     Fault fault;

@@ -85,6 +85,49 @@ def test_fresh_and_reused_result_arrays_agree(tree17):
     assert e.value.node_id == 2**40 + 5          # the exact id, not the int32 clamp
 
 
+def test_24_bit_ids_on_the_wire_and_int32_ids_agree(tree17):
+    """Trees with fewer than 2^24 nodes ship host-path ids as 24 bits each (6 bytes per pair over the link; the
+    range check is the packing step's).  Same results and the same reported id as the int32 wire format (option
+    wire48 = 0), for C-order int64, int32 and strided views, batches that are no multiple of the packing granule,
+    and every kind of bad id: >= n_nodes, >= 2^24, beyond int32, negative, several at once."""
+    parent, dist, O = tree17
+    n_nodes = len(parent)
+    dev = _capi.DeviceTree(parent, dist)
+    rng = np.random.default_rng(48)
+    for n in (1_000_003, 262_145, 40_001):
+        pairs = rng.integers(0, n_nodes, (n, 2))
+        want_d, want_m = O.distances(pairs[:50_000]), O.mrca_bulk(pairs[:50_000])
+        views = {"int64": pairs, "int32": pairs.astype(np.int32), "columns swapped": pairs[:, ::-1],
+                 "every other row": np.concatenate([pairs, pairs], 1).reshape(-1, 2)[::2]}
+        got = {}
+        for w48 in (1, 0):
+            dev.set_option("wire48", w48)
+            for name, v in views.items():
+                d, m = dev.distances_host(v, True, True)
+                got[(w48, name)] = (d, m)
+                if name in ("int64", "int32", "every other row"):
+                    assert_bits_equal(d[:50_000], want_d, "%s wire48=%d n=%d" % (name, w48, n))
+                    assert np.array_equal(m[:50_000], want_m)
+        for name in views:
+            assert_bits_equal(got[(1, name)][0], got[(0, name)][0], name)
+            assert np.array_equal(got[(1, name)][1], got[(0, name)][1]), name
+        # bad ids: the id the reference would report (the largest one >= n_nodes, else the smallest negative one)
+        cases = [({5: n_nodes}, n_nodes), ({5: n_nodes + 7, 900: 2**24 + 3}, 2**24 + 3), ({77: 2**24 - 1}, 2**24 - 1),
+                 ({n - 1: 2**40 + 5, 17: -(2**35)}, 2**40 + 5), ({3: -1}, -1), ({3: -1, n - 2: -9}, -9),
+                 ({1000: -4, 2000: n_nodes + 1}, n_nodes + 1)]
+        for bad_ids, reported in cases:
+            bad = pairs.copy()
+            for k, v in bad_ids.items():
+                bad[k, k & 1] = v
+            for w48 in (1, 0):
+                dev.set_option("wire48", w48)
+                with pytest.raises(InvalidNodeError) as e:
+                    dev.distances_host(bad, True, True)
+                assert e.value.node_id == reported, (bad_ids, w48, e.value.node_id)
+    dev.set_option("wire48", 1)
+    dev.close()
+
+
 def test_host_and_device_paths_do_not_share_a_fault_word(tree17):
     import torch
     parent, dist, O = tree17
