@@ -62,6 +62,7 @@ def main():
                     dev.set_option("mrca_ranks", int(rng.integers(0, 2)))
                     dev.set_option("sort_tile", int(rng.choice([0, 0, 1, 2, 4])))
                     dev.set_option("rec_a4", int(rng.integers(0, 2)))
+                    dev.set_option("wire48", int(rng.integers(0, 2)))
                     if k in (0, 4):
                         for name in ("walk_sort", "walk_ladder", "walk_crown", "lineage_lens"):
                             dev.set_option(name, int(rng.random() < 0.8))
