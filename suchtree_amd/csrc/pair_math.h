@@ -222,21 +222,46 @@ ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__res
 // child index, so "move the larger index up" can never step past the meeting
 // point.  `rec_*` are the understory records of a and b (global memory).
 // s += D[0]; s += D[1]; ... s += D[nb - 1] for a chain read through a pointer INTO ITS RECORD (rec_b: word0, then the
-// chain; 16-byte aligned): sixteen bytes per load instead of four (a 63-slot chain: 16 loads, not 63).
+// chain; 16-byte aligned): sixteen bytes per load instead of four, and chains of 8 slots and more -- they sit in
+// records of at least 16 words, whose size is a multiple of 16 words from there on -- in blocks of four such loads
+// that do not wait for each other (a 63-slot chain: at most four round trips instead of sixteen, or sixty-three).
 ST_HD float chain_sum_ptr(const float *__restrict__ D, uint32_t nb, float s)
 {
     if (nb <= 1) return nb ? s + D[0] : s;      // (one-slot records are 8 bytes: no 16-byte read there)
     const Quad *q = reinterpret_cast<const Quad *>(D - 1);      // {word0, D[0], D[1], D[2]}, {D[3] ...}, ...
+    if (nb >= 8) {
+        for (uint32_t base = 0; base <= nb; base += 16) {      // the block holds slots base - 1 .. base + 14
+            const Quad a = q[0], b = q[1], c = q[2], d = q[3];
+            q += 4;
+            if (base) s += a.x;      // (base - 1 < nb: the loop condition)
+            if (base + 0 < nb) s += a.y;
+            if (base + 1 < nb) s += a.z;
+            if (base + 2 < nb) s += a.w;
+            if (base + 3 < nb) s += b.x;
+            if (base + 4 < nb) s += b.y;
+            if (base + 5 < nb) s += b.z;
+            if (base + 6 < nb) s += b.w;
+            if (base + 7 < nb) s += c.x;
+            if (base + 8 < nb) s += c.y;
+            if (base + 9 < nb) s += c.z;
+            if (base + 10 < nb) s += c.w;
+            if (base + 11 < nb) s += d.x;
+            if (base + 12 < nb) s += d.y;
+            if (base + 13 < nb) s += d.z;
+            if (base + 14 < nb) s += d.w;
+        }
+        return s;
+    }
     Quad v = q[0];
-    if (nb > 0) s += v.y;
+    s += v.y;
     if (nb > 1) s += v.z;
     if (nb > 2) s += v.w;
-    for (uint32_t i = 3; i < nb; i += 4) {
-        v = *++q;
+    if (nb > 3) {      // (nb <= 7: the record has a second quad)
+        v = q[1];
         s += v.x;
-        if (i + 1 < nb) s += v.y;
-        if (i + 2 < nb) s += v.z;
-        if (i + 3 < nb) s += v.w;
+        if (nb > 4) s += v.y;
+        if (nb > 5) s += v.z;
+        if (nb > 6) s += v.w;
     }
     return s;
 }
