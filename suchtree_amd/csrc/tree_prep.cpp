@@ -143,15 +143,17 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
     return true;
 }
 
-// v = `bytes` zero bytes.  For the large record tables the cost of that is the kernel zero-filling fresh pages one
+// v = `count` zero elements.  For the large record tables the cost of that is the kernel zero-filling fresh pages one
 // fault at a time under a single-threaded memset (8.4 M nodes with 256-byte records: 7-17 s of a 9 s build on a busy
 // host): the pages are populated first, by several threads (MADV_POPULATE_WRITE on the reserved,
 // still empty buffer; failures are ignored), and the memset then runs over resident memory.
-static void assign_zero(std::vector<uint8_t> &v, size_t bytes)
+template <typename T>
+static void assign_zero(std::vector<T> &v, size_t count)
 {
+    const size_t bytes = count * sizeof(T);
     v.clear();
     if (bytes >= ((size_t)64 << 20)) {
-        v.reserve(bytes);
+        v.reserve(count);
         const long page = sysconf(_SC_PAGESIZE);
         const uintptr_t b = (reinterpret_cast<uintptr_t>(v.data()) + (uintptr_t)page - 1) & ~((uintptr_t)page - 1);
         const uintptr_t e = (reinterpret_cast<uintptr_t>(v.data()) + bytes) & ~((uintptr_t)page - 1);
@@ -176,7 +178,7 @@ static void assign_zero(std::vector<uint8_t> &v, size_t bytes)
             for (auto &th : threads) th.join();
         }
     }
-    v.assign(bytes, 0);
+    v.assign(count, T());
 }
 
 static int32_t pow2_ceil(int32_t v) {
@@ -448,8 +450,8 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries, bool with_lens)
     // (offsets share their word with a 4-bit chunk count; slots are kept in 28 bits by the kernel)
     if (entries > max_entries || entries >= ((int64_t)1 << 28) || n >= ((int64_t)1 << 28) || T.tree_depth > 65535) return false;
     build_rmq64(T);
-    T.lineage_sum.resize((size_t)entries);
-    if (with_lens) T.lineage_len.resize((size_t)entries);
+    assign_zero(T.lineage_sum, (size_t)entries);
+    if (with_lens) assign_zero(T.lineage_len, (size_t)entries);
     T.rec_p.assign((size_t)n * 8, 0);
     T.lineage_node_off.resize((size_t)n);
     int64_t off = 0;
@@ -489,8 +491,8 @@ bool prepare_walk_lineage(TreeTables &T, int64_t max_entries, bool with_lens)
         T.lineage_node_off[(size_t)x] = (uint32_t)off;
         off += lineage_block(T.depth[(size_t)x]);
     }
-    T.lineage_sum.resize((size_t)entries);
-    if (with_lens) T.lineage_len.resize((size_t)entries);
+    assign_zero(T.lineage_sum, (size_t)entries);
+    if (with_lens) assign_zero(T.lineage_len, (size_t)entries);
     auto fill = [&](int64_t lo, int64_t hi) {
         for (int64_t x = lo; x < hi; x++) {
             const size_t o = T.lineage_node_off[(size_t)x];
