@@ -20,6 +20,28 @@
 
 namespace st {
 
+// fn(begin, end) over contiguous parts of [0, n) on up to 32 threads (one part per `grain` items at least); a thread
+// that cannot be started leaves its part to the calling thread, nothing joinable is abandoned, nothing is thrown.
+template <typename Fn>
+static void parallel_ranges(int64_t n, int64_t grain, Fn fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 32), n / std::max<int64_t>(grain, 1)));
+    std::vector<std::thread> threads;
+    std::vector<std::pair<int64_t, int64_t>> mine;
+    for (int t = 0; t < n_threads; t++) {
+        const int64_t x0 = n * t / n_threads, x1 = n * (t + 1) / n_threads;
+        if (t + 1 == n_threads) { mine.emplace_back(x0, x1); break; }
+        try {
+            threads.emplace_back(fn, x0, x1);
+        } catch (const std::exception &) {
+            mine.emplace_back(x0, x1);
+        }
+    }
+    for (const auto &r : mine) fn(r.first, r.second);
+    for (auto &th : threads) th.join();
+}
+
 bool build_tree_rmq(TreeTables &T, int64_t max_bytes)
 {
     T.tree_rmq.clear();
@@ -124,13 +146,15 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
     T.tree_depth = max_leaf_depth + 1;   // MuchTree.pyx:218-225 counts nodes
 
     T.nodes.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
+    T.stride.resize((size_t)n);
+    // (three dependent scattered reads per node: on several threads for large trees)
+    parallel_ranges(n, (int64_t)1 << 18, [&](int64_t i0, int64_t i1) {
+    for (int64_t i = i0; i < i1; i++) {
         T.nodes[(size_t)i].parent = parent[i];
         T.nodes[(size_t)i].dist = distance[i];
     }
     // stride-3 image: the root's own "length" (-1 in the reference's table) is never an edge
-    T.stride.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t i = i0; i < i1; i++) {
         const int32_t p1 = parent[i] >= 0 ? parent[i] : (int32_t)i;
         const int32_t p2 = parent[p1] >= 0 ? parent[p1] : p1;
         const int32_t p3 = parent[p2] >= 0 ? parent[p2] : p2;
@@ -140,6 +164,7 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
         e.d2 = (p2 != p1 && parent[p2] >= 0) ? distance[p2] : 0.0f;
         e.p3 = p3;
     }
+    });
     return true;
 }
 
@@ -338,24 +363,7 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
             std::memcpy(T.rec_a.data() + slot * 8 + 4, &pbot, 4);
         }
     };
-    {
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 32), n >> 16));
-        // a thread that cannot be started leaves its range to this one; nothing joinable is abandoned
-        std::vector<std::thread> threads;
-        std::vector<std::pair<int64_t, int64_t>> mine;
-        for (int t = 0; t < n_threads; t++) {
-            const int64_t x0 = n * t / n_threads, x1 = n * (t + 1) / n_threads;
-            if (t + 1 == n_threads) { mine.emplace_back(x0, x1); break; }
-            try {
-                threads.emplace_back(build_records, x0, x1);
-            } catch (const std::exception &) {
-                mine.emplace_back(x0, x1);
-            }
-        }
-        for (const auto &r : mine) build_records(r.first, r.second);
-        for (auto &th : threads) th.join();
-    }
+    parallel_ranges(n, (int64_t)1 << 16, build_records);
     if (too_long.load()) return false;
     T.has_canopy = true;
     return true;
