@@ -101,6 +101,14 @@ def self_launch(args, argv):
     """Parent side of `python bench.py --gpus N` (N > 1).  Nothing here may touch the GPU: no torch,
     no HIP library (the box forbids replacing or forking a process that has initialised the GPU, so
     the ranks are children of a process that never did)."""
+    # the ranks all load libsuchtree_hip.so at once: make sure it is built before they start (hipcc needs no
+    # GPU; suchtree_amd.build imports neither torch nor the library), so that no rank has to build it
+    try:
+        from suchtree_amd import build as st_build
+        st_build.build()
+        st_build.build_microbench()
+    except Exception as e:      # noqa: BLE001 -- the ranks will report a missing library themselves
+        sys.stderr.write("bench.py: building the library in the launcher's parent failed (%s)\n" % e)
     cmd = launcher_command(args.gpus, argv, _free_port())
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -540,6 +548,11 @@ def closing_wait(dg, rank, timeout_s, release=False):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
+    # Both start forms (self-launch parent -> ranks, and ranks started by the driver's torch.distributed.run)
+    # run under the same HSA IPC mode: this pool's host driver only supports dmabuf IPC, and RCCL's
+    # peer-to-peer setup (hipIpcGetMemHandle) fails under the legacy mode.  Set before torch / HIP load;
+    # an explicit setting in the environment wins.  
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher's parent (before torch / HIP)
         sys.exit(self_launch(args, argv))
@@ -568,7 +581,11 @@ def main(argv=None):
     distributed = "RANK" in os.environ or world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise SystemExit("MASTER_PORT is not set: start the ranks with torch.distributed.run (or plain "
+                                 "`python bench.py --gpus N`, which picks a free port)")
+            os.environ["MASTER_PORT"] = str(_free_port())      # one rank: any free port will do
         dist_.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         # a collective that involves every rank before the first batched point-to-point call
         # (torch.distributed.batch_isend_irecv: "if this is the first collective call in the

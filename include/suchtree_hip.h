@@ -61,7 +61,10 @@ typedef struct st_tree_info {
     int64_t device_bytes;     /* HBM held by this tree */
     int64_t lineage_entries;  /* float32 entries of the lineage-sum table (deep canopies, in-order ids), else 0 */
     int32_t big_batch_kernel; /* kernel of large distance batches: ST_KERNEL_* below */
-    int32_t tuned;            /* 1 = that kernel was chosen by timing the candidates when the tree was created */
+    int32_t tuned;            /* 1 = that kernel was chosen by timing the candidates when the tree was created, 2 = read
+                                 from the record an earlier handle of the same tree on the same device left, 0 = by rule */
+    int32_t host_wire_bytes_in;   /* bytes per pair the st_*_host entry points ship over the link: ids in (6 or 8) ... */
+    int32_t host_wire_bytes_out;  /* ... float32 distance + MRCA id back (7 or 8); follow the wire48 / wire24 options */
 } st_tree_info;
 
 /* st_tree_info.big_batch_kernel */
@@ -70,6 +73,7 @@ typedef struct st_tree_info {
 #define ST_KERNEL_CANOPY_SCALAR   2   /* branchy canopy kernel */
 #define ST_KERNEL_CANOPY_SORTED   3   /* tile-sorted canopy kernel (ladder form of the canopy in LDS) */
 #define ST_KERNEL_WALK_SORTED     4   /* tile-sorted walk kernel on a tree that also has canopy tables */
+#define ST_KERNEL_CANOPY_LADDER   5   /* scalar canopy kernel over the ladder form (long records in registers, read once) */
 
 /* Last error message of the calling thread ("" if none). */
 const char *st_last_error(void);
@@ -264,6 +268,8 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * family's tables (deep trees) go to the tile-sorted walk kernel; 0 = they stay with the canopy kernels.  Like
  * "tile_sort" and "pairs_per_lane" its default is set when the tree is created, on deep trees by timing the candidate
  * kernels on a sample of random leaf pairs (st_tree_info.tuned; SUCHTREE_AMD_AUTOTUNE=0: by a fixed rule).
+ * "ladder_scalar": 1 = (with "tile_sort" 0) records of 128 bytes and more are served by the scalar kernel over the ladder
+ * form of the canopy; a default set with the three above when a deep tree is created.
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
  * "sort_tile": tile of both tile-sorted kernels in units of 1024 pairs: 1, 2 or 4 (taken when it fits LDS and the
  * kernel's form has that tile), 0 (default) = the largest tile LDS admits, cut finer for batches that would
@@ -273,6 +279,8 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * (its understory sum; the portal comes from a block table in LDS) instead of the 8-byte entry; 0 = 8 bytes.
  * "wire48": 1 (default) = on trees of fewer than 2^24 nodes the host entry points ship ids over the link as 24 bits
  * each (6 bytes per pair instead of 8; the packing step then checks the range and keeps the id to report); 0 = int32.
+ * "wire24": 1 (default) = on such trees MRCA ids come back over the link as 24 bits each (7 bytes per pair with the
+ * float32 distance instead of 8; assembled by the kernels, widened by the host's unpack pass); 0 = int32.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe. */

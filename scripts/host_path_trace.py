@@ -35,20 +35,25 @@ def main():
         gpu_node = sh("rocm-smi --showtoponuma 2>/dev/null | grep -i 'Numa Node' | head -1 | grep -o '[0-9]*$'") or "0"
         other = "1" if gpu_node == "0" else "0"
         cpus = {k: sh("cat /sys/devices/system/node/node%s/cpulist" % k) for k in (gpu_node, other)}
-        settings = [("", None), ("", None), ("taskset -c " + cpus[gpu_node], None), ("taskset -c " + cpus[other], None), ("", "1")]
-        for prefix, skip in settings:
-            env = dict(os.environ)
-            if skip:
-                env["SUCHTREE_AMD_PIPE_SKIP_CPU"] = skip
+        settings = [("", {}), ("", {}), ("", {"ST_TRACE_WIRE24": "0"}),
+                    ("taskset -c " + cpus[gpu_node], {}), ("taskset -c " + cpus[other], {}),
+                    ("", {"SUCHTREE_AMD_PIPE_SKIP_CPU": "1"}), ("", {"SUCHTREE_AMD_PIPE_SKIP_GPU": "1"}),
+                    ("", {"SUCHTREE_AMD_COPY_THREADS": "8"}), ("", {"SUCHTREE_AMD_COPY_THREADS": "32"})]
+        for prefix, extra in settings:
+            env = dict(os.environ, **extra)
             cmd = (prefix.split() if prefix else []) + [sys.executable, os.path.abspath(__file__), str(n), "--child"]
             out = subprocess.run(cmd, env=env, capture_output=True, text=True)
             where = "process on the GPU's node" if cpus[gpu_node] in prefix and prefix else "process on the other node" if prefix else "process placed by the scheduler"
-            print("%-34s %s %s" % (where, "NO pack / unpack passes (link side alone, results not produced)" if skip else "", out.stdout.strip()))
-            print("   ", "\n    ".join(out.stderr.strip().splitlines()[-1:]))
+            note = {"SUCHTREE_AMD_PIPE_SKIP_CPU": "NO pack / unpack passes (link side alone, results not produced)",
+                    "SUCHTREE_AMD_PIPE_SKIP_GPU": "NO launches (the CPU passes alone, results not produced)"}
+            print("%-34s %s %s" % (where, " ".join(note.get(k, "%s=%s" % (k, v)) for k, v in extra.items()), out.stdout.strip()))
+            print("   ", "\n    ".join(out.stderr.strip().splitlines()[-2:]))
         return
     from suchtree_amd import _capi, synth
     parent, dist = synth.balanced_tree(20)
     tree = _capi.DeviceTree(parent, dist)
+    if os.environ.get("ST_TRACE_WIRE24") == "0":
+        tree.set_option("wire24", 0)
     pairs = synth.random_leaf_pairs(1 << 20, n, seed=3)
     h_d, h_m = np.empty(n), np.empty(n, np.int32)
     tree.distances_host(pairs, True, True, out_dist=h_d, out_mrca=h_m)
@@ -64,7 +69,21 @@ def main():
         t0 = time.perf_counter()
         tree.distances_host(p32, True, True, out_dist=h_d, out_mrca=h_m)
         b32 = min(b32, time.perf_counter() - t0)
-    print("reused %.3e pairs/s (%.1f GB/s each way)  int32 ids %.3e" % (n / best, 8 * n / best / 1e9, n / b32))
+    tree.distances_host(pairs, True, False, out_dist=h_d)
+    bd = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tree.distances_host(pairs, True, False, out_dist=h_d)
+        bd = min(bd, time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    fresh = tree.distances_host(pairs, True, True)
+    tf = time.perf_counter() - t0
+    del fresh
+    i = tree.info()
+    print("reused %.3e pairs/s (wire %d B in / %d B out)  int32 ids %.3e  distances only %.3e  fresh arrays %.3e"
+          % (n / best, i["host_wire_bytes_in"], i["host_wire_bytes_out"], n / b32, n / bd, n / tf))
+    # last trace line = the distances-only call before the fresh one; the both-output trace is the one before
+    tree.distances_host(pairs, True, True, out_dist=h_d, out_mrca=h_m)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/fab_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export SUCHTREE_AMD_AUTOTUNE=0      # (the timing launches of host_tune.h would be counted under the profiled kernel's name)
 for C in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   N=$(echo $C | cut -d' ' -f1)
   timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$N -- python3 $REPO/scripts/tune_gpu.py "$@" > $OUT/$N.log 2>&1

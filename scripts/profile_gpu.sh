@@ -13,6 +13,7 @@ mkdir -p $OUT $REPO/scripts/micro/bin
 # the calibration program (known traffic) is built on demand; binaries are not kept in git
 [ -x $REPO/scripts/micro/bin/calib_requests ] || hipcc --offload-arch=gfx950 -O3 -o $REPO/scripts/micro/bin/calib_requests $REPO/scripts/micro/calib_requests.hip
 cd /tmp && export TMPDIR=/tmp
+export SUCHTREE_AMD_AUTOTUNE=0      # (the timing launches of host_tune.h would be counted under the profiled kernel's name)
 timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" ; do

@@ -7,6 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export SUCHTREE_AMD_AUTOTUNE=0      # (the timing launches of host_tune.h would be counted under the profiled kernel's name)
 IFS=';' read -ra SETS <<< "$COUNTERS"
 for C in "${SETS[@]}"; do
   N=$(echo $C | cut -d' ' -f1)

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsuchtree_hip.so")
 ST_OK, ST_ERR_ARG, ST_ERR_HIP, ST_ERR_BOUNDS, ST_ERR_NOMEM, ST_ERR_TREE = 0, 1, 2, 3, 4, 5
 STRATEGY = {"auto": 0, "walk": 1, "canopy": 2}
 STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
-BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 2: "canopy_scalar", 3: "canopy_sorted", 4: "walk_sorted"}      # ST_KERNEL_*
+BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 2: "canopy_scalar", 3: "canopy_sorted", 4: "walk_sorted", 5: "canopy_ladder"}      # ST_KERNEL_*
 
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
@@ -47,6 +47,8 @@ class TreeInfo(ctypes.Structure):
         ("lineage_entries", ctypes.c_int64),
         ("big_batch_kernel", ctypes.c_int32),
         ("tuned", ctypes.c_int32),
+        ("host_wire_bytes_in", ctypes.c_int32),
+        ("host_wire_bytes_out", ctypes.c_int32),
     ]
 
     def as_dict(self):

@@ -5,6 +5,7 @@
 The library is git-ignored (history stays source-only) but travels to the GPU
 box with the repo snapshot, so it must be built before a gpurun call.
 """
+import glob as _glob
 import os
 import shutil
 import subprocess
@@ -27,11 +28,9 @@ UNITS = [(os.path.join(CSRC, "launch_canopy_sorted.hip"), ["-DST_SORTED_PART=%d"
 OBJ_DIR = os.path.join(HERE, "build")
 MICRO_LIB = os.path.join(HERE, "libst_microbench.so")      # measurement helpers for bench.py, not the product
 MICRO_SRC = os.path.join(CSRC, "microbench.hip")
-HEADERS = [os.path.join(CSRC, h) for h in (
-    "tree_prep.h", "pair_math.h", "host_pipe.h", "host_copy.h", "device_common.h", "launch_geometry.h", "st_tree.h",
-    "launch_policy.h", "launch_decl.h", "launch_canopy_sorted.h", "kernels_walk.h", "kernels_canopy.h",
-    "kernels_canopy_sorted.h", "kernels_misc.h", "host_tree.h", "host_launch.h", "host_path.h", "host_upload.h")]
-HEADERS.append(os.path.join(HERE, "..", "include", "suchtree_hip.h"))
+# every header under csrc/ (a new one cannot be forgotten) + the public C ABI header
+HEADERS = sorted(_glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "suchtree_hip.h")]
+LOCK = os.path.join(HERE, ".build.lock")
 
 FLAGS = [
     "--offload-arch=gfx950",
@@ -56,16 +55,55 @@ def stale():
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
 
 
+class _BuildLock:
+    """One builder at a time across processes (`bench.py --gpus N` starts N ranks that all load the library; a
+    fresh copy of the repo has none): an exclusive flock on a file beside the library.  Whoever gets the lock
+    second finds the library fresh and does nothing."""
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(LOCK, "a+")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
+def _tmp_name(path):
+    return "%s.tmp.%d" % (path, os.getpid())
+
+
+def _link_into_place(cmd_head, out, cmd_tail, verbose):
+    """Link to a temporary name, then rename over the target: a concurrent dlopen sees the old file or the
+    new one, never a half-written one."""
+    tmp = _tmp_name(out)
+    cmd = cmd_head + ["-o", tmp] + cmd_tail
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+    return out
+
+
 def build_microbench(force=False, verbose=False):
     """libst_microbench.so: the random-sector / stream-copy ceilings bench.py measures in-process."""
-    if not force and os.path.exists(MICRO_LIB) and os.path.getmtime(MICRO_LIB) >= os.path.getmtime(MICRO_SRC):
+    def fresh():
+        return os.path.exists(MICRO_LIB) and os.path.getmtime(MICRO_LIB) >= os.path.getmtime(MICRO_SRC)
+    if not force and fresh():
         return MICRO_LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", MICRO_LIB, MICRO_SRC,
-           "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return MICRO_LIB
+    with _BuildLock():
+        if not force and fresh():
+            return MICRO_LIB
+        return _link_into_place([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"], MICRO_LIB,
+                                [MICRO_SRC, "-Wl,-rpath,/opt/rocm/lib"], verbose)
 
 
 NAMES_SRC = os.path.join(CSRC, "names_ext.c")
@@ -80,22 +118,32 @@ def build_names_ext(force=False, verbose=False):
     """_names extension (CPython C API, host only): the name -> id loop of distances_by_name."""
     import sysconfig
     lib = names_ext_path()
-    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(NAMES_SRC):
+
+    def fresh():
+        return os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(NAMES_SRC)
+    if not force and fresh():
         return lib
     cc = shutil.which("gcc") or shutil.which("cc")
     if cc is None:
         raise RuntimeError("no C compiler for the _names extension")
-    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I", sysconfig.get_paths()["include"], "-o", lib, NAMES_SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return lib
+    with _BuildLock():
+        if not force and fresh():
+            return lib
+        return _link_into_place([cc, "-O2", "-fPIC", "-shared", "-Wall", "-I", sysconfig.get_paths()["include"]], lib,
+                                [NAMES_SRC], verbose)
 
 
 def build(force=False, verbose=False, extra=()):
     """Compile every translation unit (in parallel) and link libsuchtree_hip.so."""
     if not force and not stale():
         return LIB
+    with _BuildLock():
+        if not force and not stale():      # (another process built it while this one waited for the lock)
+            return LIB
+        return _build_locked(verbose, extra)
+
+
+def _build_locked(verbose, extra):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     include = ["-I", os.path.join(HERE, "..", "include")]
@@ -103,19 +151,22 @@ def build(force=False, verbose=False, extra=()):
     def compile_one(unit):
         src, unit_flags, name = unit
         obj = os.path.join(OBJ_DIR, name)
-        cmd = [hipcc()] + FLAGS + list(extra) + unit_flags + include + ["-c", src, "-o", obj]
+        tmp = _tmp_name(obj)
+        cmd = [hipcc()] + FLAGS + list(extra) + unit_flags + include + ["-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, obj)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(UNITS), max(1, os.cpu_count() or 2))) as pool:
         objs = list(pool.map(compile_one, UNITS))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return LIB
+    return _link_into_place([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"], LIB,
+                            objs + ["-Wl,-rpath,/opt/rocm/lib", "-lpthread"], verbose)
 
 
 if __name__ == "__main__":

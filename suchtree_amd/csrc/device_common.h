@@ -132,12 +132,68 @@ struct SrcQuartet {
     }
 };
 
-__device__ __forceinline__ void store_result(const DistSink &out_d, int *__restrict__ out_m,
-                                             long long i, float d, int m)
+// Where MRCA ids go: int32 per pair, or -- the host path's way back on trees of fewer than 2^24 nodes -- 24 bits
+// per pair: pair i at bytes [3 i, 3 i + 3), little endian, -1 (an id out of range) as 0xFFFFFF; the buffer is padded
+// to a multiple of four bytes.  7 instead of 8 bytes per pair then cross the link with the float32 distance
+// (scripts/micro/link_pack_bench.hip: +13 % on the link side; host_copy.h::unpack_ids24 widens them again).
+struct MrcaSink {
+    int *m32;
+    unsigned char *m24;
+    __host__ __device__ bool any() const { return m32 != nullptr || m24 != nullptr; }
+};
+
+// One id, from any lane in any control flow (scattered form): three byte stores in the packed format.
+__device__ __forceinline__ void store_mrca(const MrcaSink &out, long long i, int m)
+{
+    if (out.m32) {
+        out.m32[i] = m;
+    } else if (out.m24) {
+        unsigned char *p = out.m24 + 3 * i;
+        p[0] = (unsigned char)m;
+        p[1] = (unsigned char)(m >> 8);
+        p[2] = (unsigned char)(m >> 16);
+    }
+}
+
+// The ids of 64 consecutive pairs, one per lane: EVERY lane of the wave calls this in converged control flow with
+// i = (a multiple of 4) + lane; lanes without a pair pass live = false.  Packed format: the four ids of a quad are
+// twelve bytes = three dwords, assembled with one quad permute (lane p takes the id of lane p + 1) and stored by the
+// quad's first three lanes -- a wave writes 192 consecutive bytes in aligned dwords, no byte stores (byte-masked
+// partial writes are what a link to host memory handles worst).  A dword's upper bytes belong to the next pair: if
+// that one is not live (the tail of a batch) or its id is not known yet (it follows by store_mrca) they are zero.
+__device__ __forceinline__ void store_mrca_wave(const MrcaSink &out, long long i, int m, bool live)
+{
+    if (out.m32) {
+        if (live) out.m32[i] = m;
+    } else if (out.m24) {
+        const unsigned v = live ? ((unsigned)m & 0xFFFFFFu) : 0u;
+        const unsigned next = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xF9 /* quad_perm:[1,2,3,3] */, 0xF, 0xF, true);
+        const unsigned p = (unsigned)i & 3u;
+        if (live && p != 3u) {
+            const unsigned w = (v >> (8u * p)) | (next << (24u - 8u * p));
+            reinterpret_cast<unsigned *>(out.m24)[(i >> 2) * 3 + p] = w;
+        }
+    }
+}
+
+__device__ __forceinline__ void store_dist(const DistSink &out_d, long long i, float d)
 {
     if (out_d.d64) out_d.d64[i] = (double)d;
     else if (out_d.f32) out_d.f32[i] = d;
-    if (out_m) out_m[i] = m;
+}
+
+// scattered form (any lane, any control flow)
+__device__ __forceinline__ void store_result(const DistSink &out_d, const MrcaSink &out_m, long long i, float d, int m)
+{
+    store_dist(out_d, i, d);
+    store_mrca(out_m, i, m);
+}
+
+// converged form (see store_mrca_wave)
+__device__ __forceinline__ void store_result_wave(const DistSink &out_d, const MrcaSink &out_m, long long i, float d, int m, bool live)
+{
+    if (live) store_dist(out_d, i, d);
+    store_mrca_wave(out_m, i, m, live);
 }
 
 }  // namespace st

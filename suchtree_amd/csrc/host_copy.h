@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cerrno>
 #include <emmintrin.h>
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -25,10 +26,30 @@
 
 namespace st {
 
+// The wide forms below are compiled for AVX2 whatever the build's baseline (function-level target attribute) and
+// chosen at run time; the SSE2 forms stay as the fallback.
+inline bool cpu_has_avx2()
+{
+    static const bool yes = __builtin_cpu_supports("avx2");
+    return yes;
+}
+
+__attribute__((target("avx2"))) inline int64_t widen_f32_to_f64_avx2(double *dst, const float *src, int64_t k, int64_t n)
+{
+    while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 31)) { dst[k] = (double)src[k]; k++; }
+    for (; k + 8 <= n; k += 8) {
+        const __m256 v = _mm256_loadu_ps(src + k);
+        _mm256_stream_pd(dst + k, _mm256_cvtps_pd(_mm256_castps256_ps128(v)));
+        _mm256_stream_pd(dst + k + 4, _mm256_cvtps_pd(_mm256_extractf128_ps(v, 1)));
+    }
+    return k;
+}
+
 // float32 -> float64, dst written with streaming stores.
 inline void widen_f32_to_f64(double *dst, const float *src, int64_t n)
 {
     int64_t k = 0;
+    if (cpu_has_avx2()) k = widen_f32_to_f64_avx2(dst, src, 0, n);
     while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 15)) { dst[k] = (double)src[k]; k++; }
     for (; k + 4 <= n; k += 4) {
         const __m128 v = _mm_loadu_ps(src + k);
@@ -36,6 +57,46 @@ inline void widen_f32_to_f64(double *dst, const float *src, int64_t n)
         _mm_stream_pd(dst + k + 2, _mm_cvtps_pd(_mm_movehl_ps(v, v)));
     }
     for (; k < n; k++) dst[k] = (double)src[k];
+    _mm_sfence();
+}
+
+// 24-bit ids (device_common.h::MrcaSink: pair i at bytes [3 i, 3 i + 3), 0xFFFFFF = -1) -> int32, ids
+// [first, first + n) of the packed stream `src`; dst (the caller's array, already offset to `first`) written with
+// streaming stores.  The packed buffer is readable for at least 4 bytes past its last id (a staging slot of 4 bytes
+// per pair).
+__attribute__((target("avx2"))) inline int64_t unpack_ids24_avx2(int32_t *dst, const uint8_t *src, int64_t k, int64_t n)
+{
+    while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 31)) {
+        uint32_t w;
+        std::memcpy(&w, src + 3 * k, 4);
+        w &= 0xFFFFFFu;
+        dst[k] = w == 0xFFFFFFu ? -1 : (int32_t)w;
+        k++;
+    }
+    const __m256i pick = _mm256_setr_epi8(0, 1, 2, -1, 3, 4, 5, -1, 6, 7, 8, -1, 9, 10, 11, -1,
+                                          0, 1, 2, -1, 3, 4, 5, -1, 6, 7, 8, -1, 9, 10, 11, -1);
+    const __m256i none = _mm256_set1_epi32(0xFFFFFF);
+    for (; k + 10 <= n; k += 8) {      // (16-byte loads at 3 k and 3 k + 12: the last one ends 4 bytes past id k + 7)
+        const __m128i lo = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 3 * k));
+        const __m128i hi = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + 3 * k + 12));
+        __m256i v = _mm256_shuffle_epi8(_mm256_inserti128_si256(_mm256_castsi128_si256(lo), hi, 1), pick);
+        v = _mm256_or_si256(v, _mm256_slli_epi32(_mm256_cmpeq_epi32(v, none), 24));      // 0xFFFFFF -> -1
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k), v);
+    }
+    return k;
+}
+
+inline void unpack_ids24(int32_t *dst, const uint8_t *src, int64_t first, int64_t n)
+{
+    const uint8_t *p = src + 3 * first;
+    int64_t k = 0;
+    if (cpu_has_avx2()) k = unpack_ids24_avx2(dst, p, 0, n);
+    for (; k < n; k++) {
+        uint32_t w;
+        std::memcpy(&w, p + 3 * k, 4);
+        w &= 0xFFFFFFu;
+        dst[k] = w == 0xFFFFFFu ? -1 : (int32_t)w;
+    }
     _mm_sfence();
 }
 
@@ -101,6 +162,44 @@ inline void narrow_pairs_i64(int32_t *dst, const int64_t *src, int64_t m, long l
 // for the kernel too, which answers NaN / -1 -- and hi / lo keep the largest id >= n_nodes and the smallest negative
 // one: in this format the host is the judge of the range (the reference's choice of the id to report,
 // MuchTree.pyx:897-903, is made from these).
+// Four pairs of a C-order (m,2) array at once (AVX2): 0 if any of the eight ids is outside [0, n_nodes) -- the
+// caller then takes the scalar form for these four, which also records the offender -- else their 24 packed bytes.
+__attribute__((target("avx2"))) inline bool pack4_pairs48_i64(const int64_t *src, long long n_nodes, uint64_t out[3])
+{
+    const __m256i v0 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src));          // a0 b0 a1 b1
+    const __m256i v1 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + 4));      // a2 b2 a3 b3
+    const __m256i top = _mm256_set1_epi64x(n_nodes - 1), zero = _mm256_setzero_si256();
+    const __m256i bad = _mm256_or_si256(_mm256_or_si256(_mm256_cmpgt_epi64(v0, top), _mm256_cmpgt_epi64(zero, v0)),
+                                        _mm256_or_si256(_mm256_cmpgt_epi64(v1, top), _mm256_cmpgt_epi64(zero, v1)));
+    if (!_mm256_testz_si256(bad, bad)) return false;
+    const __m256i pick = _mm256_setr_epi8(0, 1, 2, 8, 9, 10, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                          0, 1, 2, 8, 9, 10, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i w0 = _mm256_shuffle_epi8(v0, pick), w1 = _mm256_shuffle_epi8(v1, pick);
+    const uint64_t p0 = (uint64_t)_mm256_extract_epi64(w0, 0), p1 = (uint64_t)_mm256_extract_epi64(w0, 2);
+    const uint64_t p2 = (uint64_t)_mm256_extract_epi64(w1, 0), p3 = (uint64_t)_mm256_extract_epi64(w1, 2);
+    out[0] = p0 | (p1 << 48);
+    out[1] = (p1 >> 16) | (p2 << 32);
+    out[2] = (p2 >> 32) | (p3 << 16);
+    return true;
+}
+
+__attribute__((target("avx2"))) inline bool pack4_pairs48_i32(const int32_t *src, long long n_nodes, uint64_t out[3])
+{
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src));           // a0 b0 a1 b1 | a2 b2 a3 b3
+    const __m256i top = _mm256_set1_epi32((int)(n_nodes - 1)), zero = _mm256_setzero_si256();
+    const __m256i bad = _mm256_or_si256(_mm256_cmpgt_epi32(v, top), _mm256_cmpgt_epi32(zero, v));
+    if (!_mm256_testz_si256(bad, bad)) return false;
+    const __m256i pick = _mm256_setr_epi8(0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1,
+                                          0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14, -1, -1, -1, -1);
+    const __m256i w = _mm256_shuffle_epi8(v, pick);
+    const uint64_t l0 = (uint64_t)_mm256_extract_epi64(w, 0), l1 = (uint64_t)_mm256_extract_epi64(w, 1) & 0xFFFFFFFFull;
+    const uint64_t h0 = (uint64_t)_mm256_extract_epi64(w, 2), h1 = (uint64_t)_mm256_extract_epi64(w, 3) & 0xFFFFFFFFull;
+    out[0] = l0;
+    out[1] = l1 | (h0 << 32);
+    out[2] = (h0 >> 32) | (h1 << 32);
+    return true;
+}
+
 template <typename Id>
 inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, int64_t s0, int64_t s1, long long n_nodes,
                          long long &hi, long long &lo)
@@ -126,12 +225,24 @@ inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, 
         const uint64_t w = one(k);
         std::memcpy(out + 6 * k, &w, 6);
     }
+    const bool wide = cpu_has_avx2() && s0 == 2 && s1 == 1 && n_nodes >= 1 && n_nodes <= 0xFFFFFF;
     for (; k + 4 <= m; k += 4) {
-        const uint64_t p0 = one(k), p1 = one(k + 1), p2 = one(k + 2), p3 = one(k + 3);
         long long *q = reinterpret_cast<long long *>(out + 6 * k);      // 8-byte aligned: dst is 16-byte aligned, 6 (first + k) is a multiple of 24
-        _mm_stream_si64(q + 0, (long long)(p0 | (p1 << 48)));
-        _mm_stream_si64(q + 1, (long long)((p1 >> 16) | (p2 << 32)));
-        _mm_stream_si64(q + 2, (long long)((p2 >> 32) | (p3 << 16)));
+        uint64_t w[3];
+        bool done = false;
+        if (wide) {
+            if (sizeof(Id) == 8) done = pack4_pairs48_i64(reinterpret_cast<const int64_t *>(src) + 2 * k, n_nodes, w);
+            else done = pack4_pairs48_i32(reinterpret_cast<const int32_t *>(src) + 2 * k, n_nodes, w);
+        }
+        if (!done) {
+            const uint64_t p0 = one(k), p1 = one(k + 1), p2 = one(k + 2), p3 = one(k + 3);
+            w[0] = p0 | (p1 << 48);
+            w[1] = (p1 >> 16) | (p2 << 32);
+            w[2] = (p2 >> 32) | (p3 << 16);
+        }
+        _mm_stream_si64(q + 0, (long long)w[0]);
+        _mm_stream_si64(q + 1, (long long)w[1]);
+        _mm_stream_si64(q + 2, (long long)w[2]);
     }
     for (; k < m; k++) {
         const uint64_t w = one(k);

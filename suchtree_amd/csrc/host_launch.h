@@ -11,7 +11,7 @@ static const Fault kFaultInit = {std::numeric_limits<long long>::min(),
 // Small batches are not worth staging 128 KiB of canopy per workgroup.
 
 template <typename Src>
-static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, int32_t *d_mrca,
+static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, MrcaSink d_mrca,
                        Fault *fault, hipStream_t stream, bool allow_sorted = true)
 {
     if (n == 0) return ST_OK;
@@ -21,7 +21,7 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, in
     // kernel must not work on -- it reads every pair twice and scatters its stores)
     // MRCA ids only, rank table available: k_mrca_ranks whatever the tree's depth (it reads every
     // pair once and stores coalesced, so it may also work on pinned host memory)
-    const bool ranks_only = !d_out.any() && d_mrca && mrca_ranks_ready(t) && n >= kCanopyMinPairs;
+    const bool ranks_only = !d_out.any() && d_mrca.any() && mrca_ranks_ready(t) && n >= kCanopyMinPairs;
     const bool canopy = ranks_only ||
                         (t->strategy == ST_STRATEGY_CANOPY && n >= canopy_min_pairs(t) &&
                          (allow_sorted || !(t->tile_sort && sorted_q(t) > 0) || sorted_zero_copy(t)) &&
@@ -33,7 +33,7 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, in
 }
 
 static int enqueue(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t s0, int64_t s1,
-                   DistSink d_out, int32_t *d_mrca, hipStream_t stream)
+                   DistSink d_out, MrcaSink d_mrca, hipStream_t stream)
 {
     const long long *p = reinterpret_cast<const long long *>(d_pairs);
     if (s0 == 2 && s1 == 1 && (reinterpret_cast<uintptr_t>(d_pairs) & 15) == 0)

@@ -159,6 +159,17 @@ __global__ __launch_bounds__(1024) void k_widen_copy(const float *__restrict__ s
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (double)src[i];
 }
 
+// int32 MRCA ids (device) -> the 24-bit wire format (pinned host), coalesced: the staged form of a direct result write
+__global__ __launch_bounds__(1024) void k_pack24_copy(const int *__restrict__ src, unsigned char *__restrict__ dst, long long n)
+{
+    const MrcaSink out{nullptr, dst};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const long long i = base + threadIdx.x;
+        store_mrca_wave(out, i, i < n ? src[i] : 0, i < n);
+    }
+}
+
 // Is [p, p + bytes) pinned host memory the GPU can address (hipHostMalloc / hipHostRegister)?
 // Result arrays like that -- st_host_alloc blocks, pinned torch tensors -- are written by the
 // kernels directly: no staging slot, no unpack pass, no page faults.
@@ -182,7 +193,14 @@ struct HostOut {
     double *dist = nullptr;
     int32_t *mrca = nullptr;
     bool direct_d = false, direct_m = false;
+    bool wire24 = false;      // staged MRCA ids cross the link as 24 bits each (device_common.h::MrcaSink)
 };
+
+// MRCA ids come back as 24 bits each on trees of fewer than 2^24 nodes (option wire24; direct result arrays take int32)
+static bool wire24_of(const st_tree *t, const HostOut &out)
+{
+    return out.mrca && !out.direct_m && t->wire24 && t->n_nodes <= 0xFFFFFF;
+}
 
 static HostOut make_host_out(double *out_dist, int32_t *out_mrca, int64_t n)
 {
@@ -210,7 +228,12 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
             if (out.direct_d) sink.d64 = out.dist + off;
             else sink.f32 = static_cast<float *>(s.h_d);
         }
-        int32_t *mrca = !out.mrca ? nullptr : out.direct_m ? out.mrca + off : static_cast<int32_t *>(s.h_m);
+        MrcaSink mrca{nullptr, nullptr};
+        if (out.mrca) {
+            if (out.direct_m) mrca.m32 = out.mrca + off;
+            else if (out.wire24) mrca.m24 = static_cast<unsigned char *>(s.h_m);
+            else mrca.m32 = static_cast<int32_t *>(s.h_m);
+        }
         return enqueue_src(r, make_src(s.h_in), m, sink, mrca, r->d_fault_host, s.stream, false);
     }
     // Pairs come in through the copy engine, results go out through copy kernels: the two
@@ -222,7 +245,7 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
         e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * in_bytes_per_pair, hipMemcpyHostToDevice, s.stream);
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, out.dist ? static_cast<float *>(s.d_d) : nullptr},
-                               out.mrca ? static_cast<int32_t *>(s.d_m) : nullptr, r->d_fault_host, s.stream);
+                               MrcaSink{out.mrca ? static_cast<int32_t *>(s.d_m) : nullptr, nullptr}, r->d_fault_host, s.stream);
     if (rc != ST_OK) return rc;
     if (out.dist && out.direct_d) {
         hipLaunchKernelGGL(k_widen_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, kCopyKernelBlocks))),
@@ -231,7 +254,13 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
     } else if (out.dist) {
         e = enqueue_words_copy(s.d_d, s.h_d, m, s.stream);
     }
-    if (e == hipSuccess && out.mrca) e = enqueue_words_copy(s.d_m, out.direct_m ? static_cast<void *>(out.mrca + off) : s.h_m, m, s.stream);
+    if (e == hipSuccess && out.mrca && out.wire24 && !out.direct_m) {
+        hipLaunchKernelGGL(k_pack24_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, kCopyKernelBlocks))),
+                           dim3(1024), 0, s.stream, static_cast<const int *>(s.d_m), static_cast<unsigned char *>(s.h_m), (long long)m);
+        e = hipGetLastError();
+    } else if (e == hipSuccess && out.mrca) {
+        e = enqueue_words_copy(s.d_m, out.direct_m ? static_cast<void *>(out.mrca + off) : s.h_m, m, s.stream);
+    }
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     return ST_OK;
 }
@@ -250,7 +279,12 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     static const bool trace = std::getenv("SUCHTREE_AMD_TRACE_PIPE") != nullptr;
     // SUCHTREE_AMD_PIPE_SKIP_CPU=1 (measurement only, results are garbage): no pack and no unpack passes --
     // what the GPU / link side of the pipeline takes when the host's memory system is otherwise idle
-    static const bool skip_cpu = std::getenv("SUCHTREE_AMD_PIPE_SKIP_CPU") != nullptr;
+    // SUCHTREE_AMD_PIPE_SKIP_GPU=1 (measurement only, results are garbage): the pack / pre-fault / unpack passes alone,
+    // nothing launched -- what the host side of the pipeline sustains when it never waits for a GPU: the most a
+    // multi-device handle (one pipeline per GPU, all fed by this host's memory system) can scale to
+    // (both read per call, so that a benchmark can switch them on for one call)
+    const bool skip_cpu = std::getenv("SUCHTREE_AMD_PIPE_SKIP_CPU") != nullptr;
+    const bool skip_gpu = std::getenv("SUCHTREE_AMD_PIPE_SKIP_GPU") != nullptr;
     using Clock = std::chrono::steady_clock;
     double t_wait = 0, t_unpack = 0, t_pack = 0, t_launch = 0, t_prefault = 0;
     const Clock::time_point t_begin = Clock::now();
@@ -275,8 +309,10 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         if (!s.busy) return hipSuccess;
         s.busy = false;
         Clock::time_point tp = trace ? Clock::now() : Clock::time_point();
-        const hipError_t e = hipEventSynchronize(s.done);
-        if (e != hipSuccess) return e;
+        if (!skip_gpu) {
+            const hipError_t e = hipEventSynchronize(s.done);
+            if (e != hipSuccess) return e;
+        }
         lap(t_wait, tp);
         // distances crossed PCIe as float32 and are widened into the caller's float64 array;
         // MRCA ids are copied; one pass of the pool over the chunk does both
@@ -284,10 +320,12 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         const int32_t *src_m = static_cast<const int32_t *>(s.h_m);
         double *dst_d = out_dist ? out_dist + s.off : nullptr;
         int32_t *dst_m = out_mrca ? out_mrca + s.off : nullptr;
+        const bool wire24 = out.wire24;
         if ((dst_d || dst_m) && !skip_cpu)
             P.pool.parallel_for(s.m, [=](int64_t b, int64_t e) {
                 if (dst_d) widen_f32_to_f64(dst_d + b, src_d + b, e - b);
-                if (dst_m) copy_stream(dst_m + b, src_m + b, (e - b) * 4);
+                if (dst_m && wire24) unpack_ids24(dst_m + b, reinterpret_cast<const uint8_t *>(src_m), b, e - b);
+                else if (dst_m) copy_stream(dst_m + b, src_m + b, (e - b) * 4);
             });
         lap(t_unpack, tp);
         return hipSuccess;
@@ -312,42 +350,73 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         }
         return fail(code, msg);
     };
+    // This device's chunks, the first and the last of them cut into pieces of 1/8, 1/8, 1/4, 1/2 (and the mirror
+    // image): the GPU has nothing to do while the first piece is packed, and the host nothing to overlap with while
+    // the last one is unpacked, so those two are kept small (5e7 pairs in 2^22-pair chunks: ~0.5 of 10 ms).
+    struct Piece { int64_t off, m; bool last; };
+    std::vector<Piece> pieces;
+    {
+        std::vector<std::pair<int64_t, int64_t>> chunks;
+        for (int64_t c = seq.first; c * seq.chunk < seq.n; c += seq.step)
+            chunks.emplace_back(c * seq.chunk, std::min(seq.chunk, seq.n - c * seq.chunk));
+        constexpr int64_t kRampMin = (int64_t)1 << 20;      // chunks below this are not worth cutting
+        for (size_t q = 0; q < chunks.size(); q++) {
+            const int64_t off = chunks[q].first, m = chunks[q].second;
+            const bool first = q == 0, last = q + 1 == chunks.size();
+            if ((!first && !last) || m < kRampMin) { pieces.push_back({off, m, false}); continue; }
+            const int64_t e = (m / 8 + 1023) / 1024 * 1024;
+            std::vector<int64_t> cuts;
+            if (first && last) cuts = {e, e, 2 * e, 2 * e, e};            // (the rest: one more small piece)
+            else if (first) cuts = {e, e, 2 * e};                         // (the rest: about half)
+            else cuts = {4 * e, 2 * e, e};                                // (the rest: the last eighth)
+            int64_t at = 0;
+            for (const int64_t c : cuts) {
+                if (at + c >= m) break;
+                pieces.push_back({off + at, c, false});
+                at += c;
+            }
+            pieces.push_back({off + at, m - at, false});
+        }
+        if (!pieces.empty()) pieces.back().last = true;
+    }
     int64_t k = 0;
-    for (int64_t c = seq.first; c * seq.chunk < seq.n; c += seq.step, k++) {
-        const int64_t off = c * seq.chunk;
-        const int64_t m = std::min(seq.chunk, seq.n - off);
+    for (const Piece &pc : pieces) {
+        const int64_t off = pc.off, m = pc.m;
         PipeSlot &s = P.slot[k % kPipeSlots];
         hipError_t e = drain(s);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         Clock::time_point tp = trace ? Clock::now() : Clock::time_point();
         if (!skip_cpu) pack(s, off, m);
         lap(t_pack, tp);
-        const int rc = launch(s, off, m);
-        if (rc != ST_OK) return bail(rc, g_last_error);
-        if ((c + seq.step) * seq.chunk >= seq.n) {
-            // last chunk of this device: fetch the fault word behind it (and behind the chunk
-            // still in flight on the other stream), so that one wait covers results and faults
-            for (PipeSlot &other : P.slot)
-                if (&other != &s && other.busy && e == hipSuccess) e = hipStreamWaitEvent(s.stream, other.done, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(P.h_fault, t->d_fault_host, sizeof(Fault), hipMemcpyDeviceToHost, s.stream);
+        if (!skip_gpu) {
+            const int rc = launch(s, off, m);
+            if (rc != ST_OK) return bail(rc, g_last_error);
+            if (pc.last) {
+                // last piece of this device: fetch the fault word behind it (and behind the pieces
+                // still in flight on the other streams), so that one wait covers results and faults
+                for (PipeSlot &other : P.slot)
+                    if (&other != &s && other.busy && e == hipSuccess) e = hipStreamWaitEvent(s.stream, other.done, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(P.h_fault, t->d_fault_host, sizeof(Fault), hipMemcpyDeviceToHost, s.stream);
+                if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
+            }
+            e = hipEventRecord(s.done, s.stream);
             if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         }
-        e = hipEventRecord(s.done, s.stream);
-        if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
         s.busy = true;
         s.off = off;
         s.m = m;
         lap(t_launch, tp);
         prefault(off, m);
         lap(t_prefault, tp);
-        e = drain(P.slot[(k + 1) % kPipeSlots]);   // unpack the oldest chunk while the newer ones are in flight
+        k++;
+        e = drain(P.slot[k % kPipeSlots]);   // unpack the oldest piece while the newer ones are in flight
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
     for (int j = 0; j < kPipeSlots; j++) {     // oldest first
         const hipError_t e = drain(P.slot[(k + j) % kPipeSlots]);
         if (e != hipSuccess) return bail(ST_ERR_HIP, std::string("pipeline: ") + hipGetErrorString(e));
     }
-    if (k > 0) {
+    if (k > 0 && !skip_gpu) {
         fault = *static_cast<const Fault *>(P.h_fault);
         if (fault.max_bad != kFaultInit.max_bad || fault.min_bad != kFaultInit.min_bad) {     // fired: re-arm
             hipStream_t s0 = P.slot[0].stream;
@@ -358,7 +427,7 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     t->host_fault_dirty = false;
     if (trace)
         std::fprintf(stderr, "[pipe] n %lld chunk %lld chunks %lld total %.1f us: pack %.1f launch %.1f prefault %.1f wait %.1f unpack %.1f\n",
-                     (long long)seq.n, (long long)seq.chunk, (long long)k,
+                     (long long)seq.n, (long long)seq.chunk, (long long)k,      // (pieces: the first and last chunk are cut)
                      std::chrono::duration<double, std::micro>(Clock::now() - t_begin).count(), t_pack, t_launch, t_prefault,
                      t_wait, t_unpack);
     return ST_OK;

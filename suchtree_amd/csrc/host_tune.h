@@ -6,9 +6,16 @@
 // depends on the shape of the tree in ways no single statistic captured (launch_policy.h has the numbers), and the
 // spread is 2-4x, so the handle times them once on a sample of 2^22 random leaf pairs drawn on the device -- 6 ms on ml.tree next to the 0.07-2 s
 // the tables of such a tree take to build -- and sets its defaults (tile_sort, pairs_per_lane, prefer_walk_sorted)
-// to the fastest.  st_tree_set_option / st_tree_set_strategy still override them.  SUCHTREE_AMD_AUTOTUNE=0: the
-// fixed rule instead.  Never an error: if anything here fails the rule's defaults stay.
+// to the fastest -- if it beats the rule's own choice by more than 7 % (kTuneMargin), else the rule stands.  The decision
+// is recorded per (tree digest, device, library build) and read back by later handles and processes, so a handle's
+// kernel is stable across runs (info.tuned: 1 = timed now, 2 = read from the record); multi-device handles time on
+// the primary and copy the settings to the peers.  st_tree_set_option / st_tree_set_strategy still override them.
+// SUCHTREE_AMD_AUTOTUNE=0: the fixed rule instead.  Results are bit-identical whatever is chosen.  Never an error:
+// if anything here fails the rule's defaults stay.
 #pragma once
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
 
 constexpr int64_t kTunePairs = (int64_t)1 << 22;      // (large enough for every candidate's largest tiles on every CU: with 2^20 a 13 % gap at 2e7 pairs went unseen)
 
@@ -18,6 +25,7 @@ static int big_batch_kernel_of(const st_tree *t)
     if (t->strategy != ST_STRATEGY_CANOPY) return ST_KERNEL_WALK;
     if (prefers_walk_sorted(t, (int64_t)1 << 40, true)) return ST_KERNEL_WALK_SORTED;
     if (t->tile_sort && sorted_q(t) > 0) return ST_KERNEL_CANOPY_SORTED;
+    if (ladder_scalar_ready(t)) return ST_KERNEL_CANOPY_LADDER;
     return t->pairs_per_lane == 0 ? ST_KERNEL_CANOPY_SCALAR : ST_KERNEL_CANOPY;
 }
 
@@ -28,13 +36,99 @@ static void rule_for_deep_tree(st_tree *t)
     // 63-slot chains: the tile-sorted canopy kernel reads them through a pointer and never won a measurement
     if (t->rec_cap > 31 || sorted_q(t) <= 0) { t->pairs_per_lane = 1; t->tile_sort = 0; }
     t->prefer_walk_sorted = walk_sorted_by_rule(t) ? 1 : 0;
+    t->ladder_scalar = 0;
 }
 
-static void tune_deep_tree(st_tree *t, const TreeTables &T)
+// ---- persistent record of what a tree measured -------------------------------------------------------------
+// Results are identical whatever the choice, but a handle's kernel should not change from run to run because a
+// busy GPU flipped a close race: the decision is written to a small file keyed by (tree digest, device name,
+// build of this library) and read back by later processes.  $SUCHTREE_AMD_CACHE_DIR, else $XDG_CACHE_HOME/suchtree_amd,
+// else ~/.cache/suchtree_amd; SUCHTREE_AMD_TUNE_CACHE=0: neither read nor written.  Never an error.
+static uint64_t tree_digest(const TreeTables &T)
+{
+    uint64_t h = 1469598103934665603ull;      // FNV-1a over the {parent, distance} table, eight bytes at a time
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(T.nodes.data());
+    for (int64_t k = 0; k < T.n; k++) { h ^= w[k]; h *= 1099511628211ull; }
+    h ^= (uint64_t)T.n; h *= 1099511628211ull;
+    return h;
+}
+
+static std::string tune_cache_path(const st_tree *t, const TreeTables &T, const char *device_name)
+{
+    if (const char *env = std::getenv("SUCHTREE_AMD_TUNE_CACHE"))
+        if (env[0] == '0') return std::string();
+    std::string dir;
+    if (const char *env = std::getenv("SUCHTREE_AMD_CACHE_DIR")) dir = env;
+    else if (const char *xdg = std::getenv("XDG_CACHE_HOME")) dir = std::string(xdg) + "/suchtree_amd";
+    else if (const char *home = std::getenv("HOME")) dir = std::string(home) + "/.cache/suchtree_amd";
+    if (dir.empty()) return std::string();
+    uint64_t h = tree_digest(T);
+    for (const char *c = device_name; c && *c; c++) { h ^= (uint64_t)(unsigned char)*c; h *= 1099511628211ull; }
+    for (const char *c = __DATE__ " " __TIME__; *c; c++) { h ^= (uint64_t)(unsigned char)*c; h *= 1099511628211ull; }      // (a rebuilt library measures again)
+    h ^= (uint64_t)t->n_cu; h *= 1099511628211ull;
+    char name[64];
+    std::snprintf(name, sizeof name, "/tune-%016llx.txt", (unsigned long long)h);
+    return dir + name;
+}
+
+static bool tune_cache_read(const std::string &path, int &tile_sort, int &ppl, int &walk, int &ladder)
+{
+    if (path.empty()) return false;
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    int a = -1, b = -1, c = -1, d = -1;
+    const int got = std::fscanf(f, "%d %d %d %d", &a, &b, &c, &d);
+    std::fclose(f);
+    if (got != 4 || (a != 0 && a != 1) || b < 0 || b > 2 || (c != 0 && c != 1) || (d != 0 && d != 1)) return false;
+    tile_sort = a; ppl = b; walk = c; ladder = d;
+    return true;
+}
+
+static void tune_cache_write(const std::string &path, int tile_sort, int ppl, int walk, int ladder)
+{
+    if (path.empty()) return;
+    const size_t slash = path.rfind('/');
+    const std::string dir = path.substr(0, slash);
+    for (size_t k = 1; k <= dir.size(); k++)      // mkdir -p
+        if (k == dir.size() || dir[k] == '/') (void)::mkdir(dir.substr(0, k).c_str(), 0777);
+    const std::string tmp = path + ".tmp." + std::to_string((long long)::getpid());
+    FILE *f = std::fopen(tmp.c_str(), "w");
+    if (!f) return;
+    std::fprintf(f, "%d %d %d %d\n", tile_sort, ppl, walk, ladder);
+    std::fclose(f);
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
+// A candidate has to beat the rule's own choice by this much before the handle departs from it (timing noise on a
+// shared GPU is a few per cent; the gaps that matter are 1.3-4x).
+constexpr float kTuneMargin = 0.93f;
+
+static void copy_tuned_settings(st_tree *to, const st_tree *from)
+{
+    to->tile_sort = from->tile_sort;
+    to->pairs_per_lane = from->pairs_per_lane;
+    to->prefer_walk_sorted = from->prefer_walk_sorted;
+    to->ladder_scalar = from->ladder_scalar;
+    to->info.tuned = from->info.tuned;
+}
+
+static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_name)
 {
     rule_for_deep_tree(t);
     if (const char *env = std::getenv("SUCHTREE_AMD_AUTOTUNE"))
         if (env[0] == '0') return;
+    const std::string cache = tune_cache_path(t, T, device_name);
+    {
+        int a, b, c, d;
+        if (tune_cache_read(cache, a, b, c, d)) {
+            // (a recorded choice the handle cannot serve -- other table budget, other options -- is ignored)
+            const int keep_sort = t->tile_sort, keep_ppl = t->pairs_per_lane, keep_walk = t->prefer_walk_sorted;
+            t->tile_sort = a; t->pairs_per_lane = b; t->prefer_walk_sorted = c; t->ladder_scalar = d;
+            const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_scalar_ready(t));
+            if (ok) { t->info.tuned = 2; return; }
+            t->tile_sort = keep_sort; t->pairs_per_lane = keep_ppl; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = 0;
+        }
+    }
     // sample: uniform random leaf pairs (the reference's typical query, and the bench's)
     std::vector<int32_t> leaves;
     {
@@ -45,7 +139,13 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T)
             if (!has_child[(size_t)x]) leaves.push_back((int32_t)x);
     }
     if (leaves.size() < 2) return;
-    const int64_t n = kTunePairs;
+    int64_t n = kTunePairs;
+    {   // 28 bytes per sampled pair: a quarter of the sample when that is more than 1/8 of the free HBM, none below 1/2
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+        if ((size_t)n * 28 > free_b / 8) n >>= 2;
+        if ((size_t)n * 28 + leaves.size() * 4 > free_b / 2) return;
+    }
     int32_t *d_leaves = nullptr;
     long long *d_pairs = nullptr;
     double *d_dist = nullptr;
@@ -65,14 +165,15 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T)
         ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     }
     // milliseconds of the fastest of three launches after one warm-up, or a negative number
-    auto time_settings = [&](int tile_sort, int ppl, int walk) -> float {
+    auto time_settings = [&](int tile_sort, int ppl, int walk, int ladder) -> float {
         t->tile_sort = tile_sort;
         t->pairs_per_lane = ppl;
         t->prefer_walk_sorted = walk;
+        t->ladder_scalar = ladder;
         float best = -1.0f;
         for (int rep = 0; rep < 4; rep++) {
             if (hipEventRecord(e0, stream) != hipSuccess) return -1.0f;
-            if (enqueue_src(t, SrcContig{d_pairs}, n, DistSink{d_dist, nullptr}, d_mrca, t->d_fault, stream) != ST_OK) return -1.0f;
+            if (enqueue_src(t, SrcContig{d_pairs}, n, DistSink{d_dist, nullptr}, MrcaSink{d_mrca, nullptr}, t->d_fault, stream) != ST_OK) return -1.0f;
             if (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.0f;
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0f;
@@ -82,28 +183,40 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T)
     };
     if (ok) {
         const int rule_sort = t->tile_sort, rule_ppl = t->pairs_per_lane, rule_walk = t->prefer_walk_sorted;
-        // the canopy family's two forms first; the walk kernel has to beat the better of them
-        int best_sort = rule_sort, best_ppl = rule_ppl;
-        float best_ms = -1.0f;
-        if (sorted_q(t) > 0) best_ms = time_settings(1, 0, 0), best_sort = 1, best_ppl = 0;
-        const float ilp_ms = time_settings(0, 1, 0);
-        if (ilp_ms > 0.0f && (best_ms < 0.0f || ilp_ms < best_ms)) best_ms = ilp_ms, best_sort = 0, best_ppl = 1;
-        int best_walk = 0;
+        struct Cand { int sort, ppl, walk, ladder; float ms; };
+        std::vector<Cand> cands;
+        if (sorted_q(t) > 0) cands.push_back({1, 0, 0, 0, -1.0f});
+        cands.push_back({0, 1, 0, 0, -1.0f});
+        t->ladder_scalar = 1;
+        t->tile_sort = 0;
+        if (ladder_scalar_ready(t)) cands.push_back({0, 1, 0, 1, -1.0f});
+        t->ladder_scalar = 0;
         t->prefer_walk_sorted = 1;
-        if (prefers_walk_sorted(t, n, true)) {
-            const float walk_ms = time_settings(best_sort, best_ppl, 1);
-            if (walk_ms > 0.0f && (best_ms < 0.0f || walk_ms < best_ms)) best_ms = walk_ms, best_walk = 1;
+        if (prefers_walk_sorted(t, n, true)) cands.push_back({rule_sort, rule_ppl, 1, 0, -1.0f});
+        for (Cand &c : cands) c.ms = time_settings(c.sort, c.ppl, c.walk, c.ladder);
+        const Cand *best = nullptr, *rule = nullptr;
+        for (const Cand &c : cands) {
+            if (c.ms <= 0.0f) continue;
+            if (!best || c.ms < best->ms) best = &c;
+            // the rule's choice among the candidates (with the walk kernel chosen, the canopy settings behind it do not matter)
+            if (c.walk == rule_walk && !c.ladder && (c.walk || (c.sort == rule_sort && c.ppl == rule_ppl))) rule = &c;
         }
-        if (best_ms > 0.0f) {
-            t->tile_sort = best_sort;
-            t->pairs_per_lane = best_ppl;
-            t->prefer_walk_sorted = best_walk;
+        if (best && rule && best != rule && best->ms > kTuneMargin * rule->ms) best = rule;      // too close to call: the rule stands
+        if (best) {
+            t->tile_sort = best->walk ? rule_sort : best->sort;
+            t->pairs_per_lane = best->walk ? rule_ppl : best->ppl;
+            t->prefer_walk_sorted = best->walk;
+            t->ladder_scalar = best->ladder;
             t->info.tuned = 1;
+            tune_cache_write(cache, t->tile_sort, t->pairs_per_lane, t->prefer_walk_sorted, t->ladder_scalar);
         } else {
             t->tile_sort = rule_sort;
             t->pairs_per_lane = rule_ppl;
             t->prefer_walk_sorted = rule_walk;
+            t->ladder_scalar = 0;
         }
+    } else {
+        rule_for_deep_tree(t);
     }
     (void)hipGetLastError();
     if (e0) (void)hipEventDestroy(e0);

@@ -161,7 +161,9 @@ struct TreeOwner {
     }
 };
 
-static int upload_tree(BuiltTables &B, int device, st_tree **out)
+// tune: time the candidate kernels of a deep tree on this device (host_tune.h); peers of a multi-device handle take
+// the primary's settings instead.
+static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = true)
 {
     TreeTables &T = B.T;
     int n_dev = 0;
@@ -281,9 +283,10 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out)
     t->info.n_devices = 1;
     t->info.device_bytes = bytes;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
-    if (B.deep) {      // (host_tune.h: the kernel of large batches, by timing the candidates; the rule's defaults if that fails)
+    if (B.deep && !tune) rule_for_deep_tree(t);
+    if (B.deep && tune) {      // (host_tune.h: the kernel of large batches, by timing the candidates; the rule's defaults if that fails)
         try {
-            tune_deep_tree(t, T);
+            tune_deep_tree(t, T, prop.gcnArchName);
         } catch (...) {
             rule_for_deep_tree(t);
             t->info.tuned = 0;

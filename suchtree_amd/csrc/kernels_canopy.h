@@ -162,26 +162,104 @@ __device__ __forceinline__ void stage_ladder(const CanopyParams &P, unsigned cha
 template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src, long long n,
                                                          DistSink out_d,
-                                                         int *__restrict__ out_m, Fault *fault)
+                                                         MrcaSink out_m, Fault *fault)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     stage_canopy(P, lds_raw);
 
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-            (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-            record_fault(fault, a, b, P.n_nodes);
-            store_result(out_d, out_m, i, __builtin_nanf(""), -1);
-            continue;
+    // (the trip count is uniform over the workgroup and results leave from one converged place: store_mrca_wave)
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const long long i = base + threadIdx.x;
+        const bool live = i < n;
+        PairResult r;
+        r.dist = __builtin_nanf("");
+        r.mrca = -1;
+        if (live) {
+            long long a, b;
+            src.load(i, a, b);
+            if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
+                (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+                record_fault(fault, a, b, P.n_nodes);
+            } else {
+                const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
+                const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
+                r = canopy_pair_scalar<CAP, false>(P, lds_raw, sa, sb, rec_bytes);
+            }
         }
-        const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
-        const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
-        const PairResult r = canopy_pair_scalar<CAP, false>(P, lds_raw, sa, sb, rec_bytes);
-        store_result(out_d, out_m, i, r.dist, r.mrca);
+        store_result_wave(out_d, out_m, i, r.dist, r.mrca, live);
+    }
+}
+
+// b's record (L.rb set) for long chains: the first 128-byte line at once, of a 63-slot chain's second line only the
+// 16-byte chunks that hold slots in use, once the length is there (k_canopy_ilp reads its records the same way).
+template <int CAP>
+__device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
+{
+    if constexpr (CAP <= 31) {
+        load_rec_b<CAP>(L);
+    } else {
+        uint32_t w[CAP + 1];
+        constexpr int kChunks = (CAP + 1) / 4, kEager = 8;
+#pragma unroll
+        for (int q = 0; q < kEager; q++) {
+            const uint4 x = reinterpret_cast<const uint4 *>(L.rb)[q];
+            w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+        }
+        L.wb = w[0];
+#pragma unroll
+        for (int q = kEager; q < kChunks; q++) {
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)(4 * q) <= (L.wb >> 16)) x = reinterpret_cast<const uint4 *>(L.rb)[q];      // slots 4q-1 .. 4q+2
+            w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int q = 0; q < CAP; q++) L.Db[q] = __uint_as_float(w[q + 1]);
+    }
+}
+
+// Scalar kernel over the LADDER image (deep canopies whose records are too long for the tile-sorted kernel's second
+// read of them: 1e6-leaf trees a few hundred levels deep, 63-slot chains).  Records are read once, in input order,
+// the chain stays in registers; with in-order ids the meeting node comes from the canopy's sparse table (two rank
+// reads and two table reads, all cache resident), so both sides climb with known edge counts, three edges per
+// 16-byte LDS read: max k_a / 3 + max k_b / 3 dependent LDS reads per wave where the predicated kernel's depth cut
+// takes max(k_a, k_b) + max k_b rounds of two reads each.  Without the table: the lock-step search on the ladder.
+template <int CAP, typename Src>
+__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ladder(CanopyParams P, Src src, long long n,
+                                                                DistSink out_d, MrcaSink out_m, Fault *fault)
+{
+    static_assert(CAP == 15 || CAP == 31 || CAP == 63, "long chains in registers");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    stage_ladder(P, lds_raw);
+    constexpr int rec_bytes = 8 * (CAP + 1);
+    const bool parity = P.parity != 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const long long i = base + threadIdx.x;
+        const bool live = i < n;
+        PairResult r;
+        r.dist = __builtin_nanf("");
+        r.mrca = -1;
+        if (live) {
+            long long a, b;
+            src.load(i, a, b);
+            if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+                record_fault(fault, a, b, P.n_nodes);
+            } else {
+                const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+                PairRecs<CAP> L;
+                L.rb = P.rec_b + sb * (rec_bytes / 2);
+                const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+                L.wa = va.x;
+                L.pbot_a = __uint_as_float(va.y);
+                load_rec_b_lazy<CAP>(L);
+                const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
+                const uint32_t meet = (P.rmq && pa != pb) ? canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb) : 0xFFFFFFFFu;
+                r = canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, meet);
+            }
+        }
+        store_result_wave(out_d, out_m, i, r.dist, r.mrca, live);
     }
 }
 
@@ -196,7 +274,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src
 template <int CAP, int PPL, typename Src, bool A4 = false>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              DistSink out_d,
-                                                             int *__restrict__ out_m, Fault *fault)
+                                                             MrcaSink out_m, Fault *fault)
 {
     static_assert(CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15 || ((CAP == 31 || CAP == 63) && PPL == 1), "register-resident chains only");
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -350,12 +428,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             }
         }
 #pragma unroll
-        for (int j = 0; j < PPL; j++) {
-            if (live[j]) {
-                if (valid[j]) store_result(out_d, out_m, idx[j], s[j], m[j]);
-                else store_result(out_d, out_m, idx[j], __builtin_nanf(""), -1);
-            }
-        }
+        for (int j = 0; j < PPL; j++)      // (converged: every lane of the workgroup is here, with consecutive pair numbers)
+            store_result_wave(out_d, out_m, base + (long long)j * blockDim.x + threadIdx.x, valid[j] ? s[j] : __builtin_nanf(""),
+                              valid[j] ? m[j] : -1, live[j]);
     }
 }
 
@@ -367,27 +442,32 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 // CAP: chain slots of the tree's records when the shared-portal case compares them in registers (1 ... 31), 0: by
 // the loop (longer chains).
 template <int CAP, typename Src>
-__global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, long long n, int *__restrict__ out_m, Fault *fault)
+__global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, long long n, MrcaSink out_m, Fault *fault)
 {
     const bool parity = P.parity != 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-            record_fault(fault, a, b, P.n_nodes);
-            out_m[i] = -1;
-            continue;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {      // (uniform trip count: store_mrca_wave)
+        const long long i = base + threadIdx.x;
+        const bool live = i < n;
+        int m = -1;
+        if (live) {
+            long long a, b;
+            src.load(i, a, b);
+            if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+                record_fault(fault, a, b, P.n_nodes);
+            } else {
+                const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+                const uint32_t ra = P.rec_r[sa], rb = P.rec_r[sb];
+                if (ra != rb) {
+                    m = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
+                } else {      // shared portal: the MRCA is the portal or lies in the understory
+                    const RecTables R{P.rec_a, P.rec_b, P.rec_i, CAP > 0 ? 4 * (CAP + 1) : P.rec_bytes / 2};
+                    if constexpr (CAP > 0) m = mrca_same_portal_regs<CAP>(P.canopy_id, R, sa, sb);
+                    else m = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
+                }
+            }
         }
-        const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-        const uint32_t ra = P.rec_r[sa], rb = P.rec_r[sb];
-        if (ra != rb) {
-            out_m[i] = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
-        } else {      // shared portal: the MRCA is the portal or lies in the understory
-            const RecTables R{P.rec_a, P.rec_b, P.rec_i, CAP > 0 ? 4 * (CAP + 1) : P.rec_bytes / 2};
-            if constexpr (CAP > 0) out_m[i] = mrca_same_portal_regs<CAP>(P.canopy_id, R, sa, sb);
-            else out_m[i] = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
-        }
+        store_mrca_wave(out_m, i, m, live);
     }
 }
 

@@ -27,7 +27,7 @@ namespace st {
 // modes stay below 64, which is what lets two of their workgroups share a CU).
 template <int CAP, int Q, bool SUMS, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, Src src, long long n,
-                                                                DistSink out_d, int *__restrict__ out_m,
+                                                                DistSink out_d, MrcaSink out_m,
                                                                 Fault *fault, int key_shift)
 {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -103,25 +103,31 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                 if (want_d)
                     side_[q] = P.lineage[(size_t)(va_[q].y & 0x0FFFFFFFu) + ((va_[q].x >> 16) - (uint32_t)(e1_[q] >> 32))];
             }
+            // The MRCA ids are known here and leave at once, coalesced (converged: every lane of the workgroup is here).
+            // Pairs that share a portal (their id follows from the sorted phase: store_mrca) leave a zero.
+            if (out_m.any()) {
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const bool shared = (va_[q].x & 0xFFFFu) == (vb_[q].x & 0xFFFFu);
+                    store_mrca_wave(out_m, base + (int)threadIdx.x + q * kCanopyBlock,
+                                    !valid_[q] ? -1 : shared ? 0 : (int)(uint32_t)e1_[q], in_[q]);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int j = (int)threadIdx.x + q * kCanopyBlock;
-                const long long i = base + j;
                 key[q] = 0xFFFFFFFFu;
                 rank[q] = 0;
                 if (!in_[q]) continue;
                 if (!valid_[q]) {
                     record_fault(fault, a_[q], b_[q], P.n_nodes);
                     SIDE_A[j] = __builtin_nanf("");      // (the distances of the tile leave LDS together, below)
-                    if (out_m) out_m[i] = -1;
                     continue;
                 }
                 uint32_t k = 0;
                 if ((va_[q].x & 0xFFFFu) == (vb_[q].x & 0xFFFFu)) {     // shared portal: left to the general form
                     MEET[j] = 0xFFFFFFFFu;
                 } else {
-                    // the MRCA id is known here and leaves at once, coalesced
-                    if (out_m) out_m[i] = (int)(uint32_t)e1_[q];
                     if (!want_d) continue;      // MRCA ids only: this pair is done
                     const uint32_t kb = (vb_[q].x >> 16) - (uint32_t)(e1_[q] >> 32);
                     MEET[j] = kb;
@@ -190,6 +196,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
 #pragma unroll
         for (int q = 0; q < Q; q++)
             if (key[q] != 0xFFFFFFFFu) PERM[HIST[key[q]] + rank[q]] = (uint16_t)((int)threadIdx.x + q * kCanopyBlock);
+        // packed MRCA ids: the key phase's dword stores have left a zero where a shared-portal pair's id will go, and
+        // the sorted phase writes those three bytes from another wave -- make sure the dwords have landed first
+        if (have_sums && out_m.m24) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t total = WSUM[4];
         // wave w: sorted groups w, 31 - w, 32 + w, 63 - w (short pairs with long pairs)
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                                                               record_slot(b, parity, P.n_leaves), rec_bytes, 0xFFFFFFFFu);
                         }
                         dist = r.dist;
-                        if (out_m) out_m[base + j] = r.mrca;
+                        store_mrca(out_m, base + j, r.mrca);
                     }
                     SIDE_A[j] = dist;      // the pair's scratch word has served: its distance waits there
                 }
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
                     const int j = (int)threadIdx.x + q * kCanopyBlock;
-                    if (base + j < n) store_result(out_d, nullptr, base + j, SIDE_A[j], 0);
+                    if (base + j < n) store_dist(out_d, base + j, SIDE_A[j]);
                 }
             }
         } else {

@@ -20,25 +20,29 @@ struct WalkParams {
 
 template <typename Src>
 __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n,
-                                              DistSink out_d, int *__restrict__ out_m,
+                                              DistSink out_d, MrcaSink out_m,
                                               Fault *fault)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-            (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-            record_fault(fault, a, b, P.n_nodes);
-            store_result(out_d, out_m, i, __builtin_nanf(""), -1);
-            continue;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {      // (uniform trip count: store_mrca_wave)
+        const long long i = base + threadIdx.x;
+        const bool live = i < n;
+        PairResult r;
+        r.dist = __builtin_nanf("");
+        r.mrca = -1;
+        if (live) {
+            long long a, b;
+            src.load(i, a, b);
+            if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
+                (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+                record_fault(fault, a, b, P.n_nodes);
+            } else if (out_d.any()) {
+                r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, P.rmq, P.n_nodes, P.lineage);
+            } else {
+                r.mrca = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, nullptr, P.rmq, P.n_nodes);
+            }
         }
-        if (out_d.any()) {
-            const PairResult r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, P.rmq, P.n_nodes, P.lineage);
-            store_result(out_d, out_m, i, r.dist, r.mrca);
-        } else {
-            out_m[i] = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b, nullptr, P.rmq, P.n_nodes);
-        }
+        store_result_wave(out_d, out_m, i, r.dist, r.mrca, live);
     }
 }
 
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
 // read; only the nodes below the portal are streamed from global memory.
 template <int Q, bool LADDER, typename Src>
 __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Src src, long long n, DistSink out_d,
-                                                                 int *__restrict__ out_m, Fault *fault, int key_shift)
+                                                                 MrcaSink out_m, Fault *fault, int key_shift)
 {
     extern __shared__ __align__(16) unsigned char walk_lds_all[];
     const LadderEntry *LAD = reinterpret_cast<const LadderEntry *>(walk_lds_all);
@@ -128,20 +132,23 @@ __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Sr
                 e1_[q] = e2_[q] < e1_[q] ? e2_[q] : e1_[q];      // the meeting node: depth << 32 | id
                 side_[q] = lin.sums[(size_t)ka_[q].off + (size_t)(ka_[q].depth - (uint32_t)(e1_[q] >> 32))];
             }
+            // the MRCA ids leave at once, coalesced (converged: every lane of the workgroup is here)
+            if (out_m.any()) {
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+                    store_mrca_wave(out_m, base + (int)threadIdx.x + q * kWalkSortBlock, valid_[q] ? (int)(uint32_t)e1_[q] : -1, in_[q]);
+            }
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int j = (int)threadIdx.x + q * kWalkSortBlock;
-                const long long i = base + j;
                 key[q] = 0xFFFFFFFFu;
                 rank[q] = 0;
                 if (!in_[q]) continue;
                 if (!valid_[q]) {
                     record_fault(fault, a_[q], b_[q], P.n_nodes);
                     SIDE[j] = __builtin_nanf("");
-                    if (out_m) out_m[i] = -1;
                     continue;
                 }
-                if (out_m) out_m[i] = (int)(uint32_t)e1_[q];
                 const uint32_t kb = kb_[q].depth - (uint32_t)(e1_[q] >> 32);
                 KB[j] = kb | ((kb_[q].nb_rank & 0xFFu) << 24);      // (k_b < 2^24: the lineage tables exist)
                 SIDE[j] = side_[q];
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Sr
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 const int j = (int)threadIdx.x + q * kWalkSortBlock;
-                if (base + j < n) store_result(out_d, nullptr, base + j, SIDE[j], 0);
+                if (base + j < n) store_dist(out_d, base + j, SIDE[j]);
             }
         }
         __syncthreads();     // the next tile overwrites the scratch

@@ -22,7 +22,7 @@ namespace st {
 
 template <typename Kern, typename Src>
 static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const CanopyParams &P,
-                                  const Src &src, int64_t n, DistSink out_d, int32_t *out_m,
+                                  const Src &src, int64_t n, DistSink out_d, MrcaSink out_m,
                                   Fault *fault, hipStream_t stream, size_t lds = 0)
 {
     if (lds == 0) lds = canopy_lds_bytes(t);
@@ -45,11 +45,16 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
 
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                  DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
+                                  DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
     if (t->tile_sort && sorted_q(t) > 0)
         return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
+    // the scalar ladder kernel (option ladder_scalar; deep trees: set when the tree is created, host_tune.h)
+    if constexpr (CAP == 15 || CAP == 31 || CAP == 63) {
+        if (t->ladder_scalar && P.ladder && ladder_image_bytes(t->canopy_nodes) <= 160 * 1024)
+            return launch_canopy_k(k_canopy_ladder<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream, ladder_image_bytes(t->canopy_nodes));
+    }
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     } else if constexpr (CAP == 31 || CAP == 63) {
@@ -77,7 +82,7 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
 
 template <typename Src>
 hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                                int32_t *out_m, Fault *fault, hipStream_t stream)
+                                MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     CanopyParams P;
     P.canopy = t->d_canopy;
@@ -102,7 +107,7 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
     P.canopy_nodes = t->canopy_nodes;
     P.rec_bytes = t->rec_bytes;
     P.parity = t->parity;
-    if (!out_d.any() && out_m && P.rec_r && P.rmq64 && t->mrca_ranks) {
+    if (!out_d.any() && out_m.any() && P.rec_r && P.rmq64 && t->mrca_ranks) {
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)t->n_cu * 8));
         switch (t->rec_cap) {      // (chains of up to 31 slots: the shared-portal case compares them in registers)
             case 1: hipLaunchKernelGGL((k_mrca_ranks<1, Src>), dim3((unsigned)blocks), dim3(256), 0, stream, P, src, (long long)n, out_m, fault); break;
@@ -132,7 +137,7 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
 
 
 #define ST_INSTANTIATE_CANOPY(S) \
-    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);
+    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
 ST_FOR_EACH_SRC(ST_INSTANTIATE_CANOPY)
 
 }  // namespace st

@@ -24,7 +24,7 @@ namespace st {
 
 template <int CAP, typename Src>
 hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                       DistSink out_d, int32_t *out_m, Fault *fault, hipStream_t stream)
+                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     const SortedShape shape = sorted_shape(t);
     const int q = batch_tile_q(shape.q, shape.sums ? 1 : 2, t->sort_tile, n, t->n_cu);      // (instantiated: 1, 2, 4 with lineage sums, else 2, 4)
@@ -57,12 +57,12 @@ hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const S
 
 
 #define ST_INSTANTIATE_SORTED(S)                                                                                                       \
-    template hipError_t launch_canopy_sorted<0, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);  \
-    template hipError_t launch_canopy_sorted<1, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);  \
-    template hipError_t launch_canopy_sorted<3, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);  \
-    template hipError_t launch_canopy_sorted<7, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);  \
-    template hipError_t launch_canopy_sorted<15, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t); \
-    template hipError_t launch_canopy_sorted<31, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);
+    template hipError_t launch_canopy_sorted<0, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
+    template hipError_t launch_canopy_sorted<1, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
+    template hipError_t launch_canopy_sorted<3, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
+    template hipError_t launch_canopy_sorted<7, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
+    template hipError_t launch_canopy_sorted<15, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t); \
+    template hipError_t launch_canopy_sorted<31, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
 // The instantiations are the slowest part of the build (~50 s in one piece): the file is compiled three times,
 // -DST_SORTED_PART=0 / 1 / 2, each part with two of the six pair sources (build.py).
 #ifndef ST_SORTED_PART

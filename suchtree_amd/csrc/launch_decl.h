@@ -13,18 +13,18 @@ namespace st {
 
 // canopy family (launch_canopy.hip; k_canopy_sorted behind it in launch_canopy_sorted.hip)
 template <typename Src>
-hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d, int32_t *out_m, Fault *fault,
+hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d, MrcaSink out_m, Fault *fault,
                          hipStream_t stream);
 // walk family (launch_walk.hip): k_walk or, for large batches on trees with the tables, k_walk_sorted
 template <typename Src>
-hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d, int32_t *out_m, Fault *fault,
+hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d, MrcaSink out_m, Fault *fault,
                        hipStream_t stream);
 
 #define ST_FOR_EACH_SRC(X) X(SrcContig) X(SrcContig32) X(SrcStrided) X(SrcTriangle) X(SrcGrid) X(SrcQuartet)
 #ifndef ST_LAUNCH_UNIT
 #define ST_EXTERN_LAUNCH(S)                                                                                              \
-    extern template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t); \
-    extern template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);
+    extern template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t); \
+    extern template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
 ST_FOR_EACH_SRC(ST_EXTERN_LAUNCH)
 #undef ST_EXTERN_LAUNCH
 #endif

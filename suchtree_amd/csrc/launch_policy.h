@@ -80,6 +80,13 @@ static inline int64_t canopy_min_pairs(const st_tree *t)
     return t->tile_sort && t->d_lineage && t->d_rec_p && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
 }
 
+// k_canopy_ladder (launch_canopy.hip): option on, tile sort off, records of 128 bytes and more, ladder image fits LDS
+static inline bool ladder_scalar_ready(const st_tree *t)
+{
+    return t->strategy == ST_STRATEGY_CANOPY && t->ladder_scalar && !(t->tile_sort && sorted_q(t) > 0) && t->d_ladder &&
+           (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap == 63) && ladder_image_bytes(t->canopy_nodes) <= 160 * 1024;
+}
+
 static inline bool mrca_ranks_ready(const st_tree *t)
 {
     return t->strategy == ST_STRATEGY_CANOPY && t->mrca_ranks && t->d_rec_r && t->d_rmq64;

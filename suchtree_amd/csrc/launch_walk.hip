@@ -43,7 +43,7 @@ static WalkParams walk_params(const st_tree *t)
 
 template <int Q, bool LADDER, typename Src>
 static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, const Src &src, int64_t n, DistSink out_d,
-                                     int32_t *out_m, Fault *fault, hipStream_t stream)
+                                     MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     constexpr int64_t tile = (int64_t)Q * kWalkSortBlock;
     const size_t lds = walk_sort_scratch_bytes(Q) + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
@@ -62,7 +62,7 @@ static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, cons
 
 template <typename Src>
 hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                              int32_t *out_m, Fault *fault, hipStream_t stream)
+                              MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     const WalkParams P = walk_params(t);
     if (out_d.any() && n >= walk_sorted_min_pairs(t) && walk_sorted_ready(t)) {
@@ -93,7 +93,7 @@ hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out
 
 
 #define ST_INSTANTIATE_WALK(S) \
-    template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, int32_t *, Fault *, hipStream_t);
+    template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
 ST_FOR_EACH_SRC(ST_INSTANTIATE_WALK)
 
 hipError_t launch_walk_mailbox(const st_tree *t, const long long *d_pairs, int n, double *d_dist, int *d_mrca,

@@ -236,8 +236,9 @@ try {
     primary->peers.reserve((size_t)n_devices);
     for (int i = 1; i < n_devices; i++) {
         st_tree *peer = nullptr;
-        rc = upload_tree(B, devices[i], &peer);
+        rc = upload_tree(B, devices[i], &peer, false);
         if (rc != ST_OK) return rc;
+        if (B.deep) copy_tuned_settings(peer, primary);      // one measurement per handle: every replica runs the same kernel
         primary->peers.push_back(peer);
     }
     primary->info.n_devices = n_devices;
@@ -292,6 +293,8 @@ try {
     *info = t->info;
     info->strategy = t->strategy;
     info->big_batch_kernel = big_batch_kernel_of(t);      // (follows the handle's current options)
+    info->host_wire_bytes_in = t->wire48 && t->n_nodes <= 0xFFFFFF ? 6 : 8;
+    info->host_wire_bytes_out = t->wire24 && t->n_nodes <= 0xFFFFFF ? 7 : 8;
     return ST_OK;
 } ST_CATCH_ALL
 
@@ -331,6 +334,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->tile_sort = (int)value;
         return ST_OK;
     }
+    if (std::strcmp(name, "ladder_scalar") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_scalar must be 0 or 1");
+        t->ladder_scalar = (int)value;
+        return ST_OK;
+    }
     if (std::strcmp(name, "tree_rmq") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tree_rmq must be 0 or 1");
         t->tree_rmq = (int)value;
@@ -359,6 +367,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "wire48") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "wire48 must be 0 or 1");
         t->wire48 = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "wire24") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "wire24 must be 0 or 1");
+        t->wire24 = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "sort_tile") == 0) {
@@ -415,7 +428,7 @@ try {
     if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
     if (!d_out_dist && !d_out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
     ST_DEVICE(t->device);
-    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{d_out_dist, nullptr}, d_out_mrca,
+    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{d_out_dist, nullptr}, MrcaSink{d_out_mrca, nullptr},
                    reinterpret_cast<hipStream_t>(stream));
 } ST_CATCH_ALL
 
@@ -427,7 +440,7 @@ try {
     if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
     if (!d_out_dist && !d_out_mrca) return fail(ST_ERR_ARG, "both outputs are NULL");
     ST_DEVICE(t->device);
-    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{nullptr, d_out_dist}, d_out_mrca,
+    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{nullptr, d_out_dist}, MrcaSink{d_out_mrca, nullptr},
                    reinterpret_cast<hipStream_t>(stream));
 } ST_CATCH_ALL
 
@@ -459,7 +472,8 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
         ST_DEVICE(t->device);
         return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
     }
-    const HostOut out = make_host_out(out_dist, out_mrca, n);
+    HostOut out = make_host_out(out_dist, out_mrca, n);
+    out.wire24 = wire24_of(t, out);
     // fresh result arrays: ask for huge pages before the first touch (a no-op on resident memory)
     if (out_dist && !out.direct_d && !looks_resident(out_dist, n * 8)) advise_huge(out_dist, n * 8);
     if (out_mrca && !out.direct_m && !looks_resident(out_mrca, n * 4)) advise_huge(out_mrca, n * 4);
@@ -577,7 +591,7 @@ try {
     if (rc != ST_OK) return rc;
     ST_DEVICE(t->device);
     const SrcTriangle src{reinterpret_cast<const long long *>(d_ids), (long long)id_stride, (long long)k_begin};
-    return enqueue_src(t, src, k_count, DistSink{d_out_dist, nullptr}, d_out_mrca, t->d_fault,
+    return enqueue_src(t, src, k_count, DistSink{d_out_dist, nullptr}, MrcaSink{d_out_mrca, nullptr}, t->d_fault,
                        reinterpret_cast<hipStream_t>(stream));
 } ST_CATCH_ALL
 
@@ -587,7 +601,8 @@ try {
     int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
-    const HostOut out = make_host_out(out_dist, out_mrca, k_count);
+    HostOut out = make_host_out(out_dist, out_mrca, k_count);
+    out.wire24 = wire24_of(t, out);
     if (out_dist && !out.direct_d && !looks_resident(out_dist, k_count * 8)) advise_huge(out_dist, k_count * 8);
     if (out_mrca && !out.direct_m && !looks_resident(out_mrca, k_count * 4)) advise_huge(out_mrca, k_count * 4);
     // the id list goes up once per device (packed); results stream back through the pipe
@@ -639,7 +654,8 @@ try {
     if (rc != ST_OK) return rc;
     if (symmetric && (n_rows != n_cols)) return fail(ST_ERR_ARG, "symmetric grid needs n_rows == n_cols");
     if (e_count == 0) return ST_OK;
-    const HostOut out = make_host_out(out_dist, out_mrca, e_count);
+    HostOut out = make_host_out(out_dist, out_mrca, e_count);
+    out.wire24 = wire24_of(t, out);
     if (out_dist && !out.direct_d && !looks_resident(out_dist, e_count * 8)) advise_huge(out_dist, e_count * 8);
     if (out_mrca && !out.direct_m && !looks_resident(out_mrca, e_count * 4)) advise_huge(out_mrca, e_count * 4);
     auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
@@ -704,7 +720,7 @@ try {
     for (int64_t r0 = 0; r0 < n_queries; r0 += rows_per_block) {
         const int64_t rows = std::min(rows_per_block, n_queries - r0);
         const SrcGrid src{d_q + r0, d_c, (long long)n_cands, 0, 0};
-        const int rc = enqueue_src(t, src, rows * n_cands, DistSink{nullptr, d_tmp}, nullptr, t->d_fault_host, stream);
+        const int rc = enqueue_src(t, src, rows * n_cands, DistSink{nullptr, d_tmp}, MrcaSink{nullptr, nullptr}, t->d_fault_host, stream);
         if (rc != ST_OK) { (void)hipStreamSynchronize(stream); cleanup(); return rc; }
         hipLaunchKernelGGL(k_knn_select, dim3((unsigned)rows), dim3(256), 0, stream, d_tmp, (long long)n_cands,
                            d_q + r0, d_c, skip_self, k, d_oi + r0 * k, d_od + r0 * k);
@@ -784,7 +800,7 @@ try {
             // six MRCA ids per quartet out of the canopy / rank-table kernels, then the pick
             int32_t *tmp = static_cast<int32_t *>(t->q_tmp) + (size_t)slot_index * (size_t)chunk * 6;
             const int rc = enqueue_src(t, SrcQuartet{static_cast<const long long *>(s.d_in)}, 6 * m,
-                                       DistSink{nullptr, nullptr}, tmp, t->d_fault_host, s.stream);
+                                       DistSink{nullptr, nullptr}, MrcaSink{tmp, nullptr}, t->d_fault_host, s.stream);
             if (rc != ST_OK) return bail(rc, g_last_error);
             e = launch_quartet_pick(t, static_cast<const long long *>(s.d_in), static_cast<const int *>(tmp), m,
                                     reinterpret_cast<long long *>(out_of(s)), s.stream);

@@ -191,6 +191,68 @@ static int check_host_copy(std::mt19937_64 &rng)
         st::copy_stream(b.data() + bo, a.data() + ao, bytes);
         if (b != c) return 23;
     }
+    // the 24-bit wire formats: ids in (6 bytes per pair, packed by the host) and MRCA ids out (3 bytes per id, unpacked
+    // by the host), wide and scalar forms against byte-by-byte references, at every alignment of the packed stream
+    for (int round = 0; round < 300; round++) {
+        const int64_t m = (int64_t)(rng() % 3000);
+        const int64_t first = (int64_t)(rng() % 9);
+        const long long n_nodes = round % 5 == 0 ? 0xFFFFFF : 1 + (long long)(rng() % 3000000);
+        std::vector<int64_t> src64((size_t)(2 * m + 2));
+        std::vector<int32_t> src32((size_t)(2 * m + 2));
+        for (size_t q = 0; q < src64.size(); q++) {
+            src64[q] = (int64_t)(rng() % (uint64_t)n_nodes);
+            src32[q] = (int32_t)src64[q];
+        }
+        long long want_hi = std::numeric_limits<long long>::min(), want_lo = std::numeric_limits<long long>::max();
+        if (m > 0 && round % 2 == 0) {
+            for (int k = 0; k < 4; k++) {
+                const size_t at = (size_t)(rng() % (uint64_t)(2 * m));
+                const long long bad = k == 0 ? n_nodes : k == 1 ? -1 - (long long)(rng() % 99) : k == 2 ? n_nodes + (long long)(rng() % 5000) : 0x7FFFFFF0;
+                src64[at] = bad;
+                src32[at] = (int32_t)bad;
+                if (bad < 0) want_lo = std::min(want_lo, bad); else want_hi = std::max(want_hi, bad);
+            }
+        }
+        std::vector<uint8_t> want((size_t)(6 * (first + m) + 16), 0xAB), got64 = want, got32 = want, got_str = want;
+        for (int64_t k = 0; k < m; k++)
+            for (int c = 0; c < 2; c++) {
+                const long long v = src64[(size_t)(2 * k + c)];
+                const uint32_t id = (unsigned long long)v >= (unsigned long long)n_nodes ? 0xFFFFFFu : (uint32_t)v;
+                for (int b = 0; b < 3; b++) want[(size_t)(6 * (first + k) + 3 * c + b)] = (uint8_t)(id >> (8 * b));
+            }
+        // the packed stream starts 16-byte aligned in the product (a pinned slot): std::vector's storage is
+        alignas(16) static uint8_t slot[6 * 3016 + 32];
+        auto run = [&](auto *src, int64_t s0, int64_t s1, std::vector<uint8_t> &out, int code) -> int {
+            std::memset(slot, 0xAB, sizeof slot);
+            long long hi = std::numeric_limits<long long>::min(), lo = std::numeric_limits<long long>::max();
+            st::pack_pairs48(slot, first, src, m, s0, s1, n_nodes, hi, lo);
+            std::memcpy(out.data(), slot, out.size());
+            if (std::memcmp(out.data() + 6 * first, want.data() + 6 * first, (size_t)(6 * m)) != 0) return code;
+            for (int64_t q = 0; q < 6 * first; q++) if (out[(size_t)q] != 0xAB) return code + 1;       // nothing before the range
+            for (size_t q = (size_t)(6 * (first + m)); q < out.size(); q++) if (out[q] != 0xAB) return code + 1;      // nothing after
+            if (hi != want_hi || lo != want_lo) return code + 2;
+            return 0;
+        };
+        if (const int rc = run(src64.data(), 2, 1, got64, 30)) return rc;
+        if (const int rc = run(src32.data(), 2, 1, got32, 40)) return rc;
+        {   // strided view: every other row of a (2m, 2) array, columns swapped back
+            std::vector<int64_t> wide((size_t)(4 * m + 4), -77);
+            for (int64_t k = 0; k < m; k++) { wide[(size_t)(4 * k + 1)] = src64[(size_t)(2 * k)]; wide[(size_t)(4 * k)] = src64[(size_t)(2 * k + 1)]; }
+            if (const int rc = run(wide.data() + 1, 4, -1, got_str, 50)) return rc;
+        }
+        // MRCA ids back: 3 bytes per id, -1 as 0xFFFFFF
+        std::vector<int32_t> ids((size_t)m);
+        for (auto &v : ids) v = rng() % 7 == 0 ? -1 : (int32_t)(rng() % 0xFFFFFF);
+        if (m > 2) { ids[0] = 0xFFFFFE; ids[(size_t)m - 1] = 0; }
+        std::vector<uint8_t> packed((size_t)(4 * (first + m) + 4), 0xCD);      // (a staging slot has 4 bytes per pair)
+        for (int64_t k = 0; k < m; k++)
+            for (int b = 0; b < 3; b++) packed[(size_t)(3 * (first + k) + b)] = (uint8_t)((uint32_t)ids[(size_t)k] >> (8 * b));
+        const int so = (int)(rng() % 9);
+        std::vector<int32_t> back((size_t)(m + 12), 55), back_want((size_t)(m + 12), 55);
+        for (int64_t k = 0; k < m; k++) back_want[(size_t)(so + k)] = ids[(size_t)k];
+        st::unpack_ids24(back.data() + so, packed.data(), first, m);
+        if (back != back_want) return 60;
+    }
     // a fresh anonymous mapping is not resident; after populate_for_write it is
     const size_t len = (size_t)8 << 20;
     void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);

@@ -128,6 +128,118 @@ def test_24_bit_ids_on_the_wire_and_int32_ids_agree(tree17):
     dev.close()
 
 
+def test_24_bit_mrca_ids_on_the_way_back(tree17, ml_arrays):
+    """Trees with fewer than 2^24 nodes: MRCA ids come back over the link as 24 bits each (7 bytes per pair with the
+    float32 distance; option wire24 = 0: int32).  Every kernel the host path launches assembles the packed stream
+    itself (k_canopy_ilp, k_canopy, k_walk, k_mrca_ranks, both tile-sorted kernels' key phases; the staged form of
+    the tile-sorted canopy kernel packs in its copy kernel; pairs under one portal write their three bytes singly):
+    same bits as the int32 form and as the oracle, for batch sizes that are no multiple of a quad, MRCA ids alone,
+    generated pairs."""
+    rng = np.random.default_rng(2424)
+    ml_parent, ml_dist = ml_arrays
+    sizes = (8_193, 40_001, 262_147, 1_000_003)
+
+    def check(dev, pairs, want_d, want_m, what):
+        for n in sizes:
+            got = {}
+            for w24 in (1, 0):
+                dev.set_option("wire24", w24)
+                d, m = dev.distances_host(pairs[:n], True, True)
+                m_only = dev.distances_host(pairs[:n], False, True)[1]
+                got[w24] = (d, m, m_only)
+                k = min(n, len(want_m))
+                assert_bits_equal(d[:k], want_d[:k], "%s wire24=%d n=%d" % (what, w24, n))
+                assert np.array_equal(m[:k], want_m[:k]), (what, w24, n, np.flatnonzero(m[:k] != want_m[:k])[:8])
+                assert np.array_equal(m_only[:k], want_m[:k]), (what, w24, n, "MRCA ids alone")
+            assert_bits_equal(got[1][0], got[0][0], what)
+            assert np.array_equal(got[1][1], got[0][1]) and np.array_equal(got[1][2], got[0][2]), (what, n)
+        dev.set_option("wire24", 1)
+
+    # shallow canopy: the predicated kernel in its forms, the scalar kernel, the walk family
+    parent, dist, O = tree17
+    n_nodes = len(parent)
+    pairs = rng.integers(0, n_nodes, (sizes[-1], 2))
+    pairs[5] = (n_nodes - 1, n_nodes - 1)                  # the largest id of the tree as an MRCA
+    pairs[6] = (0, 0)
+    k = 120_000
+    want_d, want_m = O.distances(pairs[:k]), O.mrca_bulk(pairs[:k])
+    dev = _capi.DeviceTree(parent, dist)
+    for ppl in (1, 2, 0):
+        dev.set_option("pairs_per_lane", ppl)
+        check(dev, pairs, want_d, want_m, "2^17 leaves, pairs_per_lane=%d" % ppl)
+    dev.set_option("pairs_per_lane", 1)
+    dev.set_option("rec_a4", 0)
+    check(dev, pairs, want_d, want_m, "2^17 leaves, 8-byte a side")
+    dev.set_option("rec_a4", 1)
+    dev.set_strategy("walk")
+    check(dev, pairs, want_d, want_m, "2^17 leaves, walk family")
+    dev.set_strategy("auto")
+    ids = np.arange(0, 2 * 1500, 2, dtype=np.int64)
+    i, j = np.tril_indices(len(ids), -1)
+    tri_m = O.mrca_bulk(np.stack([ids[j], ids[i]], 1))
+    for w24 in (1, 0):
+        dev.set_option("wire24", w24)
+        assert np.array_equal(dev.triangle_host(ids, want_dist=True, want_mrca=True)[1], tri_m)
+    dev.set_option("wire24", 1)
+    dev.close()
+
+    # deep canopy: the tile-sorted kernels on the pinned slots, shared-portal pairs, the staged form
+    n_nodes = len(ml_parent)
+    a = rng.integers(0, n_nodes - 12, sizes[-1] // 2)
+    near = np.stack([a, a + rng.integers(0, 12, a.size)], 1)           # mostly one portal
+    far = rng.integers(0, n_nodes, (sizes[-1] - len(near), 2))
+    pairs = np.concatenate([near, far])[rng.permutation(sizes[-1])].astype(np.int64)
+    pairs[9] = (n_nodes - 1, n_nodes - 1)
+    k = 60_000
+    from conftest import oracle_both
+    want_d, want_m = oracle_both(ml_parent, ml_dist, pairs[:k])
+    dev = _capi.DeviceTree(ml_parent, ml_dist)
+    for opts in ({}, {"lineage_sums": 0}, {"tile_sort": 0, "pairs_per_lane": 1}, {"tile_sort": 0, "pairs_per_lane": 0},
+                 {"prefer_walk_sorted": 1}):
+        for name, v in opts.items():
+            dev.set_option(name, v)
+        check(dev, pairs, want_d, want_m, "ml.tree %s" % (opts or "default"))
+        for name in opts:
+            dev.set_option(name, {"lineage_sums": 1, "tile_sort": 1, "pairs_per_lane": 0, "prefer_walk_sorted": 0}[name])
+    dev.set_strategy("walk")
+    check(dev, pairs, want_d, want_m, "ml.tree, walk family")
+    dev.close()
+
+
+def test_wire_formats_at_the_2_24_node_boundary():
+    """A tree of 2^24 - 1 nodes (the largest the 24-bit formats serve; its largest id, 2^24 - 2, as an id and as an
+    MRCA) and one of 2^24 + 1 nodes (int32 both ways: ids 2^24 - 1 and 2^24 come back whole)."""
+    rng = np.random.default_rng(2**24)
+    for n_leaves, packed in ((1 << 23, True), ((1 << 23) + 1, False)):
+        parent, dist = (synth.balanced_tree(23) if packed else synth.random_binary_tree(n_leaves, seed=9))
+        n_nodes = len(parent)
+        assert n_nodes == 2 * n_leaves - 1 and (n_nodes <= 0xFFFFFF) == packed
+        dev = _capi.DeviceTree(parent, dist)
+        info = dev.info()
+        assert (info["host_wire_bytes_in"], info["host_wire_bytes_out"]) == ((6, 7) if packed else (8, 8)), info
+        pairs = rng.integers(0, n_nodes, (300_001, 2))
+        top = np.arange(n_nodes - 40, n_nodes, dtype=np.int64)
+        pairs[:40] = np.stack([top, top], 1)                  # MRCA = the id itself, up to n_nodes - 1
+        pairs[40:80] = np.stack([top, top[::-1]], 1)
+        O = OracleTree(parent, dist)
+        k = 20_000
+        want_d, want_m = O.distances(pairs[:k]), O.mrca_bulk(pairs[:k])
+        assert want_m[39] == n_nodes - 1
+        for w in (1, 0):
+            dev.set_option("wire24", w)
+            dev.set_option("wire48", w)
+            d, m = dev.distances_host(pairs, True, True)
+            assert_bits_equal(d[:k], want_d, "n_nodes=%d wire=%d" % (n_nodes, w))
+            assert np.array_equal(m[:k], want_m)
+            assert np.array_equal(dev.distances_host(pairs, False, True)[1][:k], want_m)
+            bad = pairs.copy()
+            bad[77, 1] = n_nodes
+            with pytest.raises(InvalidNodeError) as e:
+                dev.distances_host(bad, True, True)
+            assert e.value.node_id == n_nodes
+        dev.close()
+
+
 def test_host_and_device_paths_do_not_share_a_fault_word(tree17):
     import torch
     parent, dist, O = tree17

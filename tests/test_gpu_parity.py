@@ -653,7 +653,7 @@ def test_every_candidate_kernel_on_nj_tree(nj_arrays):
     dev.close()
 
 
-def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch):
+def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
     """Deep trees: the handle times its candidate kernels when it is created and makes the fastest its default
     (st_tree_info.tuned / big_batch_kernel); every candidate, forced by options, gives the same bits.  512-byte
     records (63-slot chains in registers in the predicated kernel), a batch large enough for every kernel."""
@@ -679,23 +679,36 @@ def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch):
         assert_bits_equal(out_d.cpu().numpy(), want_d, what)
         assert np.array_equal(out_m.cpu().numpy(), want_m), what
 
+    # the decision is recorded per (tree, device, library build): the first handle times (tuned = 1), later ones --
+    # in this or any other process -- read the record (tuned = 2) and run the same kernel
+    monkeypatch.setenv("SUCHTREE_AMD_CACHE_DIR", str(tmp_path / "tune"))
     dev = _capi.DeviceTree(parent, dist)
     info = dev.info()
     assert info["strategy"] == "canopy" and info["record_bytes"] == 512 and info["lineage_entries"] > 0, info
-    assert info["tuned"] == 1 and info["big_batch_kernel"] in ("canopy", "canopy_sorted", "walk_sorted"), info
+    assert info["tuned"] == 1 and info["big_batch_kernel"] in ("canopy", "canopy_sorted", "walk_sorted", "canopy_ladder"), info
+    assert len(list((tmp_path / "tune").glob("tune-*.txt"))) == 1
+    again = _capi.DeviceTree(parent, dist)
+    assert again.info()["tuned"] == 2 and again.info()["big_batch_kernel"] == info["big_batch_kernel"], again.info()
+    again.close()
+    monkeypatch.setenv("SUCHTREE_AMD_TUNE_CACHE", "0")
+    timed = _capi.DeviceTree(parent, dist)
+    assert timed.info()["tuned"] == 1
+    timed.close()
+    monkeypatch.delenv("SUCHTREE_AMD_TUNE_CACHE")
     run(dev, "default (%s)" % info["big_batch_kernel"])
     seen = set()
-    for sort, ppl, walk in ((1, 0, 0), (0, 1, 0), (0, 0, 0), (1, 0, 1)):
+    for sort, ppl, walk, ladder in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 1, 0), (0, 1, 0, 1)):
         dev.set_option("tile_sort", sort)
         dev.set_option("pairs_per_lane", ppl)
         dev.set_option("prefer_walk_sorted", walk)
+        dev.set_option("ladder_scalar", ladder)
         kernel = dev.info()["big_batch_kernel"]
         seen.add(kernel)
         run(dev, kernel)
         d, m = dev.distances_host(allp[:300_000], True, True)
         assert_bits_equal(d, want_d[:300_000], "host path, " + kernel)
         assert np.array_equal(m, want_m[:300_000])
-    assert seen == {"canopy_sorted", "canopy", "canopy_scalar", "walk_sorted"}, seen
+    assert seen == {"canopy_sorted", "canopy", "canopy_scalar", "walk_sorted", "canopy_ladder"}, seen
     dev.close()
     monkeypatch.setenv("SUCHTREE_AMD_AUTOTUNE", "0")
     dev = _capi.DeviceTree(parent, dist)
