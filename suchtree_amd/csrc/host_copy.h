@@ -17,8 +17,11 @@
 #include <unistd.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
+#include <vector>
 
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23   // Linux 5.14
@@ -226,6 +229,8 @@ inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, 
         std::memcpy(out + 6 * k, &w, 6);
     }
     const bool wide = cpu_has_avx2() && s0 == 2 && s1 == 1 && n_nodes >= 1 && n_nodes <= 0xFFFFFF;
+    // SUCHTREE_AMD_PACK_CACHED=1 (experiment): ordinary stores instead of streaming stores for the packed ids
+    static const bool cached = std::getenv("SUCHTREE_AMD_PACK_CACHED") != nullptr;
     for (; k + 4 <= m; k += 4) {
         long long *q = reinterpret_cast<long long *>(out + 6 * k);      // 8-byte aligned: dst is 16-byte aligned, 6 (first + k) is a multiple of 24
         uint64_t w[3];
@@ -240,9 +245,13 @@ inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, 
             w[1] = (p1 >> 16) | (p2 << 32);
             w[2] = (p2 >> 32) | (p3 << 16);
         }
-        _mm_stream_si64(q + 0, (long long)w[0]);
-        _mm_stream_si64(q + 1, (long long)w[1]);
-        _mm_stream_si64(q + 2, (long long)w[2]);
+        if (cached) {
+            q[0] = (long long)w[0]; q[1] = (long long)w[1]; q[2] = (long long)w[2];
+        } else {
+            _mm_stream_si64(q + 0, (long long)w[0]);
+            _mm_stream_si64(q + 1, (long long)w[1]);
+            _mm_stream_si64(q + 2, (long long)w[2]);
+        }
     }
     for (; k < m; k++) {
         const uint64_t w = one(k);
@@ -298,6 +307,52 @@ inline bool looks_resident(const void *p, int64_t bytes)
     }
     return true;
 }
+
+// Populates the pages of freshly allocated result arrays on threads of its own while the call's pipeline runs: the
+// first touch of 600 MB (5e7 pairs: float64 + int32) is 5 ms of page zeroing by the kernel, which the copy pool
+// used to do chunk by chunk BETWEEN its pack and unpack passes -- half of the host thread's time in a call that
+// returns fresh arrays.  Here K threads walk the arrays front to back in blocks of 2^18 pairs (thread t: blocks t,
+// t + K, ...), so the populated frontier stays ahead of the unpack passes, which start two chunks into the call; an
+// unpack pass that does catch up takes ordinary page faults for a while (populating a page twice is harmless).
+// join() before the call returns: the arrays are the caller's.
+class AsyncPrefault {
+public:
+    AsyncPrefault() = default;
+    AsyncPrefault(const AsyncPrefault &) = delete;
+    AsyncPrefault &operator=(const AsyncPrefault &) = delete;
+    ~AsyncPrefault() { join(); }
+
+    // dist (8 bytes per pair) and / or mrca (4 bytes per pair), n pairs; either may be NULL
+    void start(double *dist, int32_t *mrca, int64_t n, int n_threads)
+    {
+        if ((!dist && !mrca) || n <= 0 || n_threads < 1) return;
+        constexpr int64_t kBlock = (int64_t)1 << 18;
+        const int64_t blocks = (n + kBlock - 1) / kBlock;
+        const int k = (int)std::min<int64_t>(n_threads, blocks);
+        try {
+            for (int t = 0; t < k; t++)
+                threads_.emplace_back([=] {
+                    for (int64_t b = t; b < blocks; b += k) {
+                        const int64_t lo = b * kBlock, m = std::min(kBlock, n - lo);
+                        if (dist) populate_for_write(dist + lo, m * 8);
+                        if (mrca) populate_for_write(mrca + lo, m * 4);
+                    }
+                });
+        } catch (...) {      // (thread limit: the unpack passes take the page faults themselves)
+        }
+    }
+
+    bool active() const { return !threads_.empty(); }
+
+    void join()
+    {
+        for (auto &t : threads_) t.join();
+        threads_.clear();
+    }
+
+private:
+    std::vector<std::thread> threads_;
+};
 
 inline void advise_huge(void *p, int64_t bytes)
 {

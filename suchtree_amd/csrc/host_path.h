@@ -334,7 +334,19 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     // chunk is on the GPU -- not one fault at a time inside the unpack loops
     // (only pages that are not there yet: a recycled result array is resident already, and
     // populating resident pages costs more than everything else a mid-sized call does)
+    // large fresh arrays: on threads of their own, ahead of the unpack passes (host_copy.h: AsyncPrefault); the
+    // per-piece form below then finds the pages resident (or nearly so) and does nothing
+    AsyncPrefault async_prefault;      // (joins on every way out of this function)
+    {
+        constexpr int64_t kAsyncMinBytes = (int64_t)64 << 20;
+        double *const pd = out_dist && !looks_resident(out_dist, seq.n * 8) ? out_dist : nullptr;
+        int32_t *const pm = out_mrca && !looks_resident(out_mrca, seq.n * 4) ? out_mrca : nullptr;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (!skip_cpu && seq.step == 1 && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8)
+            async_prefault.start(pd, pm, seq.n, (int)std::min<unsigned>(16, hw / 4));
+    }
     auto prefault = [&](int64_t off, int64_t m) {
+        if (async_prefault.active()) return;
         double *const pd = out_dist && !looks_resident(out_dist + off, m * 8) ? out_dist : nullptr;
         int32_t *const pm = out_mrca && !looks_resident(out_mrca + off, m * 4) ? out_mrca : nullptr;
         if (!pd && !pm) return;

@@ -60,7 +60,7 @@ public:
         const int want = n_;
         try {
             workers_.reserve((size_t)want);
-            for (int i = 0; i < want - 1; i++) workers_.emplace_back([this, i, born] { loop(i + 1, born); });
+            for (int i = 0; i < want - 1; i++) workers_.emplace_back([this, born] { loop(born); });
         } catch (...) {
             // (thread limit reached, out of memory: the pool works with the threads it has -- the phases
             // are split into n_ parts and wait for n_ - 1 workers, so n_ must be what actually runs)
@@ -79,18 +79,24 @@ public:
         workers_.clear();
     }
 
-    // fn(begin, end) over a partition of [0, n); returns when every part is done.
-    void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)> &fn)
+    // fn(begin, end) over a partition of [0, n) into blocks of `grain` items (a multiple of 1024; 0 = about eight
+    // blocks per thread), handed out by an atomic counter: a thread that lands on a busy core or is descheduled
+    // for a while (the pool's hosts are shared) takes fewer blocks instead of holding the whole phase up, which a
+    // static split into one range per thread did.  Returns when every block is done.
+    void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)> &fn, int64_t grain = 0)
     {
         if (n <= 0) return;
         if (workers_.empty() || n < (int64_t)1 << 14) { fn(0, n); return; }
+        if (grain <= 0) grain = std::max<int64_t>(4096, (n / (8 * (int64_t)n_) + 1023) / 1024 * 1024);
         fn_ = &fn;
         total_ = n;
+        grain_ = grain;
+        next_.store(0, std::memory_order_relaxed);
         pending_.store(n_ - 1, std::memory_order_relaxed);
         generation_.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> g(m_); }     // a worker about to sleep has either seen the new generation or is waiting
         cv_.notify_all();
-        run_part(0);
+        run_blocks();
         for (unsigned spins = 0; pending_.load(std::memory_order_acquire) != 0; spins++) {
             if ((spins & 1023) == 1023) std::this_thread::yield();
             else _mm_pause();
@@ -108,13 +114,16 @@ public:
 private:
     static constexpr int kSpinMicros = 200;
 
-    void run_part(int part)
+    void run_blocks()
     {
-        const int64_t b = total_ * part / n_, e = total_ * (part + 1) / n_;
-        if (e > b) (*fn_)(b, e);
+        for (;;) {
+            const int64_t b = next_.fetch_add(grain_, std::memory_order_relaxed);
+            if (b >= total_) return;
+            (*fn_)(b, std::min(b + grain_, total_));
+        }
     }
 
-    void loop(int part, uint64_t seen)
+    void loop(uint64_t seen)
     {
         for (;;) {
             // spin a little: the next phase of the same call is usually moments away
@@ -130,7 +139,7 @@ private:
             }
             seen = generation_.load(std::memory_order_acquire);
             if (quit_.load()) return;
-            run_part(part);
+            run_blocks();
             pending_.fetch_sub(1, std::memory_order_release);
         }
     }
@@ -139,7 +148,8 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     const std::function<void(int64_t, int64_t)> *fn_ = nullptr;
-    int64_t total_ = 0;
+    int64_t total_ = 0, grain_ = 1;
+    std::atomic<int64_t> next_{0};
     int n_ = 1;
     std::atomic<int> pending_{0};
     std::atomic<uint64_t> generation_{0};

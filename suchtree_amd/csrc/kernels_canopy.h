@@ -77,7 +77,7 @@ __device__ __forceinline__ void load_rec_b(PairRecs<CAP> &L)
         for (int q = 0; q < CAP; q++) L.Db[q] = __uint_as_float(w[q + 1]);
     } else {
         L.wb = *reinterpret_cast<const uint32_t *>(L.rb);
-        L.Db[0] = 0.0f;
+        L.Db[0] = __uint_as_float(kChainPad);
     }
 }
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_rec_b_chunks(PairRecs<CAP> &L, uint32_t chu
         uint32_t w[CAP + 1];
 #pragma unroll
         for (int q = 0; q < (CAP + 1) / 4; q++) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            uint4 v = make_uint4(kChainPad, kChainPad, kChainPad, kChainPad);      // (a chunk that is not loaded holds no chain slot in use)
             if ((uint32_t)q < chunks) v = reinterpret_cast<const uint4 *>(L.rb)[q];
             w[4 * q + 0] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
@@ -210,7 +210,7 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
         L.wb = w[0];
 #pragma unroll
         for (int q = kEager; q < kChunks; q++) {
-            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            uint4 x = make_uint4(kChainPad, kChainPad, kChainPad, kChainPad);
             if ((uint32_t)(4 * q) <= (L.wb >> 16)) x = reinterpret_cast<const uint4 *>(L.rb)[q];      // slots 4q-1 .. 4q+2
             w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
         }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             for (int j = 0; j < PPL; j++)
                 if (!valid[j] && live[j]) record_fault(fault, ida[j], idb[j], P.n_nodes);
         }
-        uint32_t u[PPL], v[PPL], pa[PPL], pb[PPL], nb[PPL];
+        uint32_t u[PPL], v[PPL], pa[PPL], pb[PPL];
         float s[PPL], Db[PPL][CAP];
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
                 wb = w[0];
 #pragma unroll
                 for (int q = kEager; q < kChunks; q++) {
-                    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                    uint4 x = make_uint4(kChainPad, kChainPad, kChainPad, kChainPad);
                     if ((uint32_t)(4 * q) <= (wb >> 16)) x = reinterpret_cast<const uint4 *>(rb)[q];      // slots 4q-1 .. 4q+2
                     w[4 * q + 0] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
                 }
@@ -362,7 +362,6 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             v[j] = wb & 0xFFFFu;
             pa[j] = u[j];
             pb[j] = v[j];
-            nb[j] = wb >> 16;
         }
 
         // climb 1: find the meeting node; the a-side sum rides along
@@ -391,10 +390,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
 #pragma unroll
         for (int j = 0; j < PPL; j++) {
 #pragma unroll
-            for (int q = 0; q < CAP; q++) {
-                const float s_next = s[j] + Db[j][q];
-                s[j] = (uint32_t)q < nb[j] ? s_next : s[j];
-            }
+            for (int q = 0; q < CAP; q++) s[j] += Db[j][q];      // (slots beyond the chain hold -0.0f: pair_math.h, kChainPad)
             v[j] = pb[j];
         }
         go = false;

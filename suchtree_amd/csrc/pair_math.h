@@ -218,6 +218,10 @@ ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__res
 }
 
 // ---- canopy family ---------------------------------------------------------
+// Chains in registers (CAP > 0): every slot is added, unconditionally -- slots beyond the chain's length hold -0.0f
+// (tree_prep.cpp writes it into the records, the kernels into chunks they do not load), and s + (-0.0f) == s bit for
+// bit for every float s (+0, -0, denormals, infinities and NaNs included): one v_add_f32 per slot instead of add + select.
+constexpr uint32_t kChainPad = 0x80000000u;
 // `can` is the canopy table (LDS on the device), BFS-numbered: parent index <
 // child index, so "move the larger index up" can never step past the meeting
 // point.  `rec_*` are the understory records of a and b (global memory).
@@ -322,8 +326,7 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
     const uint32_t mc = u;
     if (CAP > 0) {
 #pragma unroll
-        for (int i = 0; i < CAP; i++)
-            if ((uint32_t)i < nb_b) s += D_b[i];
+        for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
         s = chain_sum_ptr(D_b, nb_b, s);
     }
@@ -398,8 +401,7 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
     }
     if (CAP > 0) {
 #pragma unroll
-        for (int i = 0; i < CAP; i++)
-            if ((uint32_t)i < nb_b) s += D_b[i];
+        for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
         s = chain_sum_ptr(D_b, nb_b, s);
     }
@@ -431,8 +433,7 @@ ST_HD float ladder_sum_b(LadPtr lad, uint32_t kb, float s_a, uint32_t pb, const 
     float s = s_a;
     if (CAP > 0) {
 #pragma unroll
-        for (int i = 0; i < CAP; i++)
-            if ((uint32_t)i < nb_b) s += D_b[i];
+        for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
         s = chain_sum_ptr(D_b, nb_b, s);
     }
@@ -497,8 +498,7 @@ ST_HD PairResult pair_ladder_split(LadPtr lad, DepthPtr cdepth, const int32_t *_
     }
     if (CAP > 0) {
 #pragma unroll
-        for (int i = 0; i < CAP; i++)
-            if ((uint32_t)i < nb_b) s += D_b[i];
+        for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
         s = chain_sum_ptr(D_b, nb_b, s);
     }

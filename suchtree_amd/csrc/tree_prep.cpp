@@ -357,6 +357,12 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
                 for (uint32_t i = 0; i < nb; i++) acc = acc + D[i];
                 pbot = acc;
             }
+            // unused chain slots hold -0.0f: s + (-0.0f) == s bit for bit for every s, so kernels that keep the chain in
+            // registers add all `cap` slots unconditionally (one v_add_f32 per slot, no select: pair_math.h)
+            {
+                const uint32_t nb_used = w0 >> 16, neg_zero = 0x80000000u;
+                for (uint32_t i = nb_used; i < (uint32_t)cap; i++) std::memcpy(D + i, &neg_zero, 4);
+            }
             std::memcpy(rb, &w0, 4);
             std::memcpy(ri, &pbot, 4);
             std::memcpy(T.rec_a.data() + slot * 8, &w0, 4);

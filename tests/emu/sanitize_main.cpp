@@ -70,6 +70,20 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
         const PairResult c = A.portal != B.portal
             ? pair_canopy_split<0>(T.canopy.data(), T.canopy_id.data(), A.portal, A.pbot, B.portal, B.D, B.nb)
             : pair_canopy_same_portal(T.canopy_id.data(), A, B);
+        // the padding contract of chains kept in registers (pair_math.h: kChainPad): slots beyond the chain hold
+        // -0.0f, and adding every slot -- what the kernels do -- gives the bits of adding the chain alone
+        {
+            float s_all = A.pbot, s_chain = A.pbot;
+            for (int32_t q = 0; q < B.cap; q++) {
+                uint32_t bits;
+                std::memcpy(&bits, B.D + q, 4);
+                if ((uint32_t)q >= B.nb && bits != kChainPad) return 12;
+                volatile float t = s_all + B.D[q];
+                s_all = t;
+                if ((uint32_t)q < B.nb) { volatile float u = s_chain + B.D[q]; s_chain = u; }
+            }
+            if (std::memcmp(&s_all, &s_chain, 4) != 0) return 13;
+        }
         if (c.mrca != w.mrca || std::memcmp(&c.dist, &w.dist, 4) != 0) {
             std::printf("mismatch leaves=%d skew=%g pair (%lld,%lld)\n", n_leaves, skew, (long long)a, (long long)b);
             return 3;
