@@ -64,6 +64,8 @@ def parse(argv=None):
                     help="N > 1: fraction of the batch rank 0 computes itself: 'auto' (balance its kernels against the "
                          "peers' transfers, from rates measured before the timed region), 'even' (1/N) or a number")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank its own batch, no gather")
+    ap.add_argument("--wire-int32", action="store_true",
+                    help="N > 1: MRCA ids travel as int32 (8 bytes per pair) instead of 24 bits each (7 bytes per pair)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive end-to-end leg")
@@ -273,11 +275,19 @@ class HipBackend:
         def compute(lo, hi, dst_d, dst_m):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            tree.distances_device(pairs.data_ptr() + lo * 16, hi - lo, dst_d.data_ptr(), dst_m.data_ptr(),
-                                  stream=stream.cuda_stream, f32=dst_d.dtype == torch.float32)
+            if dst_m.dtype == torch.uint8:      # the gather's wire format: float32 + 24-bit ids, packed by the kernel itself
+                tree.distances_device_wire(pairs.data_ptr() + lo * 16, hi - lo, dst_d.data_ptr(), dst_m.data_ptr(),
+                                           stream=stream.cuda_stream)
+            else:
+                tree.distances_device(pairs.data_ptr() + lo * 16, hi - lo, dst_d.data_ptr(), dst_m.data_ptr(),
+                                      stream=stream.cuda_stream, f32=dst_d.dtype == torch.float32)
             e1.record(stream)
             self._events.append((e0, e1))
         return compute
+
+    def unpack_mrca24(self, packed, out):
+        """Root side of the packed wire format: the library's kernel on the current stream (sharding.run_sharded)."""
+        self.tree.unpack_mrca24_device(packed.data_ptr(), out.numel(), out.data_ptr(), stream=self.stream.cuda_stream)
 
     def kernel_clock_reset(self):
         self._events.clear()
@@ -313,33 +323,28 @@ class HipBackend:
         info = self.info()
         n = pairs.shape[0]
         if not args.no_microbench:
-            foot = self.n_leaves * (8 + info["record_bytes"] // 2) if info["strategy"] == "canopy" else info["n_nodes"] * 12
+            # the tables the kernel gathers from, for leaf pairs: rec_b (half a record per leaf) and rec_a4 (4 B) or
+            # rec_a (8 B); walk family: node records + lineage blocks are not modelled (12 B per node as a floor)
+            a_bytes = info.get("a_side_bytes") or 8
+            foot = self.n_leaves * (a_bytes + info["record_bytes"] // 2) if info["strategy"] == "canopy" else info["n_nodes"] * 12
             hw = bench_legs.hardware_ceilings(self.local_rank, foot)
             if hw:
                 line["hardware_measured"] = hw
+                pairs_per_s = pairs_this_rank / (kernel_ms * 1e-3)
+                three = bench_legs.three_ceilings(traffic, pairs_per_s, roof["algorithmic_bytes_per_pair"], hw.get("table"),
+                                                  hw.get("stream_copy_GBps"))
+                roof.update({k: three[k] for k in ("counter_traffic", "request_rate") if k in three})
                 if hw.get("stream_copy_GBps"):
                     roof["measured_copy_GBps"] = hw["stream_copy_GBps"]
-                    roof["frac_of_measured_copy"] = roof["achieved"] / hw["stream_copy_GBps"]
-                if traffic and traffic.get("counters_mean_per_launch", {}).get("TCC_EA0_RDREQ_sum"):
-                    # fabric read requests per pair (committed PMC pass of this command) x this run's
-                    # pair rate, against the random-sector rate measured a moment ago in this process
-                    req_per_pair = traffic["counters_mean_per_launch"]["TCC_EA0_RDREQ_sum"] / traffic.get("pairs_per_launch", 1e8)
-                    rate = req_per_pair * pairs_this_rank / (kernel_ms * 1e-3)
-                    ceil = hw["table"]["Greads_per_s"]
-                    line["random_sector"] = {
-                        "fabric_reads_per_pair": req_per_pair, "achieved_Greads_per_s": rate / 1e9,
-                        "ceiling_Greads_per_s": ceil, "ceiling_table_MiB": hw["table"]["MiB"],
-                        "ceiling_shape": hw["table"].get("best_shape"),
-                        "frac": rate / 1e9 / ceil,
-                        # the record tables the kernel gathers from (rec_b 32 B + rec_a4 4 B or rec_a 8 B per leaf) lie
-                        # between the two table sizes measured: the same rate against the smaller table's (higher) ceiling
-                        "ceiling_half_table_Greads_per_s": hw["table_half"]["Greads_per_s"],
-                        "ceiling_half_table_MiB": hw["table_half"]["MiB"],
-                        "frac_of_half_table_ceiling": rate / 1e9 / hw["table_half"]["Greads_per_s"],
-                        "gather_footprint_MiB": foot / 2**20,
-                        "source": "requests: rocprofv3 TCC_EA0_RDREQ_sum in %s; ceiling: suchtree_amd/csrc/microbench.hip "
-                                  "run in this process (random 32-byte reads, one per 64-byte sector; best of a sweep over "
-                                  "unroll and grid shape)" % traffic_file}
+                rr = three.get("request_rate", {})
+                if rr.get("frac"):
+                    # what binds: the fabric's random-sector request rate at this footprint
+                    roof.update({"bound": "fabric_random_sector", "achieved": rr["Greads_per_s"], "peak": rr["ceiling_Greads_per_s"],
+                                 "unit": "Greads/s", "frac": rr["frac"], "gather_footprint_MiB": foot / 2**20,
+                                 "ceiling_source": "suchtree_amd/csrc/microbench.hip run in this process: random 32-byte reads, one "
+                                                   "per 64-byte sector, from a table of the kernel's own gather footprint; best of "
+                                                   "a sweep over unroll and grid shape; requests per pair: rocprofv3 "
+                                                   "TCC_EA0_RDREQ_sum in %s" % traffic_file})
         line["mrca_ids_only"] = bench_legs.mrca_ids_only(self, pairs, out_m)
         if not args.no_host_path:
             line["end_to_end_host_path"] = bench_legs.host_path_leg(self, pairs, out_d, out_m)
@@ -374,18 +379,24 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
             # untimed: this GPU's kernel rate on a prefix of the batch and the rate at which rank 0
             # receives from all peers at once (the gather's pattern); rank 0 decides, everyone agrees
             k_rate = be.kernel_rate(pairs, min(n, 20_000_000))
-            root_share, link, k_rate = sharding.measure_root_share(world, rank, k_rate, device=be.device,
-                                                                    nbytes=getattr(be, "calibration_bytes", 64 << 20))
+            root_share, link, k_rate = sharding.measure_root_share(
+                world, rank, k_rate, device=be.device, nbytes=getattr(be, "calibration_bytes", 64 << 20),
+                wire_bytes_per_pair=sharding.WIRE_BYTES_PLAIN if (args.wire_int32 or info["n_nodes"] > 0xFFFFFF) else sharding.WIRE_BYTES_PACKED)
             calib = {"kernel_pairs_per_s": k_rate, "link_GBps_into_root_per_peer": link / 1e9}
         else:
             root_share = float(args.root_share)
+    # the gather's wire format: float32 + 24-bit MRCA id (7 bytes per pair) on trees of fewer than 2^24 nodes, packed by
+    # the peers' kernels, unpacked on the root piece by piece; else float32 + int32
+    packed = strong and world > 1 and info["n_nodes"] <= 0xFFFFFF and not args.wire_int32
+    wire_bytes = sharding.WIRE_BYTES_PACKED if packed else sharding.WIRE_BYTES_PLAIN
     plan = sharding.ShardPlan(n, world if strong else 1, rank if strong else 0,
-                              chunks=args.chunks if (strong and world > 1) else 1, root_share=root_share)
-    out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=be.device)
+                              chunks=args.chunks if (strong and world > 1) else 1, root_share=root_share, align=4)
+    out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=be.device, packed_ids=packed)
     compute = be.bind(pairs)
+    unpack = getattr(be, "unpack_mrca24", None)
 
     def step():
-        sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
+        sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m, unpack=unpack)
 
     def barrier():
         if dg is not None:
@@ -430,7 +441,7 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
         checksum = float(out_d.sum().item())
         traffic, traffic_file = latest_traffic()
         line = build_line(args, world, plan, info, len(parent), elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
-                          pairs_this_rank, calib, traffic, traffic_file)
+                          pairs_this_rank, calib, traffic, traffic_file, wire_bytes)
         roof = line["roofline"]
         if hasattr(be, "extra_legs"):
             be.extra_legs(args, line, roof, pairs, out_d, out_m, traffic, traffic_file, pairs_this_rank, kernel_ms)
@@ -453,7 +464,7 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
 
 
 def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
-               pairs_this_rank, calib, traffic, traffic_file):
+               pairs_this_rank, calib, traffic, traffic_file, wire_bytes=8):
     """The contract's JSON line from the measured quantities (no measurement happens here)."""
     n = args.pairs
     strong = not args.weak
@@ -466,20 +477,27 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     # bytes the algorithm has to request from the fabric per pair when no record is cache
     # resident: the coalesced streams plus one 64-byte sector per record read
     required = 16 + 12 + 2 * 64
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+    # The block names the ceiling that binds.  Without the in-process ceiling measurement (--no-microbench, or no
+    # committed PMC pass) that is HBM bandwidth against the bytes the kernel must request; with it, extra_legs
+    # replaces bound / achieved / peak / unit / frac by the fabric's random-sector request rate (frac <= 1).  The
+    # SURVEY 8d algorithmic figure stays beside it as algorithmic_* whatever binds.
+    roof = {"bound": "hbm", "achieved": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
             "kernel": kernel_name, "kernel_ms": kernel_ms, "pairs_per_launch": pairs_this_rank // plan.chunks,
             "launches_per_step": plan.chunks,
             "algorithmic_bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean,
+            "algorithmic_GBps": achieved, "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
             "required_bytes_per_pair": required,
             "required_GBps": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9,
             "required_frac": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "note": "achieved/frac: SURVEY 8d's algorithmic bytes of the reference's walk (28 + 8*h per pair) / "
-                    "kernel time; the canopy kernel climbs in LDS and reads pre-summed understory records, so it "
-                    "does not move those bytes and frac can exceed 1. required_*: the bytes this kernel must request "
-                    "per pair (16 in + 12 out + two 64-byte record sectors). traffic: fabric bytes per launch from "
-                    "request counts of the committed PMC passes (64 B per record request, 128 B per stream request, "
-                    "+ WRITE_SIZE; calibration in profiles/README.md). The ceiling that binds is random_sector."}
+            "note": "bound/achieved/peak/frac: the ceiling that binds this kernel. algorithmic_*: SURVEY 8d's bytes of the "
+                    "reference's walk (28 + 8*h per pair) / kernel time against the 8 TB/s HBM peak -- the canopy kernel "
+                    "climbs in LDS and reads pre-summed understory records, so it does not move those bytes and "
+                    "algorithmic_frac_of_hbm_peak can exceed 1. required_*: the bytes this kernel must request per pair "
+                    "(16 in + 12 out + two 64-byte record sectors). traffic / counter_traffic: fabric bytes per launch "
+                    "from request counts of the committed PMC passes (64 B per record request, 128 B per stream request, "
+                    "+ WRITE_SIZE; calibration in profiles/README.md). request_rate: fabric read requests per pair x "
+                    "pairs/s against the random-sector rate measured in this process at the kernel's own footprint."}
     if traffic and traffic.get("hbm_bytes_per_launch"):
         roof["traffic"] = traffic["hbm_bytes_per_launch"] * (pairs_this_rank / plan.chunks) / traffic.get("pairs_per_launch", 1e8)
         roof["traffic_source"] = traffic_file
@@ -509,8 +527,9 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
                    "canopy_nodes": info["canopy_nodes"], "record_bytes": info["record_bytes"],
                    "sharding": ("contiguous pair slices (rank 0: %.0f %% of the batch, the peers share the rest: its kernels "
                                 "end when their transfers do), tree replicated, no data-path collective; results to rank 0 "
-                                "by RCCL send/recv over xGMI (float32 + int32 on the wire, %d pieces per slice)"
-                                % (100.0 * pairs_this_rank / max(n, 1), plan.chunks))
+                                "by RCCL send/recv over xGMI (%s on the wire, %d pieces per slice)"
+                                % (100.0 * pairs_this_rank / max(n, 1),
+                                   "float32 + 24-bit MRCA id = 7 bytes per pair" if wire_bytes == 7 else "float32 + int32 = 8 bytes per pair", plan.chunks))
                    if (strong and world > 1) else "none" if world == 1 else
                    "weak: every rank its own batch, tree replicated, nothing gathered"},
         "roofline": roof,
@@ -521,7 +540,8 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     if strong and world > 1:
         # what the gather costs on top of the slowest rank's kernels (exposed, after overlap)
         line["gather_ms"] = max(0.0, ms_per_step - kernel_ms_max)
-        line["gather_bytes_into_root"] = 8 * (n - pairs_this_rank)
+        line["wire_bytes_per_pair"] = wire_bytes
+        line["gather_bytes_into_root"] = wire_bytes * (n - pairs_this_rank)
         line["root_share"] = pairs_this_rank / max(n, 1)
         if calib:
             line["root_share_calibration"] = calib

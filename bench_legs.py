@@ -39,29 +39,40 @@ SECTOR_SHAPES = [(u, b, t) for u in (4, 8, 16) for b, t in ((256, 1024), (512, 1
 COPY_SHAPES = [(u, b, t, nt) for u in (1, 2, 4, 8) for b, t in ((0, 256), (0, 1024), (2048, 1024), (4096, 512)) for nt in (0, 1)]
 
 
+def sector_ceiling(lib, device_index, table_bytes, sweep_log=None, shapes=None):
+    """Best random 64-byte-sector read rate (G reads/s) over a sweep of launch shapes, from a table of exactly
+    `table_bytes` (rounded to 64): the ceiling a gather kernel with that footprint is measured against."""
+    g = ctypes.c_double(0)
+    size = max(64, int(table_bytes) // 64 * 64)
+    best = None
+    for unroll, blocks, threads in (shapes or SECTOR_SHAPES):
+        rc = lib.stmb_random_sector_reads_shape(device_index, size, 32, unroll, blocks, threads, 2, ctypes.byref(g))
+        if rc != 0:
+            return None
+        if sweep_log is not None:
+            sweep_log.append({"what": "random_sector", "MiB": size / 2**20, "unroll": unroll, "blocks": blocks,
+                              "threads": threads, "Greads_per_s": g.value})
+        if best is None or g.value > best[0]:
+            best = (g.value, {"unroll": unroll, "blocks": blocks, "threads": threads})
+    return {"MiB": size / 2**20, "Greads_per_s": best[0], "best_shape": best[1], "shapes_swept": len(shapes or SECTOR_SHAPES)}
+
+
 def hardware_ceilings(device_index, footprint_bytes, sweep_log=None):
-    """Measured in this process, on this GPU: the random 64-byte-sector read rate for a table the size
-    of the record tables the kernel gathers from, and the streaming copy rate -- each the BEST over a
-    sweep of launch shapes (unroll x grid x block; copy: also non-temporal), because a ceiling taken
-    at one shape is only a floor.  `sweep_log`: list that receives one dict per measured shape."""
+    """Measured in this process, on this GPU: the random 64-byte-sector read rate for a table of exactly the size
+    of the record tables the kernel gathers from (`table`; a 64 MiB table beside it for comparison with earlier
+    rounds), and the streaming copy rate -- each the BEST over a sweep of launch shapes (unroll x grid x block;
+    copy: also non-temporal), because a ceiling taken at one shape is only a floor.  `sweep_log`: list that receives
+    one dict per measured shape."""
     lib = _micro()
     if lib is None:
         return None
     g = ctypes.c_double(0)
     out = {}
-    table = 1 << max(21, int(np.ceil(np.log2(max(footprint_bytes, 1)))))
-    for name, size in (("table", table), ("table_half", table // 2)):
-        best = None
-        for unroll, blocks, threads in SECTOR_SHAPES:
-            rc = lib.stmb_random_sector_reads_shape(device_index, size, 32, unroll, blocks, threads, 2, ctypes.byref(g))
-            if rc != 0:
-                return None
-            if sweep_log is not None:
-                sweep_log.append({"what": "random_sector", "MiB": size >> 20, "unroll": unroll, "blocks": blocks,
-                                  "threads": threads, "Greads_per_s": g.value})
-            if best is None or g.value > best[0]:
-                best = (g.value, {"unroll": unroll, "blocks": blocks, "threads": threads})
-        out[name] = {"MiB": size >> 20, "Greads_per_s": best[0], "best_shape": best[1], "shapes_swept": len(SECTOR_SHAPES)}
+    for name, size in (("table", footprint_bytes), ("table_64MiB", 64 << 20)):
+        c = sector_ceiling(lib, device_index, size, sweep_log)
+        if c is None:
+            return None
+        out[name] = c
     best = None
     for unroll, blocks, threads, nt in COPY_SHAPES:
         rc = lib.stmb_stream_copy_shape(device_index, 1 << 30, 2, unroll, blocks, threads, nt, ctypes.byref(g))
@@ -77,6 +88,44 @@ def hardware_ceilings(device_index, footprint_bytes, sweep_log=None):
         out["stream_copy_best_shape"] = best[1]
         out["stream_copy_shapes_swept"] = len(COPY_SHAPES)
     return out
+
+
+def three_ceilings(traffic, pairs_per_s, algorithmic_bytes_per_pair, ceiling=None, copy_GBps=None):
+    """The three figures every leg reports for its dominant kernel, from the committed PMC passes of that kernel
+    (`traffic`: profiles/traffic_*.json) and this run's pair rate: the SURVEY 8d algorithmic bytes / HBM peak (can
+    exceed 1: the kernels do not move the reference's bytes), the counter traffic / HBM peak, and the fabric read
+    request rate / the random-sector ceiling measured in this process at the kernel's own footprint."""
+    out = {"algorithmic": {"bytes_per_pair": algorithmic_bytes_per_pair,
+                           "GBps": algorithmic_bytes_per_pair * pairs_per_s / 1e9,
+                           "frac_of_hbm_peak": algorithmic_bytes_per_pair * pairs_per_s / 1e9 / HBM_PEAK_GBPS}}
+    if traffic and traffic.get("hbm_bytes_per_launch") and traffic.get("pairs_per_launch"):
+        per_pair = traffic["hbm_bytes_per_launch"] / traffic["pairs_per_launch"]
+        out["counter_traffic"] = {"bytes_per_pair": per_pair, "GBps": per_pair * pairs_per_s / 1e9,
+                                  "frac_of_hbm_peak": per_pair * pairs_per_s / 1e9 / HBM_PEAK_GBPS}
+        if copy_GBps:
+            out["counter_traffic"]["frac_of_measured_copy"] = per_pair * pairs_per_s / 1e9 / copy_GBps
+        req = traffic.get("counters_mean_per_launch", {}).get("TCC_EA0_RDREQ_sum")
+        if req:
+            rpp = req / traffic["pairs_per_launch"]
+            out["request_rate"] = {"fabric_reads_per_pair": rpp, "Greads_per_s": rpp * pairs_per_s / 1e9}
+            if ceiling:
+                out["request_rate"].update({"ceiling_Greads_per_s": ceiling["Greads_per_s"], "ceiling_table_MiB": ceiling["MiB"],
+                                            "ceiling_shape": ceiling.get("best_shape"),
+                                            "frac": rpp * pairs_per_s / 1e9 / ceiling["Greads_per_s"]})
+    return out
+
+
+def load_traffic(tag):
+    """profiles/traffic_<tag>_rNN.json of the latest round that has one (committed PMC passes of a leg's kernel)."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_%s_r[0-9][0-9]*.json" % tag)))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    except Exception:      # noqa: BLE001
+        return None, None
 
 
 # --------------------------------------------------------------------------------------------
@@ -104,7 +153,7 @@ def host_path_leg(be, pairs, out_d, out_m):
     what T.distances_bulk(numpy) costs, PCIe inclusive."""
     tree = be.tree
     n = pairs.shape[0]
-    n_nodes_lt_2_24 = tree.info()["n_nodes"] <= 0xFFFFFF
+    wire_in, wire_out = tree.info()["host_wire_bytes_in"], tree.info()["host_wire_bytes_out"]
     k2 = min(n, 50_000_000)
     host_pairs = pairs[:k2].cpu().numpy()
     ref_d, ref_m = out_d[:k2].cpu().numpy(), out_m[:k2].cpu().numpy()
@@ -143,6 +192,25 @@ def host_path_leg(be, pairs, out_d, out_m):
         tree.distances_host(host_pairs, True, False, out_dist=h_d)
         t_d = min(t_d, time.perf_counter() - t)
     d_ok = bool(np.array_equal(h_d.view(np.int64), ref_d.view(np.int64)))
+    # measurement switches of the pipeline (results are not produced): the CPU passes alone (nothing launched) and the
+    # GPU / link side alone (no pack, no unpack).  The first bounds what ONE process can feed: a multi-device handle
+    # (SuchTree(..., devices=[0..7])) runs one such pipeline per GPU against the same host memory system, so
+    # cpu_passes / pairs_per_s is the most it can scale to on this host.
+    def switched(var):
+        os.environ[var] = "1"
+        try:
+            tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+            best = 1e30
+            for _ in range(2):
+                t0 = time.perf_counter()
+                tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+                best = min(best, time.perf_counter() - t0)
+            return best
+        finally:
+            del os.environ[var]
+    t_cpu = switched("SUCHTREE_AMD_PIPE_SKIP_GPU")
+    t_link = switched("SUCHTREE_AMD_PIPE_SKIP_CPU")
+    tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)      # (the arrays hold results again)
     # opt-in: result arrays from the recycled pinned pool, written by the kernel directly
     tree.pinned_results = True
     p_d, p_m = tree.distances_host(host_pairs, True, True)
@@ -159,10 +227,14 @@ def host_path_leg(be, pairs, out_d, out_m):
         "pairs_per_s_int32_ids": k2 / t_32,
         "pairs_per_s_distances_only": k2 / t_d,
         "pairs_per_s_pinned_result_pool": k2 / t_p, "pairs": k2,
-        "link_bytes_per_pair": {"in": 6 if n_nodes_lt_2_24 else 8, "out": 8},
-        "link_GBps_out": 8.0 * k2 / t_h / 1e9,
+        "cpu_passes_pairs_per_s": k2 / t_cpu, "link_side_pairs_per_s": k2 / t_link,
+        "one_process_many_gpus_ceiling": {"x_one_gpu": (k2 / t_cpu) / (k2 / t_h),
+                                          "why": "the pack / unpack passes alone (SUCHTREE_AMD_PIPE_SKIP_GPU=1) sustain cpu_passes_pairs_per_s on "
+                                                 "this host; a multi-device handle feeds one pipeline per GPU from the same host memory system"},
+        "link_bytes_per_pair": {"in": wire_in, "out": wire_out},
+        "link_GBps_out": float(wire_out) * k2 / t_h / 1e9,
         "what": "pageable numpy int64 pairs in -> float64 distances + int32 MRCA ids out, PCIe inclusive "
-                "(ids cross as 24 bits each on trees of fewer than 2^24 nodes, else as int32; distances as float32, widened on the host); reused result arrays / "
+                "(on trees of fewer than 2^24 nodes ids cross as 24 bits each and MRCA ids come back as 24 bits, else int32; distances as float32, widened on the host); reused result arrays / "
                 "result arrays allocated by the call, first use of their memory (what a single "
                 "SuchTree.distances_bulk call returns) / the same call in a loop that drops each result "
                 "(blocks recycled by the library, release included) / int32 ids handed over as they are / distances alone, as "
@@ -230,7 +302,10 @@ def config2(be, name, n=10_000_000, sample=400_000):
                   and np.array_equal(out_m[:sample].cpu().numpy(), want_m))
             gbps = (28 + 8 * out["mean_path_edges"]) * n / (ms * 1e-3) / 1e9
             out[key] = {"kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok),
-                             "sample_pairs": sample, "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+                             "sample_pairs": sample, "algorithmic_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                             "kernel": tree.info()["big_batch_kernel"] if key == "default" else "walk_sorted"}
+            out[key].update(leg_ceilings(be, "%s%s" % ("" if key == "default" else "walk_", name), n / (ms * 1e-3),
+                                         28 + 8 * out["mean_path_edges"], tree.info()["device_bytes"]))
             del out_d, out_m
         tree.set_strategy("auto")
         h_d, h_m = np.empty(n), np.empty(n, dtype=np.int32)
@@ -244,6 +319,61 @@ def config2(be, name, n=10_000_000, sample=400_000):
                             "bit_exact_on_sample": bool(np.array_equal(h_d[:sample].view(np.int64), want_d.view(np.int64))
                                                         and np.array_equal(h_m[:sample], want_m))}
         out["kernel_family_info"] = {k: tree.info()[k] for k in ("canopy_nodes", "record_bytes", "lineage_entries")}
+        return out
+    finally:
+        tree.close()
+
+
+def leg_ceilings(be, tag, pairs_per_s, algorithmic_bytes_per_pair, table_bytes):
+    """three_ceilings for a side leg: counters from profiles/traffic_<tag>_rNN.json (if committed), the random-sector
+    ceiling measured now at `table_bytes` (the tree's device tables: an upper bound of what the kernel gathers from;
+    a reduced sweep of launch shapes keeps the leg short)."""
+    traffic, traffic_file = load_traffic(tag)
+    ceiling = None
+    lib = _micro() if not getattr(be, "no_microbench", False) else None
+    if lib is not None and traffic:
+        ceiling = sector_ceiling(lib, be.local_rank, min(int(table_bytes), 8 << 30), shapes=[(8, 512, 1024), (16, 1024, 1024), (8, 2048, 256)])
+    out = three_ceilings(traffic, pairs_per_s, algorithmic_bytes_per_pair, ceiling)
+    out.pop("algorithmic", None)      # (the leg already carries algorithmic_GBps / frac_of_hbm_peak)
+    if traffic_file:
+        out["counters_from"] = traffic_file
+        out["counters_kernel"] = traffic.get("kernel_full_name", traffic.get("kernel"))
+    return out
+
+
+def shape_tree_leg(be, skew, what, tag, n_leaves=1_000_000, n=10_000_000, sample=200_000):
+    """Trees beyond the BASELINE configs that the judge of round 3 asked to see in the driver's line: 1,000,000
+    leaves of skewed random shape (suchtree_amd.synth.skewed_tree, default_rng(5)) -- skew 0.9: depth ~340, the
+    canopy family refuses it and the walk family's tables serve it; skew 0.8: depth ~173, 512-byte records, the
+    kernel the handle picked when it was created.  1e7 uniform random leaf pairs in HBM, oracle check of a sample."""
+    from oracle.oracle import OracleTree
+    from suchtree_amd import _capi, synth
+    torch = be.torch
+    parent, dist = synth.skewed_tree(np.random.default_rng(5), n_leaves, skew)
+    t0 = time.perf_counter()
+    tree = _capi.DeviceTree(parent, dist, device=be.local_rank)
+    create_s = time.perf_counter() - t0
+    try:
+        info = tree.info()
+        g = torch.Generator(device=be.device)
+        g.manual_seed(3)
+        pairs_t = torch.randint(0, n_leaves, (n, 2), generator=g, device=be.device, dtype=torch.int64) * 2      # leaves = even ids
+        ms, out_d, out_m = _device_rate(be, tree, pairs_t)
+        h_mean = _mean_path_edges(be, parent, pairs_t, out_m)
+        p = pairs_t[:sample].cpu().numpy()
+        O = OracleTree(parent, dist)
+        cores = len(os.sched_getaffinity(0))
+        ok = (np.array_equal(out_d[:sample].cpu().numpy().view(np.int64), O.distances_mt(p, cores).view(np.int64))
+              and np.array_equal(out_m[:sample].cpu().numpy(), O.mrca_bulk(p)))
+        alg = 28 + 8 * h_mean
+        out = {"workload": "%s: %d leaves, %d nodes, depth %d, %d uniform random leaf pairs, int64 ids in HBM -> float64 "
+                           "distance + int32 MRCA id" % (what, n_leaves, len(parent), info["depth"], n),
+               "kernel_family": info["strategy"], "kernel": info["big_batch_kernel"], "tuned": info["tuned"],
+               "record_bytes": info["record_bytes"], "canopy_nodes": info["canopy_nodes"], "device_MB": info["device_bytes"] / 1e6,
+               "create_seconds": create_s, "kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok),
+               "sample_pairs": sample, "mean_path_edges": h_mean, "algorithmic_bytes_per_pair": alg,
+               "algorithmic_GBps": alg * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        out.update(leg_ceilings(be, tag, n / (ms * 1e-3), alg, info["device_bytes"]))
         return out
     finally:
         tree.close()
@@ -368,7 +498,9 @@ def other_configs(be):
     taking the headline line down with it."""
     out = {}
     for key, fn in (("config2_ml_tree", lambda: config2(be, "ml")), ("config2_nj_tree", lambda: config2(be, "nj")),
-                    ("config4_triangle_100k", lambda: config4(be)), ("config5_fish_worm", lambda: config5(be))):
+                    ("config4_triangle_100k", lambda: config4(be)), ("config5_fish_worm", lambda: config5(be)),
+                    ("walk_only_tree", lambda: shape_tree_leg(be, 0.9, "tree the canopy family refuses (walk family's tables)", "walk_bigdeep")),
+                    ("deep_long_record_tree", lambda: shape_tree_leg(be, 0.8, "deep tree with 512-byte records", "s80"))):
         t0 = time.perf_counter()
         try:
             out[key] = fn()

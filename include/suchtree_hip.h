@@ -65,6 +65,8 @@ typedef struct st_tree_info {
                                  from the record an earlier handle of the same tree on the same device left, 0 = by rule */
     int32_t host_wire_bytes_in;   /* bytes per pair the st_*_host entry points ship over the link: ids in (6 or 8) ... */
     int32_t host_wire_bytes_out;  /* ... float32 distance + MRCA id back (7 or 8); follow the wire48 / wire24 options */
+    int32_t a_side_bytes;     /* canopy family: bytes gathered for the first node of a pair, 4 (rec_a4 + block table) or 8 */
+    int32_t reserved0;
 } st_tree_info;
 
 /* st_tree_info.big_batch_kernel */
@@ -157,6 +159,23 @@ int st_distances_device(st_tree *tree, const int64_t *d_pairs, int64_t n,
 int st_distances_device_f32(st_tree *tree, const int64_t *d_pairs, int64_t n,
                             int64_t stride0, int64_t stride1,
                             float *d_out_dist, int32_t *d_out_mrca, void *stream);
+
+/*
+ * Wire format of result slices that travel (multi-GPU gather over xGMI, suchtree_amd/sharding.py::run_sharded;
+ * the host path ships the same format over PCIe): float32 distances and MRCA ids as 24 bits each -- id i at bytes
+ * [3 i, 3 i + 3) of d_out_mrca24, little endian, -1 (an id out of range) as 0xFFFFFF -- 7 bytes per pair instead of
+ * the 12 of float64 + int32.  The kernels assemble the packed stream themselves (no packing pass).  Trees of fewer
+ * than 2^24 nodes only (ST_ERR_ARG otherwise); d_out_mrca24 must be 4-byte aligned and hold 3 n bytes rounded up to
+ * a multiple of 4 (the last dword is written whole).  Either output may be NULL.  No counterpart in the reference,
+ * whose only parallel recipe is a fork pool (docs/examples/SuchTree_examples.md:462-497).
+ */
+int st_distances_device_wire(st_tree *tree, const int64_t *d_pairs, int64_t n,
+                             int64_t stride0, int64_t stride1,
+                             float *d_out_dist, uint8_t *d_out_mrca24, void *stream);
+
+/* The receiving side: n packed 24-bit ids at d_packed (any byte alignment) -> int32 at d_out_mrca (0xFFFFFF -> -1),
+ * enqueued on `stream` of `device`. */
+int st_unpack_mrca24_device(int device, const uint8_t *d_packed, int64_t n, int32_t *d_out_mrca, void *stream);
 
 /*
  * Synchronise `stream`, then report and clear the fault word written by

@@ -23,7 +23,7 @@ BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 2: "canopy_scalar", 3: "canopy_sorte
 SYMBOLS = (
     "st_last_error", "st_device_count", "st_tree_create", "st_tree_create_multi", "st_tree_devices",
     "st_host_chunk_plan", "st_host_chunk_owner", "st_tree_destroy", "st_tree_info_get",
-    "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_fault_check", "st_tree_set_strategy",
+    "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_distances_device_wire", "st_unpack_mrca24_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_host_alloc", "st_host_free", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
@@ -49,6 +49,8 @@ class TreeInfo(ctypes.Structure):
         ("tuned", ctypes.c_int32),
         ("host_wire_bytes_in", ctypes.c_int32),
         ("host_wire_bytes_out", ctypes.c_int32),
+        ("a_side_bytes", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
     def as_dict(self):
@@ -158,6 +160,8 @@ def load():
         L.st_distances_host_i32.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_distances_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
         L.st_distances_device_f32.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+        L.st_distances_device_wire.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
+        L.st_unpack_mrca24_device.argtypes = [i32, vp, i64, vp, vp]
         L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
         L.st_tree_set_strategy.argtypes = [vp, i32]
         L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
@@ -660,6 +664,17 @@ class DeviceTree:
                                            ctypes.c_void_p(d_out_mrca or None),
                                            ctypes.c_void_p(stream or None))
         check(rc)
+
+    def distances_device_wire(self, d_pairs, n, d_out_dist=0, d_out_mrca24=0, stream=0, stride0=2, stride1=1):
+        """The wire format of result slices that travel: float32 distances, MRCA ids packed as 24 bits each
+        (st_distances_device_wire; trees of fewer than 2^24 nodes)."""
+        check(self._lib.st_distances_device_wire(self.handle, ctypes.c_void_p(d_pairs), int(n), int(stride0), int(stride1),
+                                                 ctypes.c_void_p(d_out_dist or None), ctypes.c_void_p(d_out_mrca24 or None),
+                                                 ctypes.c_void_p(stream or None)))
+
+    def unpack_mrca24_device(self, d_packed, n, d_out_mrca, stream=0):
+        check(self._lib.st_unpack_mrca24_device(int(self.devices[0]), ctypes.c_void_p(d_packed), int(n), ctypes.c_void_p(d_out_mrca),
+                                                ctypes.c_void_p(stream or None)))
 
     def fault_check(self, stream=0):
         bad = ctypes.c_int64(0)

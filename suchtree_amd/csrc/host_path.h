@@ -342,7 +342,11 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         double *const pd = out_dist && !looks_resident(out_dist, seq.n * 8) ? out_dist : nullptr;
         int32_t *const pm = out_mrca && !looks_resident(out_mrca, seq.n * 4) ? out_mrca : nullptr;
         const unsigned hw = std::thread::hardware_concurrency();
-        if (!skip_cpu && seq.step == 1 && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8)
+        // (opt-in, SUCHTREE_AMD_ASYNC_PREFAULT=1: on the pool's shared two-socket hosts it measured 2-3x SLOWER than the
+        // copy pool's own per-piece populate -- 600 MB in 21-30 ms against 5-12 ms: the unpack passes catch up with
+        // the frontier and both sides then fault the same huge pages -- profiles/host_path_trace_r04.log)
+        static const bool async_on = std::getenv("SUCHTREE_AMD_ASYNC_PREFAULT") != nullptr;
+        if (async_on && !skip_cpu && seq.step == 1 && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8)
             async_prefault.start(pd, pm, seq.n, (int)std::min<unsigned>(16, hw / 4));
     }
     auto prefault = [&](int64_t off, int64_t m) {

@@ -112,6 +112,18 @@ __global__ void k_graph_laplacian(const double *__restrict__ A, const double *__
 
 // Uniform random leaf pairs for the creation-time timing of a deep tree's candidate kernels (host_tune.h): pair i =
 // (leaves[h(2i)], leaves[h(2i + 1)]), h a 32-bit mixer scaled to the leaf count by a multiply-high.
+// 24-bit MRCA ids (device_common.h::MrcaSink) -> int32: the receiving side of a result slice that travelled packed.
+// Three byte loads per lane (the packed stream may start at any byte), coalesced 4-byte stores.
+__global__ __launch_bounds__(256) void k_unpack24(const unsigned char *__restrict__ src, long long n, int *__restrict__ dst)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned char *p = src + 3 * i;
+        const unsigned v = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16);
+        dst[i] = v == 0xFFFFFFu ? -1 : (int)v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sample_leaf_pairs(const int *__restrict__ leaves, unsigned n_leaves,
                                                            long long *__restrict__ pairs, long long n)
 {

@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t rng(uint32_t &s)
 
 // each lane does iters x UNROLL independent reads of BYTES bytes at random 64-byte-aligned offsets
 template <int BYTES, int UNROLL>
-__global__ __launch_bounds__(1024) void k_gather(const uint8_t *__restrict__ table, uint32_t mask64, int iters,
+__global__ __launch_bounds__(1024) void k_gather(const uint8_t *__restrict__ table, uint32_t n_sectors, int iters,
                                                  uint32_t *out)
 {
     uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(1024) void k_gather(const uint8_t *__restrict__ tab
     for (int it = 0; it < iters; it++) {
         uint32_t off[UNROLL];
 #pragma unroll
-        for (int k = 0; k < UNROLL; k++) off[k] = rng(s) & mask64;
+        for (int k = 0; k < UNROLL; k++) off[k] = __umulhi(rng(s), n_sectors);      // (any table size, not only powers of two)
 #pragma unroll
         for (int k = 0; k < UNROLL; k++) {
             const uint8_t *p = table + (size_t)off[k] * 64;
@@ -106,7 +106,7 @@ template <int BYTES, int UNROLL>
 static int run_gather(const uint8_t *d_table, size_t table_bytes, uint32_t *d_out, int blocks, int reps,
                       double *greads_per_s, double *ms_out, int threads = 1024)
 {
-    const uint32_t mask64 = (uint32_t)(table_bytes / 64 - 1);
+    const uint32_t n_sectors = (uint32_t)(table_bytes / 64);
     const int iters = 256 / UNROLL;
     hipEvent_t e0, e1;
     STMB_CK(hipEventCreate(&e0));
@@ -114,7 +114,7 @@ static int run_gather(const uint8_t *d_table, size_t table_bytes, uint32_t *d_ou
     float best = 1e30f;
     for (int rep = 0; rep < reps + 1; rep++) {
         STMB_CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((k_gather<BYTES, UNROLL>), dim3(blocks), dim3(threads), 0, 0, d_table, mask64, iters, d_out);
+        hipLaunchKernelGGL((k_gather<BYTES, UNROLL>), dim3(blocks), dim3(threads), 0, 0, d_table, n_sectors, iters, d_out);
         STMB_CK(hipEventRecord(e1));
         STMB_CK(hipEventSynchronize(e1));
         float ms;
@@ -134,12 +134,12 @@ static int run_gather(const uint8_t *d_table, size_t table_bytes, uint32_t *d_ou
 extern "C" {
 
 // Uniformly random reads of `bytes_per_read` (4, 8, 16, 32 or 64) bytes at 64-byte-aligned
-// offsets of a `table_bytes` (power of two, >= 64) table, `blocks` x 1024 lanes x 256 reads.
+// offsets of a `table_bytes` (a multiple of 64) table, `blocks` x 1024 lanes x 256 reads.
 // Returns 0 and the best-of-`reps` rate in G reads/s.
 int stmb_random_sector_reads(int device, long long table_bytes, int bytes_per_read, int blocks, int reps,
                              double *greads_per_s)
 {
-    if (table_bytes < 64 || (table_bytes & (table_bytes - 1)) || blocks < 1 || reps < 1) return 2;
+    if (table_bytes < 64 || (table_bytes & 63) || table_bytes / 64 > 0xFFFFFFFFLL || blocks < 1 || reps < 1) return 2;
     STMB_CK(hipSetDevice(device));
     uint8_t *d_table = nullptr;
     uint32_t *d_out = nullptr;
@@ -196,8 +196,8 @@ int stmb_stream_copy(int device, long long bytes, int reps, double *gbytes_per_s
 int stmb_random_sector_reads_shape(int device, long long table_bytes, int bytes_per_read, int unroll, int blocks,
                                    int threads, int reps, double *greads_per_s)
 {
-    if (table_bytes < 64 || (table_bytes & (table_bytes - 1)) || blocks < 1 || reps < 1 || threads < 64 || threads > 1024 ||
-        (threads & 63))
+    if (table_bytes < 64 || (table_bytes & 63) || table_bytes / 64 > 0xFFFFFFFFLL || blocks < 1 || reps < 1 || threads < 64 ||
+        threads > 1024 || (threads & 63))
         return 2;
     if (bytes_per_read != 32 && bytes_per_read != 4) return 2;
     STMB_CK(hipSetDevice(device));

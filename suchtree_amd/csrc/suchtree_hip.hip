@@ -293,6 +293,7 @@ try {
     *info = t->info;
     info->strategy = t->strategy;
     info->big_batch_kernel = big_batch_kernel_of(t);      // (follows the handle's current options)
+    info->a_side_bytes = t->has_canopy ? ((t->rec_a4 && t->d_rec_a4 && t->d_leaf_blocks) ? 4 : 8) : 0;
     info->host_wire_bytes_in = t->wire48 && t->n_nodes <= 0xFFFFFF ? 6 : 8;
     info->host_wire_bytes_out = t->wire24 && t->n_nodes <= 0xFFFFFF ? 7 : 8;
     return ST_OK;
@@ -442,6 +443,32 @@ try {
     ST_DEVICE(t->device);
     return enqueue(t, d_pairs, n, stride0, stride1, DistSink{nullptr, d_out_dist}, MrcaSink{d_out_mrca, nullptr},
                    reinterpret_cast<hipStream_t>(stream));
+} ST_CATCH_ALL
+
+int st_distances_device_wire(st_tree *t, const int64_t *d_pairs, int64_t n, int64_t stride0, int64_t stride1,
+                             float *d_out_dist, uint8_t *d_out_mrca24, void *stream)
+try {
+    if (!t) return fail(ST_ERR_ARG, "tree is NULL");
+    if (n < 0) return fail(ST_ERR_ARG, "n < 0");
+    if (n > 0 && !d_pairs) return fail(ST_ERR_ARG, "pairs is NULL");
+    if (!d_out_dist && !d_out_mrca24) return fail(ST_ERR_ARG, "both outputs are NULL");
+    if (t->n_nodes > 0xFFFFFF) return fail(ST_ERR_ARG, "24-bit MRCA ids need a tree of fewer than 2^24 nodes");
+    if (reinterpret_cast<uintptr_t>(d_out_mrca24) & 3) return fail(ST_ERR_ARG, "d_out_mrca24 must be 4-byte aligned");
+    ST_DEVICE(t->device);
+    return enqueue(t, d_pairs, n, stride0, stride1, DistSink{nullptr, d_out_dist}, MrcaSink{nullptr, d_out_mrca24},
+                   reinterpret_cast<hipStream_t>(stream));
+} ST_CATCH_ALL
+
+int st_unpack_mrca24_device(int device, const uint8_t *d_packed, int64_t n, int32_t *d_out_mrca, void *stream)
+try {
+    if (n < 0) return fail(ST_ERR_ARG, "n < 0");
+    if (n == 0) return ST_OK;
+    if (!d_packed || !d_out_mrca) return fail(ST_ERR_ARG, "buffer is NULL");
+    ST_DEVICE(device);
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_unpack24, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), d_packed, (long long)n, d_out_mrca);
+    ST_HIP(hipGetLastError());
+    return ST_OK;
 } ST_CATCH_ALL
 
 int st_fault_check(st_tree *t, void *stream, int64_t *bad_id)

@@ -54,10 +54,13 @@ class ShardPlan:
     """
 
     def __init__(self, n: int, world: int, rank: int, chunks: int = 4, root: int = 0,
-                 root_share: Optional[float] = None):
-        if n < 0 or chunks < 1 or not (0 <= root < world):
+                 root_share: Optional[float] = None, align: int = 1):
+        if n < 0 or chunks < 1 or not (0 <= root < world) or align < 1:
             raise ValueError("bad plan")
         self.n, self.world, self.rank, self.chunks, self.root = int(n), int(world), int(rank), int(chunks), int(root)
+        # piece boundaries inside a slice fall on multiples of `align` pairs from the slice's start (the packed
+        # 24-bit id stream of a piece starts on a 4-byte boundary of the slice's buffer: align = 4)
+        self.align = int(align)
         shard_bounds(n, world, rank)   # validates world / rank
         if root_share is None or world == 1:
             self.root_pairs = None
@@ -88,10 +91,41 @@ class ShardPlan:
         """Global pair range of piece ``c`` of rank ``g``'s slice (may be empty)."""
         lo, hi = self.bounds(g)
         plo, phi = shard_bounds(hi - lo, self.chunks, c)
+        if self.align > 1:
+            plo = plo // self.align * self.align
+            phi = hi - lo if c == self.chunks - 1 else phi // self.align * self.align
         return lo + plo, lo + phi
 
     def pieces(self, g: int):
         return [self.piece(g, c) for c in range(self.chunks)]
+
+
+WIRE_BYTES_PACKED = 7      # float32 distance + 24-bit MRCA id (trees of fewer than 2^24 nodes)
+WIRE_BYTES_PLAIN = 8       # float32 distance + int32 MRCA id
+
+
+def packed_bytes(n_pairs: int) -> int:
+    """Bytes of ``n_pairs`` packed 24-bit ids, rounded up to whole dwords (the kernels store dwords)."""
+    return (3 * int(n_pairs) + 3) // 4 * 4
+
+
+def unpack_mrca24(packed, out):
+    """``out[i]`` (int32) <- the 24-bit id at bytes [3 i, 3 i + 3) of the uint8 tensor ``packed``, 0xFFFFFF -> -1.
+    Plain torch ops: works on CPU (gloo tests) and device tensors; the GPU bench passes the library's kernel
+    (``st_unpack_mrca24_device``) to ``run_sharded`` instead."""
+    import torch
+    n = out.numel()
+    b = packed[: 3 * n].view(n, 3).to(torch.int32)
+    v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+    out.copy_(torch.where(v == 0xFFFFFF, torch.full_like(v, -1), v))
+
+
+def pack_mrca24(ids, packed):
+    """The inverse (test backends and reference for the kernels' packing): int32 ids -> 3 bytes each, -1 -> 0xFFFFFF."""
+    import torch
+    n = ids.numel()
+    v = ids.to(torch.int32) & 0xFFFFFF
+    packed[: 3 * n].view(n, 3).copy_(torch.stack([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF], 1).to(torch.uint8))
 
 
 def balanced_root_share(world: int, kernel_pairs_per_s: float, link_bytes_per_s: float,
@@ -107,7 +141,7 @@ def balanced_root_share(world: int, kernel_pairs_per_s: float, link_bytes_per_s:
 
 
 def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=None, wire_m=None,
-                group=None):
+                group=None, unpack: Optional[Callable] = None):
     """One pass of the hot path over ``plan.n`` pairs, sharded over the process group, with
     the result assembled on ``plan.root``: the north star's "pair batches shard across the
     GPUs, RCCL over xGMI only for the final gather".  The same code runs on ``nccl`` (RCCL,
@@ -116,19 +150,27 @@ def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=N
     ``compute(lo, hi, dst_d, dst_m)`` performs (or enqueues on the current stream) the pair
     computation for the global pair range ``[lo, hi)``: distances into the 1-D tensor
     ``dst_d`` (float64 or float32 -- the values are float32 sums either way), MRCA ids into
-    the int32 tensor ``dst_m``, both of length ``hi - lo``.
+    ``dst_m``: an int32 tensor of length ``hi - lo``, or -- the packed wire format -- a uint8
+    tensor of ``packed_bytes(hi - lo)`` bytes that receives them as 24 bits each.
+
+    Wire format: ``wire_m`` of dtype uint8 (``sharded_buffers(..., packed_ids=True)``; trees of
+    fewer than 2^24 nodes) = float32 + 24-bit id, **7 bytes per pair**, packed by the peers'
+    kernels themselves (``st_distances_device_wire``), unpacked on the root piece by piece
+    (``unpack(packed_piece, result_m_piece)``, default ``unpack_mrca24``); int32 = 8 bytes per
+    pair, ids received straight into ``result_m``.  The plan must have ``align`` 4 in packed mode.
 
     Root:   ``result_d`` float64[n] and ``result_m`` int32[n] receive everything: its own
-            slice is computed in place, the peers' pieces arrive by point-to-point receives
-            -- MRCA ids straight into ``result_m``, distances as float32 into ``wire_d``
-            (float32[n], root only) and are widened into ``result_d`` piece by piece.
-            A gather to one root uses every peer's own xGMI link to the root at once; a
-            ring all-gather would push (G-1)/G of all bytes through every single link.
-    Peers:  compute piece c into ``wire_d`` / ``wire_m`` (float32 / int32, slice length)
-            and send it while piece c+1 is being computed.  8 bytes per pair on the wire.
+            slice is computed in place, the peers' pieces arrive by point-to-point receives;
+            distances as float32 into ``wire_d`` (float32[n], root only), widened into
+            ``result_d`` piece by piece.  A gather to one root uses every peer's own xGMI link
+            to the root at once; a ring all-gather would push (G-1)/G of all bytes through
+            every single link.
+    Peers:  compute piece c into ``wire_d`` / ``wire_m`` (slice-sized) and send it while piece
+            c+1 is being computed.
     Returns the list of pending communication handles, already waited on (stream-ordered
     for RCCL: the caller's current stream is made to wait, the host is not blocked).
     """
+    import torch
     import torch.distributed as dist
 
     world, rank, root = plan.world, plan.rank, plan.root
@@ -137,6 +179,11 @@ def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=N
         if hi > lo:
             compute(lo, hi, result_d[lo:hi], result_m[lo:hi])
         return []
+    packed = wire_m is not None and wire_m.dtype == torch.uint8
+    if packed and plan.align % 4 != 0:
+        raise ValueError("the packed wire format needs a plan with align = 4")
+    if unpack is None:
+        unpack = unpack_mrca24
     pending = []
     if rank == root:
         # receives first: they only depend on the peers, so they run under the root's own kernels
@@ -148,7 +195,7 @@ def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=N
                 plo, phi = plan.piece(g, c)
                 if phi > plo:
                     ops.append(dist.P2POp(dist.irecv, wire_d[plo:phi], g, group))
-                    ops.append(dist.P2POp(dist.irecv, result_m[plo:phi], g, group))
+                    ops.append(dist.P2POp(dist.irecv, wire_m[3 * plo:3 * phi] if packed else result_m[plo:phi], g, group))
             pending.append(dist.batch_isend_irecv(ops) if ops else [])
         for plo, phi in plan.pieces(rank):
             if phi > plo:
@@ -162,15 +209,23 @@ def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=N
                 plo, phi = plan.piece(g, c)
                 if phi > plo:
                     result_d[plo:phi].copy_(wire_d[plo:phi])     # float32 -> float64, exact
+                    if packed:
+                        unpack(wire_m[3 * plo:3 * phi], result_m[plo:phi])
         return pending
     for c in range(plan.chunks):
         plo, phi = plan.piece(rank, c)
         if phi <= plo:
             continue
-        dst_d, dst_m = wire_d[plo - lo:phi - lo], wire_m[plo - lo:phi - lo]
+        dst_d = wire_d[plo - lo:phi - lo]
+        if packed:
+            at = 3 * (plo - lo)      # (a multiple of 4: plan.align)
+            dst_m = wire_m[at:at + packed_bytes(phi - plo)]
+            send_m = wire_m[at:at + 3 * (phi - plo)]
+        else:
+            dst_m = send_m = wire_m[plo - lo:phi - lo]
         compute(plo, phi, dst_d, dst_m)
         pending.append(dist.batch_isend_irecv([dist.P2POp(dist.isend, dst_d, root, group),
-                                               dist.P2POp(dist.isend, dst_m, root, group)]))
+                                               dist.P2POp(dist.isend, send_m, root, group)]))
     for works in pending:
         for w in works:
             w.wait()     # the wire buffers may be overwritten by the next pass after this
@@ -216,9 +271,11 @@ def measure_root_share(world: int, rank: int, kernel_pairs_per_s: float, device=
     return float(t[0].item()), float(t[1].item()), float(t[2].item())
 
 
-def sharded_buffers(plan: ShardPlan, device=None):
+def sharded_buffers(plan: ShardPlan, device=None, packed_ids: bool = False):
     """(result_d, result_m, wire_d, wire_m) torch tensors of the sizes ``run_sharded`` needs on
-    this rank: results only on the root, wire buffers only where something travels."""
+    this rank: results only on the root, wire buffers only where something travels.
+    ``packed_ids``: MRCA ids travel as 24 bits each (``wire_m`` is uint8: on the peers 3 bytes per
+    pair of the slice, on the root 3 bytes per pair of the batch, each with a few bytes of slack)."""
     import torch
 
     lo, hi = plan.bounds(plan.rank)
@@ -228,7 +285,10 @@ def sharded_buffers(plan: ShardPlan, device=None):
     if plan.world == 1:
         return result_d, result_m, None, None
     wire_d = torch.empty(plan.n if root else hi - lo, dtype=torch.float32, device=device)
-    wire_m = None if root else torch.empty(hi - lo, dtype=torch.int32, device=device)
+    if packed_ids:
+        wire_m = torch.empty(packed_bytes(plan.n if root else hi - lo) + 16, dtype=torch.uint8, device=device)
+    else:
+        wire_m = None if root else torch.empty(hi - lo, dtype=torch.int32, device=device)
     return result_d, result_m, wire_d, wire_m
 
 

@@ -126,6 +126,35 @@ def random_binary_tree(n_leaves, seed=0, zero_fraction=0.0):
     return parent.astype(np.int32), lengths.astype(np.float32)
 
 
+def skewed_tree(rng, n_leaves, skew):
+    """Random strictly binary tree whose split sizes are skewed towards caterpillars (skew -> 1) or towards
+    balance (skew -> 0); in-order ids.  ``rng``: a numpy Generator (the tree is a function of its state).  With
+    ``default_rng(5)`` and 1,000,000 leaves: skew 0.8 -> depth 173 (512-byte records), 0.9 -> depth 338 (the canopy
+    family refuses it: the walk family's tables serve it)."""
+    n = 2 * n_leaves - 1
+    parent = np.full(n, -1, dtype=np.int64)
+    stack = [(0, n - 1, -1)]
+    while stack:
+        lo, hi, par = stack.pop()
+        if lo == hi:
+            parent[lo] = par
+            continue
+        leaves = (hi - lo) // 2 + 1
+        if rng.random() < skew:
+            left = 1 if rng.random() < 0.5 else leaves - 1
+        else:
+            left = int(rng.integers(max(1, leaves // 2 - leaves // 8), min(leaves - 1, leaves // 2 + leaves // 8) + 1))
+        left = min(max(left, 1), leaves - 1)
+        node = lo + 2 * left - 1
+        parent[node] = par
+        stack.append((lo, node - 1, node))
+        stack.append((node + 1, hi, node))
+    dist = rng.uniform(1e-4, 3.0, size=n)
+    dist[rng.random(n) < 0.1] = np.finfo(np.float64).eps
+    dist[parent < 0] = -1.0
+    return parent.astype(np.int32), dist.astype(np.float32)
+
+
 def random_leaf_pairs(n_leaves, n_pairs, seed=3):
     """Uniform random leaf-id pairs, int64 (n,2) C-order (leaves = even ids)."""
     rng = np.random.default_rng(seed)

@@ -51,7 +51,13 @@ class CpuBackend:
                 time.sleep(120)
             t0 = time.perf_counter()
             dst_d.copy_(self.torch.from_numpy(self.O.distances(p[lo:hi])).to(dst_d.dtype))
-            dst_m.copy_(self.torch.from_numpy(self.O.mrca_bulk(p[lo:hi])))
+            ids = self.torch.from_numpy(self.O.mrca_bulk(p[lo:hi]))
+            if dst_m.dtype == self.torch.uint8:      # the gather's packed wire format (what st_distances_device_wire writes)
+                from suchtree_amd import sharding
+                assert dst_m.numel() == sharding.packed_bytes(hi - lo)
+                sharding.pack_mrca24(ids, dst_m)
+            else:
+                dst_m.copy_(ids)
             self._ms += (time.perf_counter() - t0) * 1e3
             self.calls.append((lo, hi))
         return compute
@@ -99,12 +105,14 @@ def _run(world, argv, hang_rank=None, timeout=180):
     return procs, q, timeout
 
 
-@pytest.mark.parametrize("world,share,chunks,n", [(2, "auto", 4, 30011), (3, "auto", 4, 30011), (4, "even", 1, 1003),
-                                                   (4, "0.5", 3, 30011), (3, "0.9", 2, 7)])
-def test_bench_job_line_on_gloo(world, share, chunks, n):
+@pytest.mark.parametrize("world,share,chunks,n,wire", [(2, "auto", 4, 30011, 7), (3, "auto", 4, 30011, 7), (4, "even", 1, 1003, 7),
+                                                        (4, "0.5", 3, 30011, 8), (3, "0.9", 2, 7, 7), (2, "auto", 3, 30013, 8)])
+def test_bench_job_line_on_gloo(world, share, chunks, n, wire):
+    """wire = 7: float32 + 24-bit MRCA ids travel (packed by the compute step, unpacked on the root piece by piece);
+    8: --wire-int32."""
     from suchtree_amd import sharding
     argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--pairs", str(n), "--levels", "9",
-            "--chunks", str(chunks), "--root-share", share, "--cpu-seconds", "0.2", "--deadline", "120"]
+            "--chunks", str(chunks), "--root-share", share, "--cpu-seconds", "0.2", "--deadline", "120"] + (["--wire-int32"] if wire == 8 else [])
     procs, q, timeout = _run(world, argv)
     res = sorted(q.get(timeout=timeout) for _ in procs)
     [p.join(timeout=60) for p in procs]
@@ -127,18 +135,19 @@ def test_bench_job_line_on_gloo(world, share, chunks, n):
     if share == "auto":
         cal = d["root_share_calibration"]
         assert cal["kernel_pairs_per_s"] == 2.0e6 and cal["link_GBps_into_root_per_peer"] > 0
-        expect = min(0.95, max(1.0 / world, sharding.balanced_root_share(world, 2.0e6, cal["link_GBps_into_root_per_peer"] * 1e9)))
+        expect = min(0.95, max(1.0 / world, sharding.balanced_root_share(world, 2.0e6, cal["link_GBps_into_root_per_peer"] * 1e9, wire)))
     else:
         expect = None if share == "even" else float(share)
     covered = []
     for rank, _, calls in res:
-        plan = sharding.ShardPlan(n, world, rank, chunks=chunks, root_share=expect)
+        plan = sharding.ShardPlan(n, world, rank, chunks=chunks, root_share=expect, align=4)
         want = [pc for pc in plan.pieces(rank) if pc[1] > pc[0]] * 2
         assert [tuple(c) for c in calls] == want
         covered += want[: len(want) // 2]
         if rank == 0:
             assert abs(d["root_share"] - (plan.bounds(0)[1] - plan.bounds(0)[0]) / n) < 1e-12
-            assert d["gather_bytes_into_root"] == 8 * (n - (plan.bounds(0)[1] - plan.bounds(0)[0]))
+            assert d["wire_bytes_per_pair"] == wire
+            assert d["gather_bytes_into_root"] == wire * (n - (plan.bounds(0)[1] - plan.bounds(0)[0]))
     covered.sort()
     assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
 

@@ -11,6 +11,15 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
                           "--pairs", "4000000", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900)
@@ -25,8 +34,13 @@ def test_bench_line_contract():
     assert d["unit"] == "pairs/s" and d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    # the block names the ceiling that binds (the fabric's random-sector request rate, measured in the same process at
+    # the kernel's own footprint) and stays below it; the SURVEY 8d algorithmic figure rides along as algorithmic_*
+    assert r["bound"] == "fabric_random_sector" and r["unit"] == "Greads/s" and 30 < r["peak"] < 400
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] <= 1.02, r
+    assert r["algorithmic_bytes_per_pair"] > 300 and abs(r["algorithmic_frac_of_hbm_peak"] - r["algorithmic_GBps"] / 8000.0) < 1e-12
+    assert 0 < r["counter_traffic"]["frac_of_hbm_peak"] < 1 and r["request_rate"]["frac"] == r["frac"]
+    assert abs(r["gather_footprint_MiB"] - d["hardware_measured"]["table"]["MiB"]) < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "pairs/s" and c["sample"]
     assert d["parity"]["distances_bit_exact"] and d["parity"]["mrca_bit_exact"]
@@ -36,6 +50,8 @@ def test_bench_line_contract():
     assert d["hardware_measured"]["table"]["Greads_per_s"] > 1 and d["hardware_measured"]["stream_copy_GBps"] > 100
     e = d["end_to_end_host_path"]
     assert e["pairs_per_s"] > 1e8 and e["pairs_per_s_fresh_arrays"] > 1e8 and e["pairs_per_s_call_and_drop_loop"] > 1e8
+    assert e["cpu_passes_pairs_per_s"] > e["pairs_per_s"] * 0.5 and e["link_side_pairs_per_s"] > e["pairs_per_s"] * 0.5
+    assert e["link_bytes_per_pair"] == {"in": 6, "out": 7} and e["one_process_many_gpus_ceiling"]["x_one_gpu"] > 0.5
     assert d["mrca_ids_only"]["matches_the_fused_launch"] and d["mrca_ids_only"]["ids_per_s"] > 1e9
     # ceilings are the best of a sweep of launch shapes, and the shape is reported
     hw = d["hardware_measured"]
@@ -52,6 +68,10 @@ def test_bench_line_contract():
     t = oc["config4_triangle_100k"]
     assert t["pairs"] == 4_999_950_000 and t["bit_exact_on_sample"] and t["canopy"]["pairs_per_s"] > 1e10
     assert t["streamed_to_host"]["pairs"] == 1 << 30 and t["streamed_to_host"]["pairs_per_s"] > 1e9
+    for key in ("walk_only_tree", "deep_long_record_tree"):
+        assert "error" not in oc[key], oc[key]
+        assert oc[key]["bit_exact_on_sample"] and oc[key]["pairs_per_s"] > 1e9, oc[key]
+    assert oc["walk_only_tree"]["kernel_family"] == "walk" and oc["deep_long_record_tree"]["record_bytes"] == 512
     f = oc["config5_fish_worm"]
     assert f["distances_bit_exact"] and f["laplacian_bit_exact"] and f["pairs"] == 2 * 18145 and f["laplacian_shape"] == [422, 422]
 
@@ -60,7 +80,7 @@ def test_bench_under_torchrun_one_rank():
     """The N > 1 code path (process group, sharded step, barriers) with world size 1 -- all a
     1-GPU box can run of it; the slicing / gather itself is covered by the gloo tests."""
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "2000000", "--cpu-seconds", "1",
                           "--no-host-path", "--no-microbench", "--no-other-configs"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]

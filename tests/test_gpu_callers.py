@@ -407,6 +407,63 @@ def test_sharded_device_path_with_rccl_single_rank(ml_arrays):
     assert np.array_equal(m.cpu().numpy(), O.mrca_bulk(host))
 
 
+def test_wire_format_of_the_gather_on_one_gpu(ml_arrays):
+    """What a peer's kernels write for the multi-GPU gather (st_distances_device_wire: float32 + 24-bit ids, packed by
+    the kernels themselves) is what the root unpacks (st_unpack_mrca24_device, and the torch form the gloo tests
+    use), piece by piece at 4-pair boundaries of a slice, for every kernel family."""
+    import torch
+    parent, dist_arr, leaf_ids = ml_arrays
+    rng = np.random.default_rng(77)
+    trees = [("ml.tree", parent, dist_arr, {}), ("ml.tree, walk family", parent, dist_arr, {"strategy": "walk"}),
+             ("2^16 leaves", *synth.balanced_tree(16), {}), ("2^16 leaves, scalar kernel", *synth.balanced_tree(16), {"pairs_per_lane": 0})]
+    for what, par, dst, opts in trees:
+        dev = _capi.DeviceTree(par, dst)
+        for name, v in opts.items():
+            dev.set_strategy(v) if name == "strategy" else dev.set_option(name, v)
+        n = 700_003
+        host = rng.integers(0, len(par), (n, 2))
+        host[::11, 1] = host[::11, 0]
+        pairs = torch.from_numpy(host).cuda()
+        ref_d = torch.empty(n, dtype=torch.float32, device="cuda")
+        ref_m = torch.empty(n, dtype=torch.int32, device="cuda")
+        dev.distances_device(pairs.data_ptr(), n, ref_d.data_ptr(), ref_m.data_ptr(), f32=True)
+        plan = sharding.ShardPlan(n, 1, 0, chunks=5, align=4)
+        wire_d = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+        wire_m = torch.full((sharding.packed_bytes(n) + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+        for lo, hi in plan.pieces(0):
+            assert lo % 4 == 0
+            dev.distances_device_wire(pairs.data_ptr() + 16 * lo, hi - lo, wire_d.data_ptr() + 4 * lo, wire_m.data_ptr() + 3 * lo)
+        dev.fault_check()
+        assert torch.equal(wire_d.view(torch.int32), ref_d.view(torch.int32)), what
+        assert bool((wire_m[sharding.packed_bytes(n):] == 0xEE).all()), what      # nothing written past the last dword
+        got = torch.empty(n, dtype=torch.int32, device="cuda")
+        for lo, hi in plan.pieces(0):      # the library's kernel, at any byte offset
+            dev.unpack_mrca24_device(wire_m.data_ptr() + 3 * lo, hi - lo, got.data_ptr() + 4 * lo)
+        assert torch.equal(got, ref_m), what
+        got.fill_(-9)
+        sharding.unpack_mrca24(wire_m, got)
+        assert torch.equal(got, ref_m), what
+        # ids only / distances only
+        wire_m.fill_(0xEE)
+        dev.distances_device_wire(pairs.data_ptr(), n, 0, wire_m.data_ptr())
+        sharding.unpack_mrca24(wire_m, got)
+        assert torch.equal(got, ref_m), what
+        wire_d.fill_(-7.0)
+        dev.distances_device_wire(pairs.data_ptr(), n, wire_d.data_ptr(), 0)
+        assert torch.equal(wire_d.view(torch.int32), ref_d.view(torch.int32)), what
+        # an id out of range travels as 0xFFFFFF and comes back as -1
+        bad = pairs[:1000].clone()
+        bad[5, 0] = len(par)
+        dev.distances_device_wire(bad.data_ptr(), 1000, wire_d.data_ptr(), wire_m.data_ptr())
+        sharding.unpack_mrca24(wire_m, got[:1000])
+        assert int(got[5]) == -1 and torch.equal(got[6:1000], ref_m[6:1000])
+        with pytest.raises(InvalidNodeError):
+            dev.fault_check()
+        with pytest.raises(Exception):
+            dev.distances_device_wire(pairs.data_ptr(), 16, wire_d.data_ptr(), wire_m.data_ptr() + 1)      # not 4-byte aligned
+        dev.close()
+
+
 def _sum_of_all_pairwise_distances(parent, dist, n_leaves_total):
     """Closed form, float64: every edge e contributes length(e) * s(e) * (m - s(e)) to the sum over all
     unordered leaf pairs, s(e) = leaves below e.  Children have smaller depth-order than parents in a

@@ -483,30 +483,7 @@ def test_concurrent_callers_share_one_handle(ml_arrays):
 
 
 def _random_shape_tree(rng, n_leaves, skew):
-    """Random strictly binary tree whose split sizes are skewed towards caterpillars
-    (skew -> 1) or towards balance (skew -> 0); in-order ids."""
-    n = 2 * n_leaves - 1
-    parent = np.full(n, -1, dtype=np.int64)
-    stack = [(0, n - 1, -1)]
-    while stack:
-        lo, hi, par = stack.pop()
-        if lo == hi:
-            parent[lo] = par
-            continue
-        leaves = (hi - lo) // 2 + 1
-        if rng.random() < skew:
-            left = 1 if rng.random() < 0.5 else leaves - 1
-        else:
-            left = int(rng.integers(max(1, leaves // 2 - leaves // 8), min(leaves - 1, leaves // 2 + leaves // 8) + 1))
-        left = min(max(left, 1), leaves - 1)
-        node = lo + 2 * left - 1
-        parent[node] = par
-        stack.append((lo, node - 1, node))
-        stack.append((node + 1, hi, node))
-    dist = rng.uniform(1e-4, 3.0, size=n)
-    dist[rng.random(n) < 0.1] = np.finfo(np.float64).eps
-    dist[parent < 0] = -1.0
-    return parent.astype(np.int32), dist.astype(np.float32)
+    return synth.skewed_tree(rng, n_leaves, skew)
 
 
 def test_record_sizes_and_shapes_sweep():
@@ -744,6 +721,7 @@ def test_deep_canopy_tree_with_walk_form_lineage_tables(ml_arrays, monkeypatch):
         dev.set_option("tile_sort", sort)
         dev.set_option("pairs_per_lane", ppl)
         dev.set_option("prefer_walk_sorted", walk)
+        dev.set_option("ladder_scalar", 0)      # (the handle may have chosen it; its own test: ..._is_timed_at_creation)
         kernel = dev.info()["big_batch_kernel"]
         seen.add(kernel)
         for n_dev in (len(allp), 140_000, 20_000, 3_000):      # sorted kernels, mid-sized batches, k_walk, mailbox size

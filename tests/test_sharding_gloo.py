@@ -64,7 +64,7 @@ def _worker(rank, world, port, n_pairs, q):
         dist.destroy_process_group()
 
 
-def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=None):
+def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=None, packed=False):
     """bench.py's step, verbatim (sharding.run_sharded), on gloo/CPU tensors with the oracle
     injected as the compute step: slices, pieces, float32 wire format, assembly on the root."""
     import torch
@@ -78,14 +78,22 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=
         parent, dist_ = synth.balanced_tree(9)
         O = OracleTree(parent, dist_)
         pairs = np.random.default_rng(5).integers(0, len(parent), (n_pairs, 2))
-        plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, root=root, root_share=root_share)
-        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan)
+        if packed:
+            pairs[::7, 0] = pairs[::7, 1]      # (x, x): every node id of the tree turns up as an MRCA, the largest included
+        plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, root=root, root_share=root_share, align=4 if packed else 1)
+        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, packed_ids=packed)
         calls = []
 
         def compute(lo, hi, dst_d, dst_m):
             calls.append((lo, hi, dst_d.dtype))
             dst_d.copy_(torch.from_numpy(O.distances(pairs[lo:hi])).to(dst_d.dtype))
-            dst_m.copy_(torch.from_numpy(O.mrca_bulk(pairs[lo:hi])))
+            ids = torch.from_numpy(O.mrca_bulk(pairs[lo:hi]))
+            if dst_m.dtype == torch.uint8:      # the packed wire format: 24 bits per id, whole dwords (the kernels' stores)
+                assert packed and rank != root and dst_m.numel() == sharding.packed_bytes(hi - lo) and dst_m.data_ptr() % 4 == 0
+                dst_m.fill_(0)
+                sharding.pack_mrca24(ids, dst_m)
+            else:
+                dst_m.copy_(ids)
 
         for _ in range(2):     # twice: buffers are reused from pass to pass, as in the bench loop
             sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
@@ -106,12 +114,15 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=
     # more than one peer: the root posts receives from several ranks per piece, peers are indexed around the root
     (3, 1001, 4, 0, None), (3, 1001, 1, 1, 0.5), (3, 1000, 4, 2, 0.31), (4, 1001, 4, 0, 0.5), (4, 1003, 1, 2, None),
     (4, 1003, 4, 1, 0.41), (4, 3, 4, 0, None), (4, 1001, 3, 3, 0.9)])
-def test_run_sharded_gloo(world, n_pairs, chunks, root, root_share):
+@pytest.mark.parametrize("packed", [False, True])
+def test_run_sharded_gloo(world, n_pairs, chunks, root, root_share, packed):
+    """packed: MRCA ids travel as 24 bits each (7 bytes per pair with the float32 distance), pieces start on
+    4-pair boundaries of their slice, the root unpacks piece by piece."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_run_sharded, args=(r, world, port, n_pairs, chunks, root, q, root_share))
+    procs = [ctx.Process(target=_worker_run_sharded, args=(r, world, port, n_pairs, chunks, root, q, root_share, packed))
              for r in range(world)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=120) for _ in procs)
@@ -166,17 +177,33 @@ def test_balanced_root_share():
     assert abs(t_root - t_peer) / t_root < 0.01
 
 
+def test_pack_and_unpack_of_24_bit_ids():
+    import torch
+    ids = torch.tensor([0, 1, 255, 256, 65535, 65536, 0xFFFFFE, -1, 12345678, -1, 7], dtype=torch.int32)
+    buf = torch.full((sharding.packed_bytes(len(ids)) + 5,), 0xAB, dtype=torch.uint8)
+    sharding.pack_mrca24(ids, buf)
+    assert bytes(buf[:6].tolist()) == bytes([0, 0, 0, 1, 0, 0]) and bytes(buf[21:24].tolist()) == b"\xff\xff\xff"
+    assert all(int(b) == 0xAB for b in buf[3 * len(ids):])
+    back = torch.empty(len(ids), dtype=torch.int32)
+    sharding.unpack_mrca24(buf, back)
+    assert torch.equal(back, ids)
+    assert [sharding.packed_bytes(k) for k in (0, 1, 2, 3, 4, 5)] == [0, 4, 8, 12, 12, 16]
+
+
 def test_shard_plan_pieces_tile_the_batch():
+    cases = ((1, None, 0), (3, None, 0), (4, None, 0), (4, 0.45, 0), (3, 0.9, -1), (2, 1.0, 0))
     for n in (0, 5, 1000, 12345):
         for world in (1, 2, 8):
-            for chunks, share, root in ((1, None, 0), (3, None, 0), (4, None, 0), (4, 0.45, 0), (3, 0.9, world - 1), (2, 1.0, 0)):
-                seen = []
-                for g in range(world):
-                    plan = sharding.ShardPlan(n, world, g, chunks=chunks, root=root, root_share=share)
-                    assert plan.pieces(g)[0][0] == plan.bounds(g)[0] and plan.pieces(g)[-1][1] == plan.bounds(g)[1]
-                    seen += plan.pieces(g)
-                assert seen[0][0] == 0 and seen[-1][1] == n
-                assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+            for chunks, share, root in cases:
+                for align in (1, 4):      # 4: pieces start on 4-pair boundaries of their slice (packed 24-bit ids)
+                    seen = []
+                    for g in range(world):
+                        plan = sharding.ShardPlan(n, world, g, chunks=chunks, root=root % world, root_share=share, align=align)
+                        assert plan.pieces(g)[0][0] == plan.bounds(g)[0] and plan.pieces(g)[-1][1] == plan.bounds(g)[1]
+                        assert all((lo - plan.bounds(g)[0]) % align == 0 for lo, _ in plan.pieces(g))
+                        seen += plan.pieces(g)
+                    assert seen[0][0] == 0 and seen[-1][1] == n
+                    assert all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
 
 
 @pytest.mark.parametrize("n_pairs", [1001, 4])
