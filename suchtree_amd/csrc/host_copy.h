@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -260,8 +261,30 @@ inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, 
     _mm_sfence();
 }
 
+// Transparent huge pages available to madvise(MADV_HUGEPAGE) ranges ("always" or "madvise" in sysfs)?
+inline bool thp_available()
+{
+    static const bool yes = [] {
+        FILE *f = std::fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r");
+        if (!f) return false;
+        char buf[128] = {0};
+        const size_t got = std::fread(buf, 1, sizeof buf - 1, f);
+        std::fclose(f);
+        buf[got] = 0;
+        return std::strstr(buf, "[always]") != nullptr || std::strstr(buf, "[madvise]") != nullptr;
+    }();
+    return yes;
+}
+
 // Make [p, p + bytes) resident and writable without taking one page fault per 4 KiB inside
 // the copy loops.  Safe on any memory the caller is about to overwrite anyway.
+// Two forms, by what the host offers (scripts/micro/populate_bench.cpp, profiles/populate_bench_r04.log: 600 MB on
+// 16 threads of the pool's hosts): with transparent huge pages one store per 4 KiB page -- the first one of a huge
+// page faults in (zeroes) all 2 MiB of it, the rest find it there: 2.4 ms = 258 GB/s -- where MADV_POPULATE_WRITE
+// takes 18.7 ms (34 GB/s: it does not scale past 4 threads there); without huge pages MADV_POPULATE_WRITE (Linux
+// 5.14), else the stores.  Callers hand blocks of whole huge pages to one thread each (kPopulateGrainBytes).
+constexpr int64_t kPopulateGrainBytes = (int64_t)2 << 20;
+
 inline void populate_for_write(void *p, int64_t bytes)
 {
     static const long page = sysconf(_SC_PAGESIZE);
@@ -274,7 +297,7 @@ inline void populate_for_write(void *p, int64_t bytes)
     // page faults -- and the next call tries again.  Called from all copy threads: atomic.
     static std::atomic<int> have_populate{1};
     static std::atomic<int> probed{0};
-    if (have_populate.load(std::memory_order_relaxed)) {
+    if (!thp_available() && have_populate.load(std::memory_order_relaxed)) {
         const int rc = madvise(reinterpret_cast<void *>(b), e - b, MADV_POPULATE_WRITE);
         const int err = rc == 0 ? 0 : errno;
         const bool first = probed.exchange(1, std::memory_order_relaxed) == 0;
@@ -282,11 +305,11 @@ inline void populate_for_write(void *p, int64_t bytes)
         if (!(first && err == EINVAL)) return;
         have_populate.store(0, std::memory_order_relaxed);
     }
-    // old kernel: touch one byte per page, leaving its value as it is (the range belongs to the caller)
-    for (uintptr_t q = b; q < e; q += (uintptr_t)page) {
-        volatile char *c = reinterpret_cast<volatile char *>(q);
-        *c = *c;
-    }
+    // touch one byte per page, leaving its value as it is (the range belongs to the caller): an atomic OR with zero
+    // is one access with write intent -- one write fault per page, where `*c = *c` would take a read fault (mapping
+    // the shared zero page) and then a write fault
+    for (uintptr_t q = b; q < e; q += (uintptr_t)page)
+        (void)__atomic_fetch_or(reinterpret_cast<unsigned char *>(q), (unsigned char)0, __ATOMIC_RELAXED);
 }
 
 // Are the pages of [p, p + bytes) already resident?  Judged from its first, middle and last

@@ -354,10 +354,11 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         double *const pd = out_dist && !looks_resident(out_dist + off, m * 8) ? out_dist : nullptr;
         int32_t *const pm = out_mrca && !looks_resident(out_mrca + off, m * 4) ? out_mrca : nullptr;
         if (!pd && !pm) return;
+        // (blocks of 2^18 pairs: whole huge pages of the float64 array to one thread each -- host_copy.h)
         P.pool.parallel_for(m, [=](int64_t b, int64_t e) {
             if (pd) populate_for_write(pd + off + b, (e - b) * 8);
             if (pm) populate_for_write(pm + off + b, (e - b) * 4);
-        });
+        }, kPopulateGrainBytes / 8);
     };
     auto bail = [&](int code, const std::string &msg) {
         for (auto &s : P.slot) {
