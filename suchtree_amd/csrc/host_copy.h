@@ -305,11 +305,13 @@ inline void populate_for_write(void *p, int64_t bytes)
         if (!(first && err == EINVAL)) return;
         have_populate.store(0, std::memory_order_relaxed);
     }
-    // touch one byte per page, leaving its value as it is (the range belongs to the caller): an atomic OR with zero
+    // touch one byte per page, leaving its value as it is (the range belongs to the caller): a locked OR with zero
     // is one access with write intent -- one write fault per page, where `*c = *c` would take a read fault (mapping
     // the shared zero page) and then a write fault
+    // (inline assembly: the compiler turns an idempotent __atomic_fetch_or(p, 0) into a fenced LOAD, which takes the
+    // read fault after all -- measured: "populated" 600 MB in 0.14 ms, and the unpack passes then paid 5 ms of faults)
     for (uintptr_t q = b; q < e; q += (uintptr_t)page)
-        (void)__atomic_fetch_or(reinterpret_cast<unsigned char *>(q), (unsigned char)0, __ATOMIC_RELAXED);
+        asm volatile("lock; orb $0, %0" : "+m"(*reinterpret_cast<unsigned char *>(q)) : : "cc");
 }
 
 // Are the pages of [p, p + bytes) already resident?  Judged from its first, middle and last

@@ -4,9 +4,9 @@
 // A deep tree (canopy more than kDeepCanopyDepth edges deep) has up to three kernels that produce the same bits:
 // the tile-sorted canopy kernel, the predicated canopy kernel and the tile-sorted walk kernel.  Which one is fastest
 // depends on the shape of the tree in ways no single statistic captured (launch_policy.h has the numbers), and the
-// spread is 2-4x, so the handle times them once on a sample of 2^22 random leaf pairs drawn on the device -- 6 ms on ml.tree next to the 0.07-2 s
+// spread is 2-4x, so the handle times them once on a sample of 2^23 random leaf pairs drawn on the device -- ~15 ms on ml.tree next to the 0.07-2 s
 // the tables of such a tree take to build -- and sets its defaults (tile_sort, pairs_per_lane, prefer_walk_sorted)
-// to the fastest -- if it beats the rule's own choice by more than 7 % (kTuneMargin), else the rule stands.  The decision
+// to the fastest -- if it beats the rule's own choice by more than 5 % (kTuneMargin), else the rule stands.  The decision
 // is recorded per (tree digest, device, library build) and read back by later handles and processes, so a handle's
 // kernel is stable across runs (info.tuned: 1 = timed now, 2 = read from the record); multi-device handles time on
 // the primary and copy the settings to the peers.  st_tree_set_option / st_tree_set_strategy still override them.
@@ -17,7 +17,7 @@
 #include <sys/types.h>
 #include <unistd.h>
 
-constexpr int64_t kTunePairs = (int64_t)1 << 22;      // (large enough for every candidate's largest tiles on every CU: with 2^20 a 13 % gap at 2e7 pairs went unseen)
+constexpr int64_t kTunePairs = (int64_t)1 << 23;      // (large enough for every candidate's largest tiles on every CU: with 2^20 a 13 % gap at 2e7 pairs went unseen, with 2^22 nj.tree's 16 % gap between the scalar ladder kernel and the tile-sorted walk kernel shrank below the margin)
 
 // What the handle's current settings select for a large batch with distances.
 static int big_batch_kernel_of(const st_tree *t)
@@ -101,7 +101,7 @@ static void tune_cache_write(const std::string &path, int tile_sort, int ppl, in
 
 // A candidate has to beat the rule's own choice by this much before the handle departs from it (timing noise on a
 // shared GPU is a few per cent; the gaps that matter are 1.3-4x).
-constexpr float kTuneMargin = 0.93f;
+constexpr float kTuneMargin = 0.95f;
 
 static void copy_tuned_settings(st_tree *to, const st_tree *from)
 {
