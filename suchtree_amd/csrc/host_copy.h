@@ -297,7 +297,14 @@ inline void populate_for_write(void *p, int64_t bytes)
     // page faults -- and the next call tries again.  Called from all copy threads: atomic.
     static std::atomic<int> have_populate{1};
     static std::atomic<int> probed{0};
-    if (!thp_available() && have_populate.load(std::memory_order_relaxed)) {
+    // SUCHTREE_AMD_POPULATE=madv|touch|none: measurement override of the choice below
+    static const int forced = [] {
+        const char *env = std::getenv("SUCHTREE_AMD_POPULATE");
+        if (!env) return 0;
+        return !std::strcmp(env, "madv") ? 1 : !std::strcmp(env, "touch") ? 2 : !std::strcmp(env, "none") ? 3 : 0;
+    }();
+    if (forced == 3) return;
+    if ((forced == 1 || (forced == 0 && !thp_available())) && have_populate.load(std::memory_order_relaxed)) {
         const int rc = madvise(reinterpret_cast<void *>(b), e - b, MADV_POPULATE_WRITE);
         const int err = rc == 0 ? 0 : errno;
         const bool first = probed.exchange(1, std::memory_order_relaxed) == 0;

@@ -337,20 +337,29 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
     // large fresh arrays: on threads of their own, ahead of the unpack passes (host_copy.h: AsyncPrefault); the
     // per-piece form below then finds the pages resident (or nearly so) and does nothing
     AsyncPrefault async_prefault;      // (joins on every way out of this function)
+    bool async_populates = false;      // this call's fresh pages are populated by such threads (of this replica or of the first one)
     {
         constexpr int64_t kAsyncMinBytes = (int64_t)64 << 20;
         double *const pd = out_dist && !looks_resident(out_dist, seq.n * 8) ? out_dist : nullptr;
         int32_t *const pm = out_mrca && !looks_resident(out_mrca, seq.n * 4) ? out_mrca : nullptr;
         const unsigned hw = std::thread::hardware_concurrency();
-        // (opt-in, SUCHTREE_AMD_ASYNC_PREFAULT=1: on the pool's shared two-socket hosts it measured 2-3x SLOWER than the
-        // copy pool's own per-piece populate -- 600 MB in 21-30 ms against 5-12 ms: the unpack passes catch up with
-        // the frontier and both sides then fault the same huge pages -- profiles/host_path_trace_r04.log)
-        static const bool async_on = std::getenv("SUCHTREE_AMD_ASYNC_PREFAULT") != nullptr;
-        if (async_on && !skip_cpu && seq.step == 1 && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8)
-            async_prefault.start(pd, pm, seq.n, (int)std::min<unsigned>(16, hw / 4));
+        // Only with the page-touch form of populate_for_write (transparent huge pages): MADV_POPULATE_WRITE from
+        // threads of its own beside the faulting unpack passes measured 3x SLOWER than doing nothing (5e7 pairs, fresh
+        // arrays: 1.1-1.6e9 pairs/s; the touch form 4.5-4.9e9; populating between the passes, either form, 3.7-3.9e9;
+        // profiles/fresh_array_r04.log).  SUCHTREE_AMD_ASYNC_PREFAULT=0 / 1 overrides.  Multi-device handles: the
+        // replica that owns the first chunk populates for all.
+        static const int async_env = [] {
+            const char *env = std::getenv("SUCHTREE_AMD_ASYNC_PREFAULT");
+            return !env ? -1 : env[0] == '0' ? 0 : 1;
+        }();
+        const char *mode = std::getenv("SUCHTREE_AMD_POPULATE");
+        const bool touch_form = mode ? !std::strcmp(mode, "touch") : thp_available();
+        const bool async_on = async_env >= 0 ? async_env == 1 : touch_form;
+        async_populates = async_on && !skip_cpu && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8;
+        if (async_populates && seq.first == 0) async_prefault.start(pd, pm, seq.n, (int)std::min<unsigned>(16, hw / 4));
     }
     auto prefault = [&](int64_t off, int64_t m) {
-        if (async_prefault.active()) return;
+        if (async_populates) return;
         double *const pd = out_dist && !looks_resident(out_dist + off, m * 8) ? out_dist : nullptr;
         int32_t *const pm = out_mrca && !looks_resident(out_mrca + off, m * 4) ? out_mrca : nullptr;
         if (!pd && !pm) return;

@@ -214,58 +214,6 @@ __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Sr
     }
 }
 
-// Unsorted form over the same tables with the crown's ladder in LDS (option walk_ladder_scalar): one pair per lane in
-// input order, no tile sort, no scratch -- node records, meeting node, a's side from the lineage sums, b's side as a
-// stream below its portal and a climb of the crown in LDS (three edges per 16-byte read).  A wave is as slow as its
-// longest lane here; what it saves is the sorted kernel's key / sort / stream phases with their barriers and the
-// 18 bytes of LDS scratch per pair.  Same operands, same order of additions.
-template <typename Src>
-__global__ __launch_bounds__(kWalkSortBlock) void k_walk_ladder(WalkParams P, Src src, long long n, DistSink out_d,
-                                                                 MrcaSink out_m, Fault *fault)
-{
-    extern __shared__ __align__(16) unsigned char walk_lds_all[];
-    const LadderEntry *LAD = reinterpret_cast<const LadderEntry *>(walk_lds_all);
-    {
-        uint4 *dst = reinterpret_cast<uint4 *>(walk_lds_all);
-        const uint4 *from = reinterpret_cast<const uint4 *>(P.crown_ladder);
-        for (int k = threadIdx.x; k < P.lineage.crown_nodes; k += blockDim.x) dst[k] = from[k];
-        __syncthreads();
-    }
-    const LineageView &lin = P.lineage;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {
-        const long long i = base + threadIdx.x;
-        const bool live = i < n;
-        float s = __builtin_nanf("");
-        int m = -1;
-        if (live) {
-            long long a, b;
-            src.load(i, a, b);
-            if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-                record_fault(fault, a, b, P.n_nodes);
-            } else {
-                const NodeKey ka = lineage_key(lin, (int32_t)a), kb = lineage_key(lin, (int32_t)b);
-                const uint32_t ra = ka.nb_rank >> 8, rb = kb.nb_rank >> 8;
-                const bool crown = ra != rb;
-                const uint32_t x = crown ? ra : (uint32_t)a, y = crown ? rb : (uint32_t)b;
-                const uint64_t *tab = crown ? lin.crown_rmq : P.rmq;
-                const size_t width = crown ? (size_t)lin.crown_nodes : (size_t)P.n_nodes;
-                const uint32_t l = x < y ? x : y, r = x < y ? y : x;
-                const uint32_t k = 31u - (uint32_t)__clz((int)(r - l + 1));
-                const uint64_t e1 = tab[(size_t)k * width + l], e2 = tab[(size_t)k * width + (r + 1 - (1u << k))];
-                const uint64_t e = e2 < e1 ? e2 : e1;      // the meeting node: depth << 32 | id
-                const uint32_t dm = (uint32_t)(e >> 32);
-                m = (int)(uint32_t)e;
-                if (out_d.any()) {
-                    s = lin.sums[(size_t)ka.off + (size_t)(ka.depth - dm)];
-                    s = stream_b_ladder(lin.lens, LAD, kb.off, kb.nb_rank & 0xFFu, rb, s, (int32_t)(kb.depth - dm));
-                }
-            }
-        }
-        store_result_wave(out_d, out_m, i, s, m, live);
-    }
-}
-
 // The mailbox form of k_walk (small host batches, one lane per pair, no grid stride): pairs and
 // results live in pinned host memory, and so does a completion word -- the last workgroup to
 // finish publishes the call's sequence number there (system-scope release after every block's

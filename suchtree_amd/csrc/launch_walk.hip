@@ -65,20 +65,6 @@ hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out
                               MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     const WalkParams P = walk_params(t);
-    if (t->walk_ladder_scalar && P.crown_ladder && P.lineage.crown_rmq && P.rmq && P.lineage.lens && n >= walk_sorted_min_pairs(t) &&
-        walk_sorted_ready(t)) {
-        // the unsorted form with the crown's ladder in LDS (a measured alternative to the tile-sorted kernel)
-        const size_t lds = (size_t)P.lineage.crown_nodes * 16;
-        const int wg_per_cu = lds <= 80 * 1024 ? 2 : 1;
-        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n + kWalkSortBlock - 1) / kWalkSortBlock, (int64_t)t->n_cu * wg_per_cu));
-        auto kern = k_walk_ladder<Src>;
-        if (lds > 64 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWalkSortBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault);
-        return hipGetLastError();
-    }
     if (out_d.any() && n >= walk_sorted_min_pairs(t) && walk_sorted_ready(t)) {
         if (P.crown_ladder) {
             // the crown's ladder in LDS: the largest tile that fits beside it, cut finer for batches that would

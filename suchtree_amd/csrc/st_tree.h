@@ -46,7 +46,6 @@ struct st_tree {
     uint64_t *d_crown_rmq = nullptr;          // sparse table over the walk family's crown (in-order ids), else NULL
     LadderEntry *d_crown_ladder = nullptr;    // ladder form of the crown by rank (crowns that fit LDS), else NULL
     int walk_ladder = 1;      // tuning: 0 = k_walk_sorted streams the crown part of b's side from the portal's block instead of climbing it in LDS
-    int walk_ladder_scalar = 0;   // tuning: 1 = large batches of the walk family go to k_walk_ladder (unsorted, crown ladder in LDS) instead of k_walk_sorted
     int32_t crown_nodes = 0;
     // two fault words: the device-pointer entry points are not serialised against anything,
     // so the host path keeps its own (reset at the start of every host call, read under the

@@ -355,11 +355,6 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->rec_a4 = (int)value;
         return ST_OK;
     }
-    if (std::strcmp(name, "walk_ladder_scalar") == 0) {
-        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_ladder_scalar must be 0 or 1");
-        t->walk_ladder_scalar = (int)value;
-        return ST_OK;
-    }
     if (std::strcmp(name, "walk_ladder") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "walk_ladder must be 0 or 1");
         t->walk_ladder = (int)value;
