@@ -66,8 +66,28 @@ typedef struct st_tree_info {
     int32_t host_wire_bytes_in;   /* bytes per pair the st_*_host entry points ship over the link: ids in (6 or 8) ... */
     int32_t host_wire_bytes_out;  /* ... float32 distance + MRCA id back (7 or 8); follow the wire48 / wire24 options */
     int32_t a_side_bytes;     /* canopy family: bytes gathered for the first node of a pair, 4 (rec_a4 + block table) or 8 */
-    int32_t reserved0;
+    int32_t dropped_tables;   /* ST_TABLE_* bits: what the table budget left out (slower forms of the kernels take over) */
+    int64_t table_budget_bytes;   /* the budget this handle was built under (0 = none) */
 } st_tree_info;
+
+/* st_tree_info.dropped_tables, in the order in which a table budget (st_tree_options.table_budget_bytes, else
+ * SUCHTREE_AMD_TABLE_MB) drops them -- every one is an accelerator, results are the same bits without it: */
+#define ST_TABLE_LINEAGE_LEN   1   /* lineage lengths + crown tables: the walk family climbs b's side instead of streaming it */
+#define ST_TABLE_LINEAGE_SUM   2   /* lineage sums: a's side is climbed, the tile-sorted kernels lose their lineage-sum form */
+#define ST_TABLE_TREE_RMQ      4   /* whole-tree sparse table: the walk family finds meeting nodes by climbing */
+#define ST_TABLE_REC_I         8   /* id chains of the understory records (as large as the b-side records: judged when the
+                                      records are sized): pairs under one portal are walked on the tree */
+#define ST_TABLE_REC_A4       16   /* four-byte a side of the predicated kernel: the 8-byte entries serve */
+#define ST_TABLE_RANKS        32   /* rank table of MRCA-only requests: they go through the distance kernels */
+#define ST_TABLE_CANOPY       64   /* every canopy table: the walk family serves the tree */
+
+/* Creation options (st_tree_create_ex); zero-initialise, then set what is wanted. */
+typedef struct st_tree_options {
+    int64_t table_budget_bytes;   /* device bytes the tree's tables may take; 0 = SUCHTREE_AMD_TABLE_MB (MiB) if set, else no
+                                     limit.  Below the floor (28 bytes per node: parent/distance, depth and the three-level
+                                     image the walk kernel needs) the floor is what is uploaded. */
+    int64_t reserved[7];
+} st_tree_options;
 
 /* st_tree_info.big_batch_kernel */
 #define ST_KERNEL_WALK            0   /* k_walk / k_walk_sorted: trees the canopy family does not serve */
@@ -106,6 +126,21 @@ int st_tree_create(const int32_t *parent, const float *distance, int64_t n_nodes
  */
 int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n_nodes,
                          const int *devices, int n_devices, int strategy, st_tree **out);
+
+/*
+ * The same with creation options: a budget for the device tables.  A tree costs 28 bytes per node on the device (the
+ * floor); everything beyond that -- 60 to 1500 times the reference's 20-byte Node -- is accelerator tables, and under
+ * a budget they are left out in the order of the ST_TABLE_* bits above until the rest fits; st_tree_info reports
+ * device_bytes and dropped_tables.  opts may be NULL (= st_tree_create_multi).  No counterpart in the reference,
+ * whose tree is one calloc of n nodes (SuchTree/MuchTree.pyx:114, 160-165).
+ */
+int st_tree_create_ex(const int32_t *parent, const float *distance, int64_t n_nodes,
+                      const int *devices, int n_devices, int strategy, const st_tree_options *opts, st_tree **out);
+
+/* Host-only helper, no GPU needed: what st_tree_create_ex would build for this tree under `table_budget_bytes`
+ * (0 = SUCHTREE_AMD_TABLE_MB if set, else no limit): the device bytes, the ST_TABLE_* bits left out and the family. */
+int st_host_table_plan(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy,
+                       int64_t table_budget_bytes, int64_t *device_bytes, int32_t *dropped_tables, int32_t *family);
 
 /* Devices of a handle, devices[0] first (devices may be NULL to ask for the count only). */
 int st_tree_devices(const st_tree *tree, int *devices, int capacity, int *n_devices);

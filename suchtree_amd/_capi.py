@@ -19,9 +19,22 @@ STRATEGY = {"auto": 0, "walk": 1, "canopy": 2}
 STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
 BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 2: "canopy_scalar", 3: "canopy_sorted", 4: "walk_sorted", 5: "canopy_ladder"}      # ST_KERNEL_*
 
+# ST_TABLE_* bits of st_tree_info.dropped_tables, in the order a table budget drops them
+DROPPED_TABLES = ((1, "lineage_len"), (2, "lineage_sum"), (4, "tree_rmq"), (8, "rec_i"), (16, "rec_a4"), (32, "ranks"), (64, "canopy"))
+
+
+def dropped_table_names(bits):
+    return [name for bit, name in DROPPED_TABLES if bits & bit]
+
+
+class TreeOptions(ctypes.Structure):
+    """st_tree_options (include/suchtree_hip.h)."""
+    _fields_ = [("table_budget_bytes", ctypes.c_int64), ("reserved", ctypes.c_int64 * 7)]
+
+
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
-    "st_last_error", "st_device_count", "st_tree_create", "st_tree_create_multi", "st_tree_devices",
+    "st_last_error", "st_device_count", "st_tree_create", "st_tree_create_multi", "st_tree_create_ex", "st_host_table_plan", "st_tree_devices",
     "st_host_chunk_plan", "st_host_chunk_owner", "st_tree_destroy", "st_tree_info_get",
     "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_distances_device_wire", "st_unpack_mrca24_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
@@ -50,13 +63,15 @@ class TreeInfo(ctypes.Structure):
         ("host_wire_bytes_in", ctypes.c_int32),
         ("host_wire_bytes_out", ctypes.c_int32),
         ("a_side_bytes", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("dropped_tables", ctypes.c_int32),
+        ("table_budget_bytes", ctypes.c_int64),
     ]
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_}
         d["strategy"] = STRATEGY_NAME.get(d["strategy"], str(d["strategy"]))
         d["big_batch_kernel"] = BIG_BATCH_KERNEL.get(d["big_batch_kernel"], str(d["big_batch_kernel"]))
+        d["dropped_tables"] = dropped_table_names(d["dropped_tables"])
         return d
 
 
@@ -150,6 +165,8 @@ def load():
         L.st_device_count.argtypes = [ctypes.POINTER(i32)]
         L.st_tree_create.argtypes = [vp, vp, i64, i32, i32, ctypes.POINTER(vp)]
         L.st_tree_create_multi.argtypes = [vp, vp, i64, ctypes.POINTER(i32), i32, i32, ctypes.POINTER(vp)]
+        L.st_tree_create_ex.argtypes = [vp, vp, i64, ctypes.POINTER(i32), i32, i32, ctypes.POINTER(TreeOptions), ctypes.POINTER(vp)]
+        L.st_host_table_plan.argtypes = [vp, vp, i64, i32, i64, ctypes.POINTER(i64), ctypes.POINTER(i32), ctypes.POINTER(i32)]
         L.st_tree_devices.argtypes = [vp, ctypes.POINTER(i32), i32, ctypes.POINTER(i32)]
         L.st_host_chunk_plan.argtypes = [i64, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.st_host_chunk_owner.argtypes = [i64, i32, i64, ctypes.POINTER(i32), ctypes.POINTER(i64), ctypes.POINTER(i64)]
@@ -464,12 +481,27 @@ def _ptr(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
+def host_table_plan(parent, distance, strategy="auto", table_mb=0):
+    """What a tree would get on the device under a table budget (MiB; 0 = SUCHTREE_AMD_TABLE_MB if set, else none),
+    computed on the host (no GPU): ``{"device_bytes", "dropped_tables", "family"}`` (st_host_table_plan)."""
+    L = load()
+    parent = np.ascontiguousarray(parent, dtype=np.int32)
+    distance = np.ascontiguousarray(distance, dtype=np.float32)
+    b, d, f = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    check(L.st_host_table_plan(_ptr(parent), _ptr(distance), int(parent.shape[0]), STRATEGY[strategy], int(float(table_mb) * (1 << 20)),
+                               ctypes.byref(b), ctypes.byref(d), ctypes.byref(f)))
+    return {"device_bytes": int(b.value), "dropped_tables": dropped_table_names(int(d.value)), "family": STRATEGY_NAME.get(int(f.value))}
+
+
 class DeviceTree:
     """Owner of one ``st_tree`` handle: the tree resident in one GPU's HBM, or -- with
     ``devices=[...]`` -- replicated on several GPUs of the node (``st_tree_create_multi``),
     the host-buffer entry points then dealing their chunks over all of them."""
 
-    def __init__(self, parent, distance, device=0, strategy="auto", devices=None, pinned_results=None):
+    def __init__(self, parent, distance, device=0, strategy="auto", devices=None, pinned_results=None, table_mb=None):
+        """``table_mb``: budget (MiB) for the tree's device tables (st_tree_options.table_budget_bytes; default: the
+        environment's SUCHTREE_AMD_TABLE_MB, else none): accelerator tables are left out, in a stated order, until the
+        rest fits -- ``info()["dropped_tables"]`` names them; results are the same bits."""
         global _gpu_pid
         if pinned_results is None:
             pinned_results = os.environ.get("SUCHTREE_AMD_PINNED_RESULTS", "0") == "1"
@@ -486,13 +518,18 @@ class DeviceTree:
             raise ValueError("strategy must be one of %s" % sorted(STRATEGY))
         self.size = int(parent.shape[0])
         self._pid = os.getpid()
-        if devices is not None:
-            devices = [int(d) for d in devices]
+        if devices is not None or table_mb is not None:
+            devices = [int(d) for d in (devices if devices is not None else [device])]
             if not devices:
                 raise ValueError("devices must not be empty")
             arr = (ctypes.c_int * len(devices))(*devices)
-            rc = L.st_tree_create_multi(_ptr(parent), _ptr(distance), self.size, arr, len(devices),
-                                        STRATEGY[strategy], ctypes.byref(self._h))
+            opts = TreeOptions()
+            if table_mb is not None:
+                if table_mb < 0:
+                    raise ValueError("table_mb must be >= 0")
+                opts.table_budget_bytes = int(float(table_mb) * (1 << 20))
+            rc = L.st_tree_create_ex(_ptr(parent), _ptr(distance), self.size, arr, len(devices),
+                                     STRATEGY[strategy], ctypes.byref(opts), ctypes.byref(self._h))
             device = devices[0]
         else:
             rc = L.st_tree_create(_ptr(parent), _ptr(distance), self.size, int(device),

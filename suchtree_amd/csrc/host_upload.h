@@ -8,7 +8,23 @@ struct BuiltTables {
     TreeTables T;
     bool canopy_ok = false;
     bool deep = false;
+    int64_t budget = 0;        // device bytes the tables may take (0 = no limit)
+    int32_t dropped = 0;       // ST_TABLE_* bits left out under the budget
 };
+
+// Table budget of a handle: the creation option, else SUCHTREE_AMD_TABLE_MB (MiB), else none.
+static int64_t table_budget_from(int64_t option_bytes)
+{
+    if (option_bytes > 0) return option_bytes;
+    if (const char *env = std::getenv("SUCHTREE_AMD_TABLE_MB")) {
+        const long long mb = std::atoll(env);
+        if (mb > 0) return (int64_t)mb << 20;
+    }
+    return 0;
+}
+
+// The floor: parent/distance (8), depth (4) and the three-level image (16) per node -- what the walk kernel needs.
+static int64_t table_floor_bytes(int64_t n_nodes) { return n_nodes * 28 + 64; }
 
 // Budget of the OPTIONAL walk-family tables of a tree the canopy family does not serve (whole-tree
 // sparse table, lineage sums, lineage lengths), in bytes: SUCHTREE_AMD_WALK_TABLE_MB (default 12288;
@@ -53,17 +69,84 @@ static int crown_ladder_nodes(bool has_canopy)
 // 7 GB of lineage tables for 2 MB of tree; it climbs instead.  For trees that only the walk family serves (canopy
 // refused, or the caller asked for the walk family) and for deep canopy trees whose lineage tables are too large
 // for the 28-bit offsets of the canopy family's form.
+static int64_t device_bytes_of(const BuiltTables &B);
+
 static void build_walk_only_tables(BuiltTables &B, int64_t n_nodes, bool has_canopy)
 {
     int64_t budget = walk_table_budget();
+    if (B.budget > 0) {      // what the handle's table budget leaves beside the floor (and the canopy family's tables)
+        if (device_bytes_of(B) > B.budget && !B.T.tree_rmq.empty()) {
+            std::vector<uint64_t>().swap(B.T.tree_rmq);
+            B.T.tree_rmq_levels = 0;
+            B.dropped |= ST_TABLE_TREE_RMQ;
+        }
+        budget = std::min<int64_t>(budget, std::max<int64_t>(0, B.budget - device_bytes_of(B)));
+    }
     const int64_t by_size = (int64_t)kLineageEntriesPerNode * n_nodes;
     if (budget > 0 && (int64_t)B.T.tree_rmq.size() == 0) (void)build_tree_rmq(B.T, std::min<int64_t>(budget, kMaxTreeRmqBytesWalkOnly));
-    if (budget <= 0) return;
-    budget -= (int64_t)B.T.tree_rmq.size() * 8;
-    // sums + lens when both fit, else the sums alone
-    if (!prepare_walk_lineage(B.T, std::min<int64_t>({budget / 8, kMaxWalkLineageEntries, by_size}), true))
-        (void)prepare_walk_lineage(B.T, std::min<int64_t>({budget / 4, kMaxWalkLineageEntries, by_size}), false);
-    if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(has_canopy));
+    if (budget > 0) {
+        budget -= (int64_t)B.T.tree_rmq.size() * 8;
+        // sums + lens when both fit, else the sums alone
+        if (!prepare_walk_lineage(B.T, std::min<int64_t>({budget / 8, kMaxWalkLineageEntries, by_size}), true))
+            (void)prepare_walk_lineage(B.T, std::min<int64_t>({budget / 4, kMaxWalkLineageEntries, by_size}), false);
+        if (!B.T.lineage_sum.empty()) (void)prepare_walk_crown(B.T, crown_hot_budget(), crown_ladder_nodes(has_canopy));
+    }
+    if (B.budget > 0) {      // (what the handle's budget kept this tree from getting)
+        if (B.T.tree_rmq.empty() && B.T.inorder_ids) B.dropped |= ST_TABLE_TREE_RMQ;
+        if (B.T.lineage_sum.empty()) B.dropped |= ST_TABLE_LINEAGE_SUM | ST_TABLE_LINEAGE_LEN;
+        else if (B.T.lineage_len.empty()) B.dropped |= ST_TABLE_LINEAGE_LEN;
+    }
+}
+
+// Device bytes of what upload_tree would upload of B (the same conditions, table by table).
+static int64_t device_bytes_of(const BuiltTables &B)
+{
+    const TreeTables &T = B.T;
+    auto sz = [](const auto &v) -> int64_t { return v.empty() ? 0 : (int64_t)std::max<size_t>(v.size() * sizeof(v[0]), 16); };
+    int64_t b = sz(T.nodes) + sz(T.depth) + sz(T.stride) + sz(T.tree_rmq) + 32;
+    const bool walk_lineage = !T.lineage_node_rec.empty() && !T.lineage_sum.empty();
+    auto walk_lineage_bytes = [&]() -> int64_t {
+        return walk_lineage ? sz(T.lineage_node_rec) + sz(T.lineage_len) + sz(T.crown_rmq) + sz(T.crown_ladder) : 0;
+    };
+    if (!B.canopy_ok) return b + (walk_lineage ? sz(T.lineage_sum) : 0) + walk_lineage_bytes();
+    b += sz(T.canopy) + 8 + sz(T.canopy_id) + sz(T.ladder) + sz(T.canopy_depth) + 16;
+    if (B.deep && T.inorder_ids && !T.canopy_rmq.empty()) b += sz(T.canopy_pos) + sz(T.canopy_rmq);
+    b += sz(T.rec_a) + sz(T.rec_b) + sz(T.rec_i);
+    if (!T.rec_a4.empty()) b += sz(T.rec_a4) + sz(T.leaf_block_portal) + 16;
+    if (!T.rec_r.empty()) b += sz(T.rec_r) / 2 + sz(T.canopy_rmq64);      // (uploaded as 2-byte ranks)
+    if (!T.lineage_sum.empty()) b += sz(T.lineage_sum) + sz(T.rec_p) + walk_lineage_bytes();
+    return b;
+}
+
+// Leaves optional tables out, in the order of the ST_TABLE_* bits, until the rest fits B.budget.  (The record
+// tables were sized against the budget before they were built: prepare_canopy / TreeTables::record_budget_bytes.)
+static void apply_table_budget(BuiltTables &B)
+{
+    TreeTables &T = B.T;
+    if (B.canopy_ok && T.rec_i.empty()) B.dropped |= ST_TABLE_REC_I;      // (prepare_canopy left the id chains out)
+    if (B.budget <= 0) return;
+    auto over = [&] { return device_bytes_of(B) > B.budget; };
+    auto clear = [](auto &v) { std::decay_t<decltype(v)>().swap(v); };
+    auto drop_crown = [&] { clear(T.crown_rmq); clear(T.crown_ladder); T.crown_nodes = 0; };
+    if (over() && !T.lineage_len.empty()) { clear(T.lineage_len); drop_crown(); B.dropped |= ST_TABLE_LINEAGE_LEN; }
+    if (over() && !T.lineage_sum.empty()) {
+        clear(T.lineage_sum); clear(T.lineage_len); clear(T.rec_p); clear(T.lineage_node_rec); clear(T.lineage_node_off);
+        drop_crown();
+        B.dropped |= ST_TABLE_LINEAGE_SUM | ST_TABLE_LINEAGE_LEN;
+    }
+    if (over() && !T.tree_rmq.empty()) { clear(T.tree_rmq); T.tree_rmq_levels = 0; B.dropped |= ST_TABLE_TREE_RMQ; }
+    if (over() && B.canopy_ok && !T.rec_i.empty()) { clear(T.rec_i); B.dropped |= ST_TABLE_REC_I; }
+    if (over() && !T.rec_a4.empty()) { clear(T.rec_a4); clear(T.leaf_block_portal); B.dropped |= ST_TABLE_REC_A4; }
+    if (over() && !T.rec_r.empty()) { clear(T.rec_r); clear(T.canopy_rmq64); B.dropped |= ST_TABLE_RANKS; }
+    if (over() && B.canopy_ok) {
+        clear(T.canopy); clear(T.canopy_id); clear(T.ladder); clear(T.canopy_depth); clear(T.canopy_pos); clear(T.canopy_rmq);
+        clear(T.rec_a); clear(T.rec_b); clear(T.rec_i); clear(T.rec_a4); clear(T.leaf_block_portal); clear(T.rec_r);
+        clear(T.canopy_rmq64); clear(T.rec_p);
+        T.has_canopy = false;
+        B.canopy_ok = false;
+        B.deep = false;
+        B.dropped |= ST_TABLE_CANOPY | ST_TABLE_REC_I | ST_TABLE_RANKS | ST_TABLE_REC_A4;
+    }
 }
 
 static int build_tables_impl(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
@@ -72,6 +155,11 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
     if (!prepare_basic(parent, distance, n_nodes, B.T, err)) return fail(ST_ERR_TREE, err);
     int max_canopy = 0;
     if (const char *env = std::getenv("SUCHTREE_AMD_CANOPY_NODES")) max_canopy = std::atoi(env);   // tuning experiments
+    if (B.budget > 0) {
+        // (tables beyond the floor: the whole-tree sparse table prepare_basic may have built is the first thing to go
+        // when the records would not fit beside it)
+        B.T.record_budget_bytes = std::max<int64_t>(1, B.budget - table_floor_bytes(n_nodes));
+    }
     if (strategy != ST_STRATEGY_WALK) {
         B.canopy_ok = prepare_canopy(parent, distance, B.T, max_canopy);
         // Deep canopies (real, unbalanced phylogenies: hundreds of levels) spend their time in
@@ -102,18 +190,29 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
         }
     }
     if (strategy == ST_STRATEGY_CANOPY && !B.canopy_ok)
-        return fail(ST_ERR_TREE, "tree does not admit the canopy family (understory deeper than a record)");
+        return fail(ST_ERR_TREE, B.budget > 0 ? "tree does not admit the canopy family under this table budget"
+                                              : "tree does not admit the canopy family (understory deeper than a record)");
+    if (strategy != ST_STRATEGY_WALK && !B.canopy_ok && B.budget > 0) {
+        // refused by the budget, or by the tree itself?  (without a budget the tree decides)
+        const int64_t keep = B.T.record_budget_bytes;
+        B.T.record_budget_bytes = -1;      // (sentinel: geometry only, see prepare_canopy)
+        if (prepare_canopy(parent, distance, B.T, max_canopy)) B.dropped |= ST_TABLE_CANOPY | ST_TABLE_REC_I | ST_TABLE_RANKS | ST_TABLE_REC_A4;
+        B.T.record_budget_bytes = keep;
+    }
     if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
     // four-byte a side for the predicated kernel (shallow canopies): 32 KiB of LDS are left beside a full canopy image
     if (B.canopy_ok && !B.deep && B.T.record_cap <= 15) (void)prepare_leaf_blocks(B.T, 8192);
     if (!B.canopy_ok) build_walk_only_tables(B, n_nodes, false);
+    apply_table_budget(B);
     return ST_OK;
 }
 
 // Nothing may be thrown through the C ABI: allocation failures of the (large) optional tables
 // become ST_ERR_NOMEM.
-static int build_tables(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B)
+static int build_tables(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, BuiltTables &B,
+                        int64_t budget_option = 0)
 {
+    B.budget = table_budget_from(budget_option);
     try {
         return build_tables_impl(parent, distance, n_nodes, strategy, B);
     } catch (const std::bad_alloc &) {
@@ -241,7 +340,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
             }
         }
         if (rc == ST_OK) rc = upload(&t->d_rec_b, T.rec_b, &bytes);
-        if (rc == ST_OK) rc = upload(&t->d_rec_i, T.rec_i, &bytes);
+        if (rc == ST_OK && !T.rec_i.empty()) rc = upload(&t->d_rec_i, T.rec_i, &bytes);      // (empty: left out under a table budget)
         if (rc == ST_OK && !T.rec_r.empty()) {
             // the MRCA-only kernel needs the rank alone: 2 bytes per node, so that the leaves' half of the
             // table (2 MB for 2^20 leaves) stays in an XCD's L2 (4-byte entries: 4.4e10 ids/s)
@@ -282,6 +381,8 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
     t->info.record_bytes = B.canopy_ok ? T.record_bytes : 0;
     t->info.n_devices = 1;
     t->info.device_bytes = bytes;
+    t->info.dropped_tables = B.dropped;
+    t->info.table_budget_bytes = B.budget;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
     if (B.deep && !tune) rule_for_deep_tree(t);
     if (B.deep && tune) {      // (host_tune.h: the kernel of large batches, by timing the candidates; the rule's defaults if that fails)

@@ -21,7 +21,10 @@ struct CanopyParams {
     const uint16_t *leaf_blocks;   // [leaf_block_count]       portal of every aligned block of leaf slots (staged to LDS), or NULL
     int32_t leaf_block_shift, leaf_block_count;
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
-    const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}
+    const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}; NULL: left out under a table budget
+    const Node8 *nodes;            // the walk family's tables: pairs that share a portal are walked on the tree itself when
+    const int32_t *depth;          //   rec_i is NULL (same_portal_by_walk)
+    const Stride3 *stride;
     const uint8_t *rec_p;          // [n_nodes * 8]            {portal rank | depth << 16, lineage offset | chunks << 28}; NULL without lineage sums
     const uint64_t *rmq64;         // [levels * canopy_nodes] sparse table with node ids (tree_prep.h); in-order ids only
     const uint16_t *rec_r;         // [n_nodes] rank of the node's portal (MRCA-only queries); in-order ids only
@@ -32,6 +35,15 @@ struct CanopyParams {
     int32_t rec_bytes;
     int32_t parity;                // 1: leaf records first (leaves are the even ids)
 };
+
+// Both lineages enter the canopy at the same node and the id chains (rec_i) were left out under a table budget: the
+// pair is walked on the tree itself (pair_math.h::pair_walk: depth cut over the stride-3 image, then both sums in the
+// reference's order -- the same bits).  Rare for random pairs; all there is for pairs of nearby leaves.
+__device__ __forceinline__ PairResult same_portal_by_walk(const CanopyParams &P, long long sa, long long sb)
+{
+    const bool parity = P.parity != 0;
+    return pair_walk(P.nodes, P.depth, P.stride, (int32_t)record_node(sa, parity, P.n_leaves), (int32_t)record_node(sb, parity, P.n_leaves));
+}
 
 // stage the canopy image into LDS: 16 bytes (two entries) per lane per step, coalesced
 __device__ __forceinline__ void stage_canopy(const CanopyParams &P, unsigned char *lds_raw)
@@ -133,6 +145,7 @@ __device__ __forceinline__ PairResult canopy_pair_finish(const CanopyParams &P, 
         return pair_canopy_split<CAP>(reinterpret_cast<const CanopyEntry *>(image), P.canopy_id, pa, L.pbot_a, pb,
                                       L.chain(), L.wb >> 16);
     }
+    if (!P.rec_i) return same_portal_by_walk(P, sa, sb);
     const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
     return pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb));
 }
@@ -417,7 +430,8 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src
             if (pa[j] == pb[j]) {
                 const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
                 PairResult r;
-                if constexpr (CAP <= 31) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
+                if (!P.rec_i) r = same_portal_by_walk(P, sa[j], sb[j]);
+                else if constexpr (CAP <= 31) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
                 else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
                 s[j] = r.dist;
                 m[j] = r.mrca;
@@ -458,7 +472,8 @@ __global__ __launch_bounds__(256) void k_mrca_ranks(CanopyParams P, Src src, lon
                     m = (int)(uint32_t)canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
                 } else {      // shared portal: the MRCA is the portal or lies in the understory
                     const RecTables R{P.rec_a, P.rec_b, P.rec_i, CAP > 0 ? 4 * (CAP + 1) : P.rec_bytes / 2};
-                    if constexpr (CAP > 0) m = mrca_same_portal_regs<CAP>(P.canopy_id, R, sa, sb);
+                    if (!P.rec_i) m = pair_walk_mrca(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b);
+                    else if constexpr (CAP > 0) m = mrca_same_portal_regs<CAP>(P.canopy_id, R, sa, sb);
                     else m = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa), rec_view(R, sb)).mrca;
                 }
             }

@@ -234,7 +234,9 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                         long long a, b;
                         src.load(base + j, a, b);
                         PairResult r;
-                        if constexpr (CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15) {      // chains in registers, no dependent loads
+                        if (!P.rec_i) {      // id chains left out under a table budget
+                            r = pair_walk(P.nodes, P.depth, P.stride, (int32_t)a, (int32_t)b);
+                        } else if constexpr (CAP == 1 || CAP == 3 || CAP == 7 || CAP == 15) {      // chains in registers, no dependent loads
                             const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
                             r = pair_same_portal_regs<CAP>(P.canopy_id, R, record_slot(a, parity, P.n_leaves), record_slot(b, parity, P.n_leaves));
                         } else {

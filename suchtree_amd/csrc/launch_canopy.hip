@@ -98,6 +98,9 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
     P.leaf_block_count = t->leaf_block_count;
     P.rec_b = t->d_rec_b;
     P.rec_i = t->d_rec_i;
+    P.nodes = t->d_nodes;
+    P.depth = t->d_depth;
+    P.stride = t->d_stride;
     P.rec_p = t->d_rec_p;
     P.rmq64 = t->d_rmq64;
     P.rec_r = t->d_rec_r;

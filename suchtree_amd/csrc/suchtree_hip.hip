@@ -213,9 +213,43 @@ try {
     return upload_tree(B, device, out);
 } ST_CATCH_ALL
 
+static int create_multi(const int32_t *parent, const float *distance, int64_t n_nodes, const int *devices, int n_devices,
+                        int strategy, int64_t budget_option, st_tree **out);
+
 int st_tree_create_multi(const int32_t *parent, const float *distance, int64_t n_nodes,
                          const int *devices, int n_devices, int strategy, st_tree **out)
 try {
+    return create_multi(parent, distance, n_nodes, devices, n_devices, strategy, 0, out);
+} ST_CATCH_ALL
+
+int st_tree_create_ex(const int32_t *parent, const float *distance, int64_t n_nodes, const int *devices, int n_devices,
+                      int strategy, const st_tree_options *opts, st_tree **out)
+try {
+    if (opts && opts->table_budget_bytes < 0) return fail(ST_ERR_ARG, "table_budget_bytes < 0");
+    return create_multi(parent, distance, n_nodes, devices, n_devices, strategy, opts ? opts->table_budget_bytes : 0, out);
+} ST_CATCH_ALL
+
+int st_host_table_plan(const int32_t *parent, const float *distance, int64_t n_nodes, int strategy, int64_t table_budget_bytes,
+                       int64_t *device_bytes, int32_t *dropped_tables, int32_t *family)
+try {
+    st_tree *unused = nullptr;
+    int rc = check_create_args(parent, distance, n_nodes, strategy, &unused);
+    if (rc != ST_OK) return rc;
+    if (table_budget_bytes < 0) return fail(ST_ERR_ARG, "table_budget_bytes < 0");
+    BuiltTables B;
+    rc = build_tables(parent, distance, n_nodes, strategy, B, table_budget_bytes);
+    if (rc != ST_OK) return rc;
+    if (device_bytes) *device_bytes = device_bytes_of(B);
+    if (dropped_tables) *dropped_tables = B.dropped;
+    if (family) *family = B.canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;
+    return ST_OK;
+} ST_CATCH_ALL
+
+}  // extern "C"
+
+static int create_multi(const int32_t *parent, const float *distance, int64_t n_nodes, const int *devices, int n_devices,
+                        int strategy, int64_t budget_option, st_tree **out)
+{
     int rc = check_create_args(parent, distance, n_nodes, strategy, out);
     if (rc != ST_OK) return rc;
     if (!devices || n_devices < 1) return fail(ST_ERR_ARG, "devices is NULL or n_devices < 1");
@@ -227,7 +261,7 @@ try {
             for (int j = 0; j < i; j++)
                 if (devices[i] == devices[j]) return fail(ST_ERR_ARG, "device " + std::to_string(devices[i]) + " listed twice");
     BuiltTables B;
-    rc = build_tables(parent, distance, n_nodes, strategy, B);
+    rc = build_tables(parent, distance, n_nodes, strategy, B, budget_option);
     if (rc != ST_OK) return rc;
     st_tree *primary = nullptr;
     rc = upload_tree(B, devices[0], &primary);
@@ -245,7 +279,9 @@ try {
     owner.t = nullptr;
     *out = primary;
     return ST_OK;
-} ST_CATCH_ALL
+}
+
+extern "C" {
 
 void st_tree_destroy(st_tree *t)
 {

@@ -232,6 +232,16 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     if (count_ge[(size_t)h_min + 1] > max_canopy_nodes) return false;   // cannot happen (count_ge[hmax+1] = 0)
     int32_t rec_bytes = std::max(kMinRecordBytes, pow2_ceil(8 + 8 * h_min));
     if (rec_bytes > kMaxRecordBytes) return false;
+    // table budget: the record tables are what the canopy family costs (8 + R/2 bytes per node, R/2 more with the
+    // id chains of the shared-portal case)
+    bool with_ids = true;
+    if (T.record_budget_bytes < 0) return true;      // (geometry only: would the tree admit the family? nothing is built)
+    T.rec_i.clear();
+    if (T.record_budget_bytes > 0) {
+        const int64_t core = n * (8 + (int64_t)rec_bytes / 2);
+        if (core > T.record_budget_bytes) return false;
+        with_ids = core + n * ((int64_t)rec_bytes / 2) <= T.record_budget_bytes;
+    }
     // use the whole record: a longer understory means a smaller canopy
     int32_t cap = record_cap_for(rec_bytes);
     int32_t H = std::min(cap, hmax);
@@ -322,15 +332,16 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     const size_t half = (size_t)rec_bytes / 2;
     assign_zero(T.rec_a, (size_t)n * 8);
     assign_zero(T.rec_b, (size_t)n * half);
-    assign_zero(T.rec_i, (size_t)n * half);
+    if (with_ids) assign_zero(T.rec_i, (size_t)n * half);
     std::atomic<bool> too_long{false};
     auto build_records = [&](int64_t x0, int64_t x1) {
+        std::vector<int32_t> ids_scratch((size_t)cap + 1, 0);      // (the id chain of a node when rec_i is left out)
         for (int64_t x = x0; x < x1; x++) {
             const size_t slot = (size_t)record_slot(x, T.parity_layout, T.n_leaves);
             uint8_t *rb = T.rec_b.data() + slot * half;
-            uint8_t *ri = T.rec_i.data() + slot * half;
+            uint8_t *ri = with_ids ? T.rec_i.data() + slot * half : nullptr;
             float *D = reinterpret_cast<float *>(rb + 4);
-            int32_t *I = reinterpret_cast<int32_t *>(ri + 4);
+            int32_t *I = with_ids ? reinterpret_cast<int32_t *>(ri + 4) : ids_scratch.data();
             uint32_t w0;
             float pbot = 0.0f;
             if (cidx[(size_t)x] >= 0) {
@@ -364,7 +375,7 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
                 for (uint32_t i = nb_used; i < (uint32_t)cap; i++) std::memcpy(D + i, &neg_zero, 4);
             }
             std::memcpy(rb, &w0, 4);
-            std::memcpy(ri, &pbot, 4);
+            if (ri) std::memcpy(ri, &pbot, 4);
             std::memcpy(T.rec_a.data() + slot * 8, &w0, 4);
             std::memcpy(T.rec_a.data() + slot * 8 + 4, &pbot, 4);
         }

@@ -132,7 +132,12 @@ struct TreeTables {
     std::vector<uint16_t> leaf_block_portal;   // [ceil(n_leaves >> leaf_block_shift)] or empty
     int32_t leaf_block_shift = 0;
     std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
-    std::vector<uint8_t> rec_i;         // [n * record_bytes/2]
+    std::vector<uint8_t> rec_i;         // [n * record_bytes/2], or empty: left out under a table budget (pairs that share a
+                                        // portal are then walked on the tree itself: kernels_canopy.h::same_portal_by_walk)
+    // Table budget (host_upload.h): bytes the record tables rec_a + rec_b (+ rec_i) may take; 0 = no limit.
+    // prepare_canopy refuses the canopy family when rec_a + rec_b alone exceed it and leaves rec_i out when all three do.
+    // (< 0: geometry only -- prepare_canopy says whether the tree would admit the family and builds nothing.)
+    int64_t record_budget_bytes = 0;
     // Lineage sums (deep canopies with a sparse table; prepare_lineage_sums): the a side of a
     // pair is a sum that STARTS at a -- d = 0; d += dist[n] for n = a, parent(a), ... (pyx:934-936)
     // -- so every prefix of it can be tabulated per node, bit for bit: lineage_sum[off(x) + k] =
@@ -192,6 +197,10 @@ struct TreeTables {
 // so that leaf-pair queries touch a dense half of the table.
 ST_HD int64_t record_slot(int64_t x, bool parity, int64_t n_leaves) {
     return parity ? ((x & 1) ? n_leaves + (x >> 1) : (x >> 1)) : x;
+}
+// ... and back
+ST_HD int64_t record_node(int64_t slot, bool parity, int64_t n_leaves) {
+    return parity ? (slot < n_leaves ? 2 * slot : 2 * (slot - n_leaves) + 1) : slot;
 }
 
 // (Re)builds the whole-tree sparse table if ids are in-order and it stays within max_bytes

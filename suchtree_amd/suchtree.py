@@ -71,7 +71,7 @@ class SuchTree:
     """
 
     def __init__(self, tree_input, device: int = 0, strategy: str = "auto", devices=None,
-                 pinned_results=None):
+                 pinned_results=None, table_mb=None):
         self._epsilon = EPSILON
         if isinstance(tree_input, FlatTree):
             flat = tree_input
@@ -102,6 +102,7 @@ class SuchTree:
             raise ValueError("strategy must be one of %s" % sorted(_capi.STRATEGY))
         self._strategy = strategy
         self._pinned_results = pinned_results
+        self._table_mb = table_mb      # budget (MiB) of the device tables: _capi.DeviceTree
         self._dev_tree = None
 
     # ------------------------------------------------------------------ device
@@ -115,7 +116,8 @@ class SuchTree:
         if self._dev_tree is None:
             self._dev_tree = _capi.DeviceTree(self._flat.parent, self._flat.distance,
                                               device=self._device, strategy=self._strategy,
-                                              devices=self._devices, pinned_results=self._pinned_results)
+                                              devices=self._devices, pinned_results=self._pinned_results,
+                                              table_mb=self._table_mb)
         return self._dev_tree
 
     def to_device(self) -> "SuchTree":

@@ -126,6 +126,32 @@ def random_binary_tree(n_leaves, seed=0, zero_fraction=0.0):
     return parent.astype(np.int32), lengths.astype(np.float32)
 
 
+def random_binary_tree_levels(n_leaves, seed=0):
+    """Random strictly binary tree (uniform random split sizes, as ``random_binary_tree``; another random stream),
+    in-order ids, built one level of splits at a time with array operations: tens of millions of nodes in seconds."""
+    rng = np.random.default_rng(seed)
+    n = 2 * n_leaves - 1
+    parent = np.full(n, -1, dtype=np.int64)
+    lo = np.zeros(1, dtype=np.int64)
+    hi = np.full(1, n - 1, dtype=np.int64)
+    par = np.full(1, -1, dtype=np.int64)
+    while lo.size:
+        single = lo == hi
+        parent[lo[single]] = par[single]
+        lo, hi, par = lo[~single], hi[~single], par[~single]
+        if not lo.size:
+            break
+        leaves = (hi - lo) // 2 + 1
+        left = 1 + (rng.random(lo.size) * (leaves - 1)).astype(np.int64)      # 1 .. leaves - 1
+        left = np.minimum(np.maximum(left, 1), leaves - 1)
+        node = lo + 2 * left - 1
+        parent[node] = par
+        lo, hi, par = np.concatenate([lo, node + 1]), np.concatenate([node - 1, hi]), np.concatenate([node, node])
+    lengths = rng.uniform(0.0001, 2.0, size=n)
+    lengths[parent < 0] = -1.0
+    return parent.astype(np.int32), lengths.astype(np.float32)
+
+
 def skewed_tree(rng, n_leaves, skew):
     """Random strictly binary tree whose split sizes are skewed towards caterpillars (skew -> 1) or towards
     balance (skew -> 0); in-order ids.  ``rng``: a numpy Generator (the tree is a function of its state).  With

@@ -742,6 +742,72 @@ def test_deep_canopy_tree_with_walk_form_lineage_tables(ml_arrays, monkeypatch):
     dev.close()
 
 
+def test_table_budget_on_the_device(ml_arrays):
+    """A budget for the device tables (SuchTree(..., table_mb=) / st_tree_create_ex / SUCHTREE_AMD_TABLE_MB): tables are
+    left out in the stated order, st_tree_info says which and stays within the budget, and every form that takes over
+    gives the oracle's bits -- random pairs, pairs under one portal (walked on the tree once the id chains are gone),
+    MRCA ids alone, the host path, generated pairs.  ml.tree down to 32 MiB and below; a 2^24-leaf tree of random shape
+    (33.5 M nodes, 10 GB of tables without a budget) under 2 GiB."""
+    import torch
+    parent, dist, leaf_ids = ml_arrays
+    n = len(parent)
+    rng = np.random.default_rng(707)
+    a = rng.integers(0, n - 12, 60_000)
+    allp = np.concatenate([rng.integers(0, n, (200_000, 2)), np.stack([a, a + rng.integers(0, 12, a.size)], 1),
+                           np.stack([a[:3000], a[:3000]], 1)]).astype(np.int64)
+    want_d, want_m = oracle_both(parent, dist, allp)
+    t = torch.from_numpy(allp).cuda()
+    seen = set()
+    for mb in (None, 100, 40, 32, 12, 6, 3.5):
+        dev = _capi.DeviceTree(parent, dist, table_mb=mb)
+        info = dev.info()
+        seen.add(tuple(info["dropped_tables"]))
+        if mb is not None:
+            assert info["table_budget_bytes"] == int(mb * 2**20) and info["device_bytes"] <= mb * 2**20, info
+        out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+        out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+        dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+        dev.fault_check()
+        assert_bits_equal(out_d.cpu().numpy(), want_d, "table_mb=%s %s" % (mb, info["dropped_tables"]))
+        assert np.array_equal(out_m.cpu().numpy(), want_m), (mb, info["dropped_tables"])
+        out_m.fill_(-5)
+        dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())
+        assert np.array_equal(out_m.cpu().numpy(), want_m), (mb, "MRCA ids alone")
+        for n_host in (3_000, 50_000, len(allp)):
+            d, m = dev.distances_host(allp[:n_host], True, True)
+            assert_bits_equal(d, want_d[:n_host], "host path table_mb=%s n=%d" % (mb, n_host))
+            assert np.array_equal(m, want_m[:n_host])
+        dev.close()
+    assert () in seen and any("rec_i" in s and "canopy" not in s for s in seen) and any("canopy" in s for s in seen), seen
+    # the predicated kernel of a shallow canopy without its id chains: pairs of nearby leaves are walked
+    par, dst = synth.balanced_tree(17)
+    O = OracleTree(par, dst)
+    a = rng.integers(0, len(par) - 9, 150_000)
+    near = np.concatenate([np.stack([a, a + rng.integers(0, 9, a.size)], 1), rng.integers(0, len(par), (150_000, 2))]).astype(np.int64)
+    dev = _capi.DeviceTree(par, dst, table_mb=20)
+    info = dev.info()
+    assert "rec_i" in info["dropped_tables"] and info["strategy"] == "canopy" and info["device_bytes"] <= 20 * 2**20, info
+    for ppl in (1, 2, 0):
+        dev.set_option("pairs_per_lane", ppl)
+        d, m = dev.distances_host(near, True, True)
+        assert_bits_equal(d, O.distances(near), "2^17 leaves without id chains, pairs_per_lane=%d" % ppl)
+        assert np.array_equal(m, O.mrca_bulk(near))
+        assert np.array_equal(dev.distances_host(near, False, True)[1], O.mrca_bulk(near))
+    dev.close()
+    # 2^24 leaves of random shape under 2 GiB: the floor (940 MB) and whatever else fits; the walk kernel climbs
+    par, dst = synth.random_binary_tree_levels(1 << 24, seed=24)
+    dev = _capi.DeviceTree(par, dst, table_mb=2048)
+    info = dev.info()
+    assert info["strategy"] == "walk" and "canopy" in info["dropped_tables"] and info["device_bytes"] <= 2048 * 2**20, info
+    pairs = rng.integers(0, len(par), (400_000, 2))
+    d, m = dev.distances_host(pairs, True, True)
+    O = OracleTree(par, dst)
+    k = 60_000
+    assert_bits_equal(d[:k], O.distances(pairs[:k]), "2^24 leaves under 2 GiB")
+    assert np.array_equal(m[:k], O.mrca_bulk(pairs[:k]))
+    dev.close()
+
+
 def test_mrca_only_requests_from_the_rank_table(ml_arrays):
     """MRCA ids without distances on trees with in-order ids: k_mrca_ranks (rank of either portal
     + sparse table; shared-portal pairs through the understory records).  Shallow and deep tree,

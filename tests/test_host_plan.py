@@ -145,3 +145,40 @@ def test_recycle_pool_of_ordinary_memory():
     P.trim()
     assert P.total == 0 and not P._free
     assert _capi.RecyclePool(budget_bytes=0).array(50_000_000, np.float64) is None      # switched off
+
+
+def test_table_budget_plan_drops_tables_in_the_stated_order(ml_arrays):
+    """st_host_table_plan (no GPU): under a shrinking budget the accelerator tables go in the order of the ST_TABLE_*
+    bits -- a smaller budget never keeps a table a larger one dropped --, the device bytes stay within the budget down
+    to the floor (28 bytes per node), and below the records the walk family takes over."""
+    from suchtree_amd import _capi, synth
+    order = [name for _, name in _capi.DROPPED_TABLES]
+    parent, dist, _ = ml_arrays
+    trees = [("ml.tree", parent, dist), ("2^16 balanced", *synth.balanced_tree(16)), ("random 40k", *synth.random_binary_tree_levels(40_000, seed=2))]
+    for what, par, dst in trees:
+        full = _capi.host_table_plan(par, dst)
+        assert full["dropped_tables"] == [] and full["family"] == "canopy", (what, full)
+        floor = 28 * len(par) + 64
+        seen_walk = False
+        prev = set()
+        mb = full["device_bytes"] / 2**20 * 1.01
+        while mb > floor / 2**20 * 0.5:
+            plan = _capi.host_table_plan(par, dst, table_mb=mb)
+            dropped = plan["dropped_tables"]
+            assert dropped == [t for t in order if t in dropped], (what, mb, dropped)      # listed in drop order
+            assert prev <= set(dropped), (what, mb, prev, dropped)                           # monotone
+            if mb * 2**20 >= floor:
+                assert plan["device_bytes"] <= mb * 2**20, (what, mb, plan)
+            else:
+                assert plan["device_bytes"] <= floor + 4096 and plan["family"] == "walk", (what, mb, plan)
+            if "canopy" in dropped:
+                assert plan["family"] == "walk" and {"rec_i", "rec_a4", "ranks"} <= set(dropped)
+                seen_walk = True
+            else:
+                assert plan["family"] == "canopy"
+            prev = set(dropped)
+            mb *= 0.8
+        assert seen_walk and {"lineage_len", "lineage_sum", "tree_rmq", "rec_i", "canopy"} <= prev | {"lineage_len", "lineage_sum"}, (what, prev)
+    # the walk family asked for: nothing of the canopy family is "dropped", the optional walk tables are
+    plan = _capi.host_table_plan(parent, dist, strategy="walk", table_mb=4)
+    assert plan["family"] == "walk" and "canopy" not in plan["dropped_tables"] and plan["device_bytes"] <= 4 * 2**20
