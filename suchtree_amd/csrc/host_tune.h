@@ -36,7 +36,7 @@ static void rule_for_deep_tree(st_tree *t)
     // 63-slot chains: the tile-sorted canopy kernel reads them through a pointer and never won a measurement
     if (t->rec_cap > 31 || sorted_q(t) <= 0) { t->pairs_per_lane = 1; t->tile_sort = 0; }
     t->prefer_walk_sorted = walk_sorted_by_rule(t) ? 1 : 0;
-    t->ladder_scalar = 0;
+    t->ladder_scalar = t->rec_bytes > kMaxRecordBytes ? 1 : 0;      // (1 KB records: no other canopy kernel reads them well)
 }
 
 // ---- persistent record of what a tree measured -------------------------------------------------------------
@@ -122,11 +122,11 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         int a, b, c, d;
         if (tune_cache_read(cache, a, b, c, d)) {
             // (a recorded choice the handle cannot serve -- other table budget, other options -- is ignored)
-            const int keep_sort = t->tile_sort, keep_ppl = t->pairs_per_lane, keep_walk = t->prefer_walk_sorted;
+            const int keep_sort = t->tile_sort, keep_ppl = t->pairs_per_lane, keep_walk = t->prefer_walk_sorted, keep_ladder = t->ladder_scalar;
             t->tile_sort = a; t->pairs_per_lane = b; t->prefer_walk_sorted = c; t->ladder_scalar = d;
             const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_scalar_ready(t));
             if (ok) { t->info.tuned = 2; return; }
-            t->tile_sort = keep_sort; t->pairs_per_lane = keep_ppl; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = 0;
+            t->tile_sort = keep_sort; t->pairs_per_lane = keep_ppl; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = keep_ladder;
         }
     }
     // sample: uniform random leaf pairs (the reference's typical query, and the bench's)
@@ -182,7 +182,7 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         return best;
     };
     if (ok) {
-        const int rule_sort = t->tile_sort, rule_ppl = t->pairs_per_lane, rule_walk = t->prefer_walk_sorted;
+        const int rule_sort = t->tile_sort, rule_ppl = t->pairs_per_lane, rule_walk = t->prefer_walk_sorted, rule_ladder = t->ladder_scalar;
         struct Cand { int sort, ppl, walk, ladder; float ms; };
         std::vector<Cand> cands;
         if (sorted_q(t) > 0) cands.push_back({1, 0, 0, 0, -1.0f});
@@ -194,26 +194,29 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         t->prefer_walk_sorted = 1;
         if (prefers_walk_sorted(t, n, true)) cands.push_back({rule_sort, rule_ppl, 1, 0, -1.0f});
         for (Cand &c : cands) c.ms = time_settings(c.sort, c.ppl, c.walk, c.ladder);
-        const Cand *best = nullptr, *rule = nullptr;
+        const Cand *best = nullptr, *rule = nullptr, *best_canopy = nullptr;
         for (const Cand &c : cands) {
             if (c.ms <= 0.0f) continue;
             if (!best || c.ms < best->ms) best = &c;
+            if (!c.walk && (!best_canopy || c.ms < best_canopy->ms)) best_canopy = &c;
             // the rule's choice among the candidates (with the walk kernel chosen, the canopy settings behind it do not matter)
-            if (c.walk == rule_walk && !c.ladder && (c.walk || (c.sort == rule_sort && c.ppl == rule_ppl))) rule = &c;
+            if (c.walk == rule_walk && (c.walk || (c.ladder == rule_ladder && c.sort == rule_sort && c.ppl == rule_ppl))) rule = &c;
         }
         if (best && rule && best != rule && best->ms > kTuneMargin * rule->ms) best = rule;      // too close to call: the rule stands
         if (best) {
-            t->tile_sort = best->walk ? rule_sort : best->sort;
-            t->pairs_per_lane = best->walk ? rule_ppl : best->ppl;
+            // (the walk kernel only takes batches of 524288 pairs and more: below that the fastest canopy kernel serves)
+            const Cand *canopy = best->walk ? best_canopy : best;
+            t->tile_sort = canopy ? canopy->sort : rule_sort;
+            t->pairs_per_lane = canopy ? canopy->ppl : rule_ppl;
+            t->ladder_scalar = canopy ? canopy->ladder : rule_ladder;
             t->prefer_walk_sorted = best->walk;
-            t->ladder_scalar = best->ladder;
             t->info.tuned = 1;
             tune_cache_write(cache, t->tile_sort, t->pairs_per_lane, t->prefer_walk_sorted, t->ladder_scalar);
         } else {
             t->tile_sort = rule_sort;
             t->pairs_per_lane = rule_ppl;
             t->prefer_walk_sorted = rule_walk;
-            t->ladder_scalar = 0;
+            t->ladder_scalar = rule_ladder;
         }
     } else {
         rule_for_deep_tree(t);

@@ -160,8 +160,20 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
         // when the records would not fit beside it)
         B.T.record_budget_bytes = std::max<int64_t>(1, B.budget - table_floor_bytes(n_nodes));
     }
+    // Records: up to 512 bytes (63-slot chains) with every kernel of the family; trees that need more -- up to 127
+    // levels below the canopy: 1e6 leaves at depth 340 -- get 1 KB records without id chains, read through a pointer by
+    // the scalar ladder kernel alone (k_canopy_ladder<0>): 9.4e9 pairs/s on that tree where the walk family's tables
+    // give 7.5e9 (profiles/kernel_choice_r04.log).  SUCHTREE_AMD_MAX_RECORD_BYTES=512 keeps such trees with the walk family.
+    int max_record = kLongRecordBytes;
+    if (const char *env = std::getenv("SUCHTREE_AMD_MAX_RECORD_BYTES")) max_record = std::atoi(env);
     if (strategy != ST_STRATEGY_WALK) {
+        B.T.max_record_bytes = std::min<int>(max_record, kMaxRecordBytes);
         B.canopy_ok = prepare_canopy(parent, distance, B.T, max_canopy);
+        if (!B.canopy_ok && max_record > kMaxRecordBytes && max_canopy == 0) {
+            // (the ladder image of the kernel that reads such records: at most 10240 canopy nodes)
+            B.T.max_record_bytes = kLongRecordBytes;
+            B.canopy_ok = prepare_canopy(parent, distance, B.T, kDeepCanopyNodes);
+        }
         // Deep canopies (real, unbalanced phylogenies: hundreds of levels) spend their time in
         // the LDS climb, not in memory.  There a canopy image small enough for two workgroups
         // per CU, a longer understory (more of each lineage pre-summed in its record) and the
@@ -384,6 +396,11 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
     t->info.dropped_tables = B.dropped;
     t->info.table_budget_bytes = B.budget;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
+    if (t->rec_bytes > kMaxRecordBytes) {      // 1 KB records: the scalar ladder kernel (the scalar kernel over the plain image otherwise)
+        t->pairs_per_lane = 1;
+        t->tile_sort = 0;
+        t->ladder_scalar = 1;
+    }
     if (B.deep && !tune) rule_for_deep_tree(t);
     if (B.deep && tune) {      // (host_tune.h: the kernel of large batches, by timing the candidates; the rule's defaults if that fails)
         try {

@@ -242,10 +242,10 @@ template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ladder(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, MrcaSink out_m, Fault *fault)
 {
-    static_assert(CAP == 15 || CAP == 31 || CAP == 63, "long chains in registers");
+    static_assert(CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63, "long chains in registers, or (0) through a pointer");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     stage_ladder(P, lds_raw);
-    constexpr int rec_bytes = 8 * (CAP + 1);
+    const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const bool parity = P.parity != 0;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {

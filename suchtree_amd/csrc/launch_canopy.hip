@@ -51,8 +51,8 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     if (t->tile_sort && sorted_q(t) > 0)
         return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
     // the scalar ladder kernel (option ladder_scalar; deep trees: set when the tree is created, host_tune.h)
-    if constexpr (CAP == 15 || CAP == 31 || CAP == 63) {
-        if (t->ladder_scalar && P.ladder && ladder_image_bytes(t->canopy_nodes) <= 160 * 1024)
+    if constexpr (CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63) {
+        if (ladder_scalar_ready(t))
             return launch_canopy_k(k_canopy_ladder<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream, ladder_image_bytes(t->canopy_nodes));
     }
     if constexpr (CAP == 0) {

@@ -26,6 +26,7 @@ struct SortedShape {
 
 static inline SortedShape sorted_shape(const st_tree *t)
 {
+    if (t->rec_bytes > 512) return {0, false, false};      // (1 KB records: the scalar ladder kernel alone)
     const size_t image = ladder_image_bytes(t->canopy_nodes);
     const bool table = t->d_rmq != nullptr;
     const bool lineage = table && t->d_lineage != nullptr && t->d_rec_p != nullptr && t->lineage_sums;      // (rec_p: the canopy family's offsets into the table)
@@ -84,7 +85,7 @@ static inline int64_t canopy_min_pairs(const st_tree *t)
 static inline bool ladder_scalar_ready(const st_tree *t)
 {
     return t->strategy == ST_STRATEGY_CANOPY && t->ladder_scalar && !(t->tile_sort && sorted_q(t) > 0) && t->d_ladder &&
-           (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap == 63) && ladder_image_bytes(t->canopy_nodes) <= 160 * 1024;
+           (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap >= 63) && ladder_image_bytes(t->canopy_nodes) <= 160 * 1024;
 }
 
 static inline bool mrca_ranks_ready(const st_tree *t)

@@ -234,9 +234,13 @@ ST_HD float chain_sum_ptr(const float *__restrict__ D, uint32_t nb, float s)
     if (nb <= 1) return nb ? s + D[0] : s;      // (one-slot records are 8 bytes: no 16-byte read there)
     const Quad *q = reinterpret_cast<const Quad *>(D - 1);      // {word0, D[0], D[1], D[2]}, {D[3] ...}, ...
     if (nb >= 8) {
+        // the next block's four loads are issued before the current block is added (one block ahead: a 127-slot
+        // chain is eight round trips to memory otherwise, each waited for in turn)
+        Quad a = q[0], b = q[1], c = q[2], d = q[3];
         for (uint32_t base = 0; base <= nb; base += 16) {      // the block holds slots base - 1 .. base + 14
-            const Quad a = q[0], b = q[1], c = q[2], d = q[3];
             q += 4;
+            Quad na = a, nb4 = b, nc = c, nd = d;
+            if (base + 16 <= nb) { na = q[0]; nb4 = q[1]; nc = q[2]; nd = q[3]; }
             if (base) s += a.x;      // (base - 1 < nb: the loop condition)
             if (base + 0 < nb) s += a.y;
             if (base + 1 < nb) s += a.z;
@@ -253,6 +257,7 @@ ST_HD float chain_sum_ptr(const float *__restrict__ D, uint32_t nb, float s)
             if (base + 12 < nb) s += d.y;
             if (base + 13 < nb) s += d.z;
             if (base + 14 < nb) s += d.w;
+            a = na; b = nb4; c = nc; d = nd;
         }
         return s;
     }

@@ -231,12 +231,13 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
     while (h_min < hmax && count_ge[(size_t)h_min + 1] > max_canopy_nodes) h_min++;
     if (count_ge[(size_t)h_min + 1] > max_canopy_nodes) return false;   // cannot happen (count_ge[hmax+1] = 0)
     int32_t rec_bytes = std::max(kMinRecordBytes, pow2_ceil(8 + 8 * h_min));
-    if (rec_bytes > kMaxRecordBytes) return false;
+    if (rec_bytes > std::max<int32_t>(kMinRecordBytes, std::min<int32_t>(T.max_record_bytes, kLongRecordBytes))) return false;
     // table budget: the record tables are what the canopy family costs (8 + R/2 bytes per node, R/2 more with the
     // id chains of the shared-portal case)
     bool with_ids = true;
     if (T.record_budget_bytes < 0) return true;      // (geometry only: would the tree admit the family? nothing is built)
     T.rec_i.clear();
+    if (rec_bytes > kMaxRecordBytes) with_ids = false;      // (1 KB records: a GB per million nodes for the rare shared-portal case)
     if (T.record_budget_bytes > 0) {
         const int64_t core = n * (8 + (int64_t)rec_bytes / 2);
         if (core > T.record_budget_bytes) return false;

@@ -78,6 +78,7 @@ static_assert(sizeof(LadderEntry) == 16, "LadderEntry must be 16 bytes");
 // is kept as the name of the geometry: rec_b and rec_i have stride R/2.
 constexpr int kMaxCanopyNodes = 16384;   // 16384 * 8 B = 128 KiB of the 160 KiB LDS
 constexpr int kMaxRecordBytes = 512;
+constexpr int kLongRecordBytes = 1024;   // 127-slot chains, read through a pointer by the scalar ladder kernel alone (TreeTables::max_record_bytes)
 constexpr int kMinRecordBytes = 16;
 constexpr int64_t kMaxTreeRmqBytes = (int64_t)64 << 20;   // whole-tree sparse table: trees of up to ~450k nodes
 constexpr int64_t kMaxTreeRmqBytesWalkOnly = (int64_t)4 << 30;   // ... up to ~20M nodes when the walk family is all a tree has
@@ -138,6 +139,7 @@ struct TreeTables {
     // prepare_canopy refuses the canopy family when rec_a + rec_b alone exceed it and leaves rec_i out when all three do.
     // (< 0: geometry only -- prepare_canopy says whether the tree would admit the family and builds nothing.)
     int64_t record_budget_bytes = 0;
+    int32_t max_record_bytes = kMaxRecordBytes;   // prepare_canopy refuses trees that need longer records (kLongRecordBytes: opt-in, no id chains)
     // Lineage sums (deep canopies with a sparse table; prepare_lineage_sums): the a side of a
     // pair is a sum that STARTS at a -- d = 0; d += dist[n] for n = a, parent(a), ... (pyx:934-936)
     // -- so every prefix of it can be tabulated per node, bit for bit: lineage_sum[off(x) + k] =
