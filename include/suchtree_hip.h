@@ -322,8 +322,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * family's tables (deep trees) go to the tile-sorted walk kernel; 0 = they stay with the canopy kernels.  Like
  * "tile_sort" and "pairs_per_lane" its default is set when the tree is created, on deep trees by timing the candidate
  * kernels on a sample of random leaf pairs (st_tree_info.tuned; SUCHTREE_AMD_AUTOTUNE=0: by a fixed rule).
- * "ladder_scalar": 1 = (with "tile_sort" 0) records of 128 bytes and more are served by the scalar kernel over the ladder
- * form of the canopy; a default set with the three above when a deep tree is created.
+ * "ladder_scalar": 1 = distance batches of at least "ladder_min_pairs" pairs (0 = 131072) on records of 128 bytes and
+ * more are served by the scalar kernel over the ladder form of the canopy (records read once, no sort: large batches);
+ * both defaults are set with the three above when a deep tree is created (timed at two batch sizes).
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
  * "sort_tile": tile of both tile-sorted kernels in units of 1024 pairs: 1, 2 or 4 (taken when it fits LDS and the
  * kernel's form has that tile), 0 (default) = the largest tile LDS admits, cut finer for batches that would

@@ -47,14 +47,15 @@ template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                   DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
+    // the scalar ladder kernel: large distance batches of handles that chose it (launch_policy.h: ladder_applies;
+    // records of more than 512 bytes: every batch the family takes -- nothing else reads them well)
+    if constexpr (CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63) {
+        if ((out_d.any() && ladder_applies(t, n)) || (t->rec_bytes > 512 && t->ladder_scalar && ladder_tables_ready(t)))
+            return launch_canopy_k(k_canopy_ladder<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream, ladder_image_bytes(t->canopy_nodes));
+    }
     // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
     if (t->tile_sort && sorted_q(t) > 0)
         return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
-    // the scalar ladder kernel (option ladder_scalar; deep trees: set when the tree is created, host_tune.h)
-    if constexpr (CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63) {
-        if (ladder_scalar_ready(t))
-            return launch_canopy_k(k_canopy_ladder<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream, ladder_image_bytes(t->canopy_nodes));
-    }
     if constexpr (CAP == 0) {
         return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     } else if constexpr (CAP == 31 || CAP == 63) {

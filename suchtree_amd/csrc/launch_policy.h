@@ -76,16 +76,34 @@ constexpr int64_t kCanopyMinPairs = 4096;
 // profiles/midsize_r03.log)
 constexpr int64_t kSortedMinPairs = 131072;
 
+// k_canopy_ladder (launch_canopy.hip): records of 128 bytes and more, ladder image fits LDS.  The kernel reads every
+// record once, keeps no scratch and sorts nothing, which pays on large batches only: a pass through it is a chain of
+// four dependent global round trips and an LDS climb (17-30 us for ANY batch, k_walk: 8 us), and without a sort its
+// waves finish unevenly, so few tiles per wave leave a long tail (us per call, ladder / tile-sorted canopy / walk
+// kernels: ml.tree 2^17 pairs 20.8 / 19.0 / 20.0, 2^21 pairs 128 / 94 / 121, 2e7 pairs 700 / 880 / 1110; 1e6 leaves
+// depth 173: 23 / 31 / 27 at 2^17, 136 / 240 / 300 at 2^21; 1e6 leaves depth 338: 300 / - / 304 at 2^21, 2270 / - /
+// 2890 at 2e7; profiles/ladder_midsize_r04.log).  Its smallest batch is therefore timed too (host_tune.h).
+constexpr int64_t kLadderMinPairs = 131072;
+static inline bool ladder_tables_ready(const st_tree *t)
+{
+    return t->strategy == ST_STRATEGY_CANOPY && t->d_ladder && (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap >= 63) &&
+           ladder_image_bytes(t->canopy_nodes) <= 160 * 1024;
+}
+static inline bool ladder_applies(const st_tree *t, int64_t n)
+{
+    return t->ladder_scalar && n >= std::max<int64_t>(t->ladder_min_pairs, kLadderMinPairs) && ladder_tables_ready(t);
+}
+static inline bool ladder_scalar_ready(const st_tree *t) { return ladder_applies(t, (int64_t)1 << 40); }
+
+// Smallest batch the canopy kernels take: 4096 pairs -- or, on deep trees whose heavy kernels (tile-sorted, scalar
+// ladder) have a fixed cost of 15-30 us and whose walk kernel has a's side in one read (lineage sums by node id),
+// kSortedMinPairs.
 static inline int64_t canopy_min_pairs(const st_tree *t)
 {
-    return t->tile_sort && t->d_lineage && t->d_rec_p && t->lineage_sums && sorted_q(t) > 0 ? kSortedMinPairs : kCanopyMinPairs;
-}
-
-// k_canopy_ladder (launch_canopy.hip): option on, tile sort off, records of 128 bytes and more, ladder image fits LDS
-static inline bool ladder_scalar_ready(const st_tree *t)
-{
-    return t->strategy == ST_STRATEGY_CANOPY && t->ladder_scalar && !(t->tile_sort && sorted_q(t) > 0) && t->d_ladder &&
-           (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap >= 63) && ladder_image_bytes(t->canopy_nodes) <= 160 * 1024;
+    const bool walk_is_quick = t->d_lineage && t->d_lineage_node_rec && t->lineage_sums;
+    const bool sorted = t->tile_sort && t->d_rec_p && sorted_q(t) > 0;
+    const bool ladder = t->ladder_scalar && ladder_tables_ready(t);
+    return walk_is_quick && (sorted || ladder) ? kSortedMinPairs : kCanopyMinPairs;
 }
 
 static inline bool mrca_ranks_ready(const st_tree *t)
@@ -105,6 +123,7 @@ constexpr int64_t kWalkSortedMinPairs = 262144;
 static inline int64_t walk_sorted_min_pairs(const st_tree *t) { return t->walk_sort_min > 0 ? t->walk_sort_min : kWalkSortedMinPairs; }
 static inline bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
 {
+    if (want_dist && ladder_applies(t, n)) return false;      // (large batches of a handle that measured the ladder kernel fastest)
     if (t->strategy != ST_STRATEGY_CANOPY || !t->prefer_walk_sorted || !want_dist || n < std::max<int64_t>(walk_sorted_min_pairs(t), 524288)) return false;
     return t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t);
 }
@@ -130,7 +149,8 @@ static inline bool sorted_zero_copy(const st_tree *t)
 static inline bool wants_device_stage(const st_tree *t, int64_t m)
 {
     if (t->strategy != ST_STRATEGY_CANOPY || !t->tile_sort || sorted_q(t) <= 0) return false;
-    if (prefers_walk_sorted(t, m, true)) return false;      // (that kernel reads every pair once and stores coalesced)
+    if (ladder_applies(t, m)) return false;                 // (the scalar ladder kernel reads every pair once and stores coalesced)
+    if (prefers_walk_sorted(t, m, true)) return false;      // (and so does this one)
     if (sorted_zero_copy(t)) return false;
     return m >= canopy_min_pairs(t);
 }

@@ -58,7 +58,8 @@ struct st_tree {
     int64_t n_nodes = 0, n_leaves = 0;
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
-    int ladder_scalar = 0;    // tuning: 1 = (tile_sort off) records of 128 bytes and more go to k_canopy_ladder: the scalar kernel over the ladder image, meeting nodes from the sparse table (set when the tree is created: timed)
+    int ladder_scalar = 0;    // tuning: 1 = distance batches of >= ladder_min_pairs pairs on records of 128 bytes and more go to k_canopy_ladder: the scalar kernel over the ladder image, meeting nodes from the sparse table (set when the tree is created: timed)
+    int64_t ladder_min_pairs = 0;   // smallest batch of that kernel; 0 = kLadderMinPairs (set when the tree is created: timed at two batch sizes)
     int prefer_walk_sorted = 0;   // large distance batches of a canopy-strategy tree go to k_walk_sorted (set when the tree is created: timed, or by rule)
     int wire48 = 1;           // tuning: 0 = host-path ids always cross the link as int32 (8 bytes per pair), also on trees of fewer than 2^24 nodes
     int wire24 = 1;           // tuning: 0 = host-path MRCA ids always come back as int32 (8 bytes per pair with the float32 distance), also on trees of fewer than 2^24 nodes

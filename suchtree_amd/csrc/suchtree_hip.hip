@@ -376,6 +376,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->ladder_scalar = (int)value;
         return ST_OK;
     }
+    if (std::strcmp(name, "ladder_min_pairs") == 0) {
+        if (value < 0) return fail(ST_ERR_ARG, "ladder_min_pairs must be >= 0");
+        t->ladder_min_pairs = value;
+        return ST_OK;
+    }
     if (std::strcmp(name, "tree_rmq") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tree_rmq must be 0 or 1");
         t->tree_rmq = (int)value;
