@@ -341,11 +341,12 @@ def leg_ceilings(be, tag, pairs_per_s, algorithmic_bytes_per_pair, table_bytes):
     return out
 
 
-def shape_tree_leg(be, skew, what, tag, n_leaves=1_000_000, n=10_000_000, sample=200_000):
+def shape_tree_leg(be, skew, what, tag, n_leaves=1_000_000, n=10_000_000, sample=200_000, walk_tag=None):
     """Trees beyond the BASELINE configs that the judge of round 3 asked to see in the driver's line: 1,000,000
-    leaves of skewed random shape (suchtree_amd.synth.skewed_tree, default_rng(5)) -- skew 0.9: depth ~340, the
-    canopy family refuses it and the walk family's tables serve it; skew 0.8: depth ~173, 512-byte records, the
-    kernel the handle picked when it was created.  1e7 uniform random leaf pairs in HBM, oracle check of a sample."""
+    leaves of skewed random shape (suchtree_amd.synth.skewed_tree, default_rng(5)) -- skew 0.9: depth ~340, beyond
+    512-byte records (round 3: the walk family's tables alone; since round 4 1 KB records read by the scalar ladder
+    kernel, the walk family timed beside it: walk_tag); skew 0.8: depth ~173, 512-byte records.  The kernel is the one
+    the handle picked when it was created.  1e7 uniform random leaf pairs in HBM, oracle check of a sample."""
     from oracle.oracle import OracleTree
     from suchtree_amd import _capi, synth
     torch = be.torch
@@ -358,22 +359,34 @@ def shape_tree_leg(be, skew, what, tag, n_leaves=1_000_000, n=10_000_000, sample
         g = torch.Generator(device=be.device)
         g.manual_seed(3)
         pairs_t = torch.randint(0, n_leaves, (n, 2), generator=g, device=be.device, dtype=torch.int64) * 2      # leaves = even ids
-        ms, out_d, out_m = _device_rate(be, tree, pairs_t)
-        h_mean = _mean_path_edges(be, parent, pairs_t, out_m)
         p = pairs_t[:sample].cpu().numpy()
         O = OracleTree(parent, dist)
         cores = len(os.sched_getaffinity(0))
-        ok = (np.array_equal(out_d[:sample].cpu().numpy().view(np.int64), O.distances_mt(p, cores).view(np.int64))
-              and np.array_equal(out_m[:sample].cpu().numpy(), O.mrca_bulk(p)))
-        alg = 28 + 8 * h_mean
+        want_d, want_m = O.distances_mt(p, cores), O.mrca_bulk(p)
+
+        def run(tag_):
+            ms, out_d, out_m = _device_rate(be, tree, pairs_t)
+            h = _mean_path_edges(be, parent, pairs_t, out_m)
+            ok = (np.array_equal(out_d[:sample].cpu().numpy().view(np.int64), want_d.view(np.int64))
+                  and np.array_equal(out_m[:sample].cpu().numpy(), want_m))
+            alg = 28 + 8 * h
+            r = {"kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok), "sample_pairs": sample,
+                 "algorithmic_GBps": alg * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            r.update(leg_ceilings(be, tag_, n / (ms * 1e-3), alg, info["device_bytes"]))
+            return r, h
+
+        main, h_mean = run(tag)
         out = {"workload": "%s: %d leaves, %d nodes, depth %d, %d uniform random leaf pairs, int64 ids in HBM -> float64 "
                            "distance + int32 MRCA id" % (what, n_leaves, len(parent), info["depth"], n),
                "kernel_family": info["strategy"], "kernel": info["big_batch_kernel"], "tuned": info["tuned"],
                "record_bytes": info["record_bytes"], "canopy_nodes": info["canopy_nodes"], "device_MB": info["device_bytes"] / 1e6,
-               "create_seconds": create_s, "kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok),
-               "sample_pairs": sample, "mean_path_edges": h_mean, "algorithmic_bytes_per_pair": alg,
-               "algorithmic_GBps": alg * n / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-        out.update(leg_ceilings(be, tag, n / (ms * 1e-3), alg, info["device_bytes"]))
+               "create_seconds": create_s, "mean_path_edges": h_mean, "algorithmic_bytes_per_pair": 28 + 8 * h_mean}
+        out.update(main)
+        if walk_tag and info["strategy"] != "walk":
+            tree.set_strategy("walk")
+            out["walk"] = run(walk_tag)[0]
+            out["walk"]["kernel"] = "walk_sorted"
+            tree.set_strategy("auto")
         return out
     finally:
         tree.close()
@@ -499,7 +512,8 @@ def other_configs(be):
     out = {}
     for key, fn in (("config2_ml_tree", lambda: config2(be, "ml")), ("config2_nj_tree", lambda: config2(be, "nj")),
                     ("config4_triangle_100k", lambda: config4(be)), ("config5_fish_worm", lambda: config5(be)),
-                    ("walk_only_tree", lambda: shape_tree_leg(be, 0.9, "tree the canopy family refuses (walk family's tables)", "walk_bigdeep")),
+                    ("walk_only_tree", lambda: shape_tree_leg(be, 0.9, "tree beyond 512-byte records (1 KB records / the walk family's tables)",
+                                                              "bigdeep", walk_tag="walk_bigdeep")),
                     ("deep_long_record_tree", lambda: shape_tree_leg(be, 0.8, "deep tree with 512-byte records", "s80"))):
         t0 = time.perf_counter()
         try:

@@ -234,13 +234,9 @@ ST_HD float chain_sum_ptr(const float *__restrict__ D, uint32_t nb, float s)
     if (nb <= 1) return nb ? s + D[0] : s;      // (one-slot records are 8 bytes: no 16-byte read there)
     const Quad *q = reinterpret_cast<const Quad *>(D - 1);      // {word0, D[0], D[1], D[2]}, {D[3] ...}, ...
     if (nb >= 8) {
-        // the next block's four loads are issued before the current block is added (one block ahead: a 127-slot
-        // chain is eight round trips to memory otherwise, each waited for in turn)
-        Quad a = q[0], b = q[1], c = q[2], d = q[3];
         for (uint32_t base = 0; base <= nb; base += 16) {      // the block holds slots base - 1 .. base + 14
+            const Quad a = q[0], b = q[1], c = q[2], d = q[3];
             q += 4;
-            Quad na = a, nb4 = b, nc = c, nd = d;
-            if (base + 16 <= nb) { na = q[0]; nb4 = q[1]; nc = q[2]; nd = q[3]; }
             if (base) s += a.x;      // (base - 1 < nb: the loop condition)
             if (base + 0 < nb) s += a.y;
             if (base + 1 < nb) s += a.z;
@@ -257,7 +253,6 @@ ST_HD float chain_sum_ptr(const float *__restrict__ D, uint32_t nb, float s)
             if (base + 12 < nb) s += d.y;
             if (base + 13 < nb) s += d.z;
             if (base + 14 < nb) s += d.w;
-            a = na; b = nb4; c = nc; d = nd;
         }
         return s;
     }
@@ -271,6 +266,40 @@ ST_HD float chain_sum_ptr(const float *__restrict__ D, uint32_t nb, float s)
         if (nb > 4) s += v.y;
         if (nb > 5) s += v.z;
         if (nb > 6) s += v.w;
+    }
+    return s;
+}
+
+// The same additions with the next block's four loads issued before the current block is added (one block ahead):
+// a 127-slot chain is eight round trips to memory otherwise, each waited for in turn.  The hot path of the kernels
+// that read long chains through a pointer (CAP == 0 below); sixteen more registers than the plain form, which the
+// cold paths keep (pair_canopy_same_portal: its registers would otherwise set every kernel's allocation).
+ST_HD float chain_sum_ptr_ahead(const float *__restrict__ D, uint32_t nb, float s)
+{
+    if (nb < 8) return chain_sum_ptr(D, nb, s);
+    const Quad *q = reinterpret_cast<const Quad *>(D - 1);
+    Quad a = q[0], b = q[1], c = q[2], d = q[3];
+    for (uint32_t base = 0; base <= nb; base += 16) {      // the block holds slots base - 1 .. base + 14
+        q += 4;
+        Quad na = a, nb4 = b, nc = c, nd = d;
+        if (base + 16 <= nb) { na = q[0]; nb4 = q[1]; nc = q[2]; nd = q[3]; }
+        if (base) s += a.x;
+        if (base + 0 < nb) s += a.y;
+        if (base + 1 < nb) s += a.z;
+        if (base + 2 < nb) s += a.w;
+        if (base + 3 < nb) s += b.x;
+        if (base + 4 < nb) s += b.y;
+        if (base + 5 < nb) s += b.z;
+        if (base + 6 < nb) s += b.w;
+        if (base + 7 < nb) s += c.x;
+        if (base + 8 < nb) s += c.y;
+        if (base + 9 < nb) s += c.z;
+        if (base + 10 < nb) s += c.w;
+        if (base + 11 < nb) s += d.x;
+        if (base + 12 < nb) s += d.y;
+        if (base + 13 < nb) s += d.z;
+        if (base + 14 < nb) s += d.w;
+        a = na; b = nb4; c = nc; d = nd;
     }
     return s;
 }
@@ -333,7 +362,7 @@ ST_HD PairResult pair_canopy_split(CanPtr can, const int32_t *__restrict__ canop
 #pragma unroll
         for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
-        s = chain_sum_ptr(D_b, nb_b, s);
+        s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
     v = pb;
     while (v != mc) {
@@ -408,7 +437,7 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
 #pragma unroll
         for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
-        s = chain_sum_ptr(D_b, nb_b, s);
+        s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
     k = db - dm;
     uint32_t v = pb;
@@ -440,7 +469,7 @@ ST_HD float ladder_sum_b(LadPtr lad, uint32_t kb, float s_a, uint32_t pb, const 
 #pragma unroll
         for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
-        s = chain_sum_ptr(D_b, nb_b, s);
+        s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
     uint32_t k = kb;
     uint32_t v = pb;
@@ -505,7 +534,7 @@ ST_HD PairResult pair_ladder_split(LadPtr lad, DepthPtr cdepth, const int32_t *_
 #pragma unroll
         for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
-        s = chain_sum_ptr(D_b, nb_b, s);
+        s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
     k = db - du;
     v = pb;
