@@ -23,9 +23,9 @@ constexpr int64_t kTunePairs = (int64_t)1 << 23;      // (large enough for every
 static int big_batch_kernel_of(const st_tree *t)
 {
     if (t->strategy != ST_STRATEGY_CANOPY) return ST_KERNEL_WALK;
+    if (ladder_scalar_ready(t)) return ST_KERNEL_CANOPY_LADDER;      // (launch_canopy.hip: the first choice of large batches)
     if (prefers_walk_sorted(t, (int64_t)1 << 40, true)) return ST_KERNEL_WALK_SORTED;
     if (t->tile_sort && sorted_q(t) > 0) return ST_KERNEL_CANOPY_SORTED;
-    if (ladder_scalar_ready(t)) return ST_KERNEL_CANOPY_LADDER;
     return t->pairs_per_lane == 0 ? ST_KERNEL_CANOPY_SCALAR : ST_KERNEL_CANOPY;
 }
 

@@ -238,8 +238,12 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
 // reads and two table reads, all cache resident), so both sides climb with known edge counts, three edges per
 // 16-byte LDS read: max k_a / 3 + max k_b / 3 dependent LDS reads per wave where the predicated kernel's depth cut
 // takes max(k_a, k_b) + max k_b rounds of two reads each.  Without the table: the lock-step search on the ladder.
+// (launch bounds: two 1024-lane workgroups per CU = 8 waves per SIMD need at most 64 VGPRs AND at most 80 SGPRs --
+// the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD -- so the short-record form, whose
+// ladder image can leave room for two workgroups (ml.tree: 74 KiB), is compiled for 8; at 92 SGPRs it ran one
+// workgroup per CU and ml.tree at 2.0e10 pairs/s instead of 2.85e10)
 template <int CAP, typename Src>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ladder(CanopyParams P, Src src, long long n,
+__global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_ladder(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, MrcaSink out_m, Fault *fault)
 {
     static_assert(CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63, "long chains in registers, or (0) through a pointer");
@@ -284,8 +288,10 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_ladder(CanopyParams P, 
 // A4: the four-byte form of the a side (tree_prep.h): pbot from rec_a4 (4 bytes, a table half the size
 // of rec_a), the portal from the block table of leaf slots, staged into LDS behind the canopy image;
 // leaves of straddling blocks and internal nodes take the 8-byte entry (a wave-uniform rare branch).
+// (launch bounds: short records on canopies of at most 80 KiB run two workgroups per CU = 8 waves per SIMD, which the
+// hardware only admits at <= 64 VGPRs and <= 80 SGPRs; see k_canopy_ladder)
 template <int CAP, int PPL, typename Src, bool A4 = false>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy_ilp(CanopyParams P, Src src, long long n,
+__global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              DistSink out_d,
                                                              MrcaSink out_m, Fault *fault)
 {

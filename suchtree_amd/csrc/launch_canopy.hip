@@ -125,7 +125,7 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
     }
     // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
     // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
-    if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 &&
+    if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 && !(out_d.any() && ladder_applies(t, n)) &&
         ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq, sorted_shape(t).sums) > 80 * 1024)
         return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
     switch (t->rec_cap) {

@@ -15,7 +15,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CSRC = os.path.join(ROOT, "suchtree_amd", "csrc")
 
 
-def _vgprs(unit, tmp_path):
+def _resources(unit, tmp_path):
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
                           "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-c", "-Rpass-analysis=kernel-resource-usage",
                           "-o", str(tmp_path / "unit.o"), os.path.join(CSRC, unit)], capture_output=True, text=True, timeout=900)
@@ -27,7 +27,10 @@ def _vgprs(unit, tmp_path):
             name = m.group(1)
         m = re.search(r"\bVGPRs: (\d+)", line)
         if m and name:
-            res[name] = int(m.group(1))
+            res.setdefault(name, {})["vgpr"] = int(m.group(1))
+        m = re.search(r"TotalSGPRs: (\d+)", line)
+        if m and name:
+            res.setdefault(name, {})["sgpr"] = int(m.group(1))
         m = re.search(r"VGPRs Spill: (\d+)", line)
         if m and name:
             assert int(m.group(1)) == 0, (name, "spills")
@@ -36,19 +39,19 @@ def _vgprs(unit, tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_register_budgets_of_the_canopy_kernels(tmp_path):
-    v = _vgprs("launch_canopy.hip", tmp_path)
+    v = _resources("launch_canopy.hip", tmp_path)
 
     def of(fragment):
         hits = {k: n for k, n in v.items() if fragment in k}
         assert hits, fragment
         return hits
 
-    # two 1024-lane workgroups per CU (canopy / ladder images of at most 80 KiB): at most 64 VGPRs
-    for frag in ("k_canopy_ilpILi7ELi1ENS_9SrcContigELb1E", "k_canopy_ilpILi7ELi1ENS_11SrcContig32ELb1E",
-                 "k_canopy_ladderILi15ENS_9SrcContigE", "k_canopy_ladderILi15ENS_11SrcContig32E"):
+    # two 1024-lane workgroups per CU (canopy / ladder images of at most 80 KiB) are 8 waves per SIMD: at most 64
+    # VGPRs and at most 80 SGPRs (the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD)
+    for frag in ("k_canopy_ilpILi7ELi1E", "k_canopy_ilpILi3ELi1E", "k_canopy_ilpILi1ELi1E", "k_canopy_ladderILi15E"):
         for k, n in of(frag).items():
-            assert n <= 64, (k, n)
+            assert n["vgpr"] <= 64 and n["sgpr"] <= 80, (k, n)
     # every kernel of the family is launched with 1024 lanes: at most 128 VGPRs
     for k, n in v.items():
         if "k_canopy" in k or "k_mrca_ranks" in k:
-            assert n <= 128, (k, n)
+            assert n["vgpr"] <= 128, (k, n)
