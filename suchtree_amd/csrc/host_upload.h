@@ -109,7 +109,7 @@ static int64_t device_bytes_of(const BuiltTables &B)
         return walk_lineage ? sz(T.lineage_node_rec) + sz(T.lineage_len) + sz(T.crown_rmq) + sz(T.crown_ladder) : 0;
     };
     if (!B.canopy_ok) return b + (walk_lineage ? sz(T.lineage_sum) : 0) + walk_lineage_bytes();
-    b += sz(T.canopy) + 8 + sz(T.canopy_id) + sz(T.ladder) + sz(T.canopy_depth) + 16;
+    b += sz(T.canopy) + 8 + sz(T.canopy_id) + sz(T.ladder) + sz(T.canopy_depth) + 16 + (int64_t)kWorkSlots * 64 * 8;
     if (B.deep && T.inorder_ids && !T.canopy_rmq.empty()) b += sz(T.canopy_pos) + sz(T.canopy_rmq);
     b += sz(T.rec_a) + sz(T.rec_b) + sz(T.rec_i);
     if (!T.rec_a4.empty()) b += sz(T.rec_a4) + sz(T.leaf_block_portal) + 16;
@@ -380,6 +380,14 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
         if (e == hipSuccess) e = hipMemcpy(t->d_fault, init2, sizeof(init2), hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(ST_ERR_HIP, std::string("tree setup: ") + hipGetErrorString(e));
         else t->d_fault_host = t->d_fault + 1;
+    }
+    if (rc == ST_OK && B.canopy_ok && !T.ladder.empty()) {      // work counters of the scalar ladder kernel (optional: static deal without)
+        if (hipMalloc(reinterpret_cast<void **>(&t->d_work), (size_t)kWorkSlots * 64 * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            t->d_work = nullptr;
+        } else {
+            bytes += (int64_t)kWorkSlots * 64 * 8;
+        }
     }
     if (rc != ST_OK) return rc;      // (owner destroys t and keeps the message)
     t->strategy = B.canopy_ok ? ST_STRATEGY_CANOPY : ST_STRATEGY_WALK;

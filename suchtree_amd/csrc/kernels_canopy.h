@@ -242,18 +242,41 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
 // the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD -- so the short-record form, whose
 // ladder image can leave room for two workgroups (ml.tree: 74 KiB), is compiled for 8; at 92 SGPRs it ran one
 // workgroup per CU and ml.tree at 2.0e10 pairs/s instead of 2.85e10)
+constexpr int kLadderChunk = 128;      // pairs a wave takes per visit to its work counter (two passes of 64)
+
+// One pair of the scalar ladder kernel (valid ids): records, meeting node, both climbs.
+template <int CAP>
+__device__ __forceinline__ PairResult ladder_pair(const CanopyParams &P, const unsigned char *lds_raw, long long a, long long b,
+                                                  bool parity, int rec_bytes)
+{
+    const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+    PairRecs<CAP> L;
+    L.rb = P.rec_b + sb * (rec_bytes / 2);
+    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+    L.wa = va.x;
+    L.pbot_a = __uint_as_float(va.y);
+    load_rec_b_lazy<CAP>(L);
+    const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
+    const uint32_t meet = (P.rmq && pa != pb) ? canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb) : 0xFFFFFFFFu;
+    return canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, meet);
+}
+
+// `work`: NULL = pairs are dealt statically (workgroup b takes tiles b, b + G, ...), else eight counters (one per XCD,
+// zeroed before the launch) from which every WAVE draws chunks of kLadderChunk pairs: the kernel sorts nothing, a wave
+// is as slow as its longest lane, and with a static deal the launch ends when the unluckiest wave does -- with 19 tiles
+// per wave (1e7 pairs) that tail is a quarter of the run.  XCD x owns the x-th eighth of the batch (its waves draw from
+// counter x first, then help the next XCDs), so one counter sees an eighth of the requests.
 template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_ladder(CanopyParams P, Src src, long long n,
-                                                                DistSink out_d, MrcaSink out_m, Fault *fault)
+                                                                DistSink out_d, MrcaSink out_m, Fault *fault,
+                                                                unsigned long long *work)
 {
     static_assert(CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63, "long chains in registers, or (0) through a pointer");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     stage_ladder(P, lds_raw);
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const bool parity = P.parity != 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {
-        const long long i = base + threadIdx.x;
+    auto one = [&](long long i) {      // (converged: the whole wave, consecutive pair numbers)
         const bool live = i < n;
         PairResult r;
         r.dist = __builtin_nanf("");
@@ -261,22 +284,33 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
         if (live) {
             long long a, b;
             src.load(i, a, b);
-            if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes) {
+            if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes)
                 record_fault(fault, a, b, P.n_nodes);
-            } else {
-                const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
-                PairRecs<CAP> L;
-                L.rb = P.rec_b + sb * (rec_bytes / 2);
-                const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-                L.wa = va.x;
-                L.pbot_a = __uint_as_float(va.y);
-                load_rec_b_lazy<CAP>(L);
-                const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
-                const uint32_t meet = (P.rmq && pa != pb) ? canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb) : 0xFFFFFFFFu;
-                r = canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, meet);
-            }
+            else
+                r = ladder_pair<CAP>(P, lds_raw, a, b, parity, rec_bytes);
         }
         store_result_wave(out_d, out_m, i, r.dist, r.mrca, live);
+    };
+    if (!work) {
+        const long long stride = (long long)gridDim.x * blockDim.x;
+        for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) one(base + threadIdx.x);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned xcd = __builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & 7u;      // HW_REG_XCC_ID
+    const long long chunks = (n + kLadderChunk - 1) / kLadderChunk;
+    for (unsigned turn = 0; turn < 8; turn++) {
+        const unsigned x = (xcd + turn) & 7u;
+        const long long first = chunks * x / 8, last = chunks * (x + 1) / 8;      // this counter's chunks
+        for (;;) {
+            unsigned long long c = 0;
+            if (lane == 0) c = atomicAdd(&work[x * 8], 1ull);      // (counters 64 bytes apart)
+            c = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)c) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(c >> 32)) << 32);
+            if ((long long)c >= last - first) break;
+            const long long base = (first + (long long)c) * kLadderChunk;
+#pragma unroll 1
+            for (int j = 0; j < kLadderChunk / 64; j++) one(base + j * 64 + lane);
+        }
     }
 }
 

@@ -43,6 +43,33 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     return hipGetLastError();
 }
 
+// k_canopy_ladder: batches of kLadderDynamicMin pairs and more draw their work from counters (a slot of the handle's
+// ring, zeroed on the stream in front of the launch); smaller ones are dealt statically (no second enqueue).
+constexpr int64_t kLadderDynamicMin = (int64_t)1 << 20;
+template <int CAP, typename Src>
+static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
+                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
+{
+    const size_t lds = ladder_image_bytes(t->canopy_nodes);
+    auto kern = k_canopy_ladder<CAP, Src>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int wg_per_cu = (lds <= 80 * 1024 && CAP == 15) ? 2 : 1;      // (the short-record form is compiled for 8 waves per SIMD)
+    int64_t blocks = std::min<int64_t>((n + kCanopyBlock - 1) / kCanopyBlock, (int64_t)t->n_cu * wg_per_cu);
+    blocks = std::max<int64_t>(blocks, 1);
+    unsigned long long *work = nullptr;
+    if (t->d_work && t->ladder_dynamic && n >= kLadderDynamicMin) {
+        const unsigned slot = t->work_next.fetch_add(1, std::memory_order_relaxed) % kWorkSlots;
+        work = t->d_work + (size_t)slot * 64;      // eight counters, 64 bytes apart
+        const hipError_t e = hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), stream);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, work);
+    return hipGetLastError();
+}
+
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                   DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
@@ -51,7 +78,7 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     // records of more than 512 bytes: every batch the family takes -- nothing else reads them well)
     if constexpr (CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63) {
         if ((out_d.any() && ladder_applies(t, n)) || (t->rec_bytes > 512 && t->ladder_scalar && ladder_tables_ready(t)))
-            return launch_canopy_k(k_canopy_ladder<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream, ladder_image_bytes(t->canopy_nodes));
+            return launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream);
     }
     // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
     if (t->tile_sort && sorted_q(t) > 0)

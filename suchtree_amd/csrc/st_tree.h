@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <vector>
@@ -18,6 +19,8 @@ using st::Fault;
 using st::LadderEntry;
 using st::Node8;
 using st::Stride3;
+
+constexpr unsigned kWorkSlots = 64;      // work-counter slots of a handle (k_canopy_ladder): launches in flight at once never come near
 
 struct st_tree {
     int device = 0;
@@ -59,6 +62,9 @@ struct st_tree {
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
     int ladder_scalar = 0;    // tuning: 1 = distance batches of >= ladder_min_pairs pairs on records of 128 bytes and more go to k_canopy_ladder: the scalar kernel over the ladder image, meeting nodes from the sparse table (set when the tree is created: timed)
+    int ladder_dynamic = 1;   // tuning: 0 = the scalar ladder kernel deals its pairs statically whatever the batch size
+    unsigned long long *d_work = nullptr;          // kWorkSlots x 64 counters (eight used per launch, 64 bytes apart)
+    mutable std::atomic<unsigned> work_next{0};
     int64_t ladder_min_pairs = 0;   // smallest batch of that kernel; 0 = kLadderMinPairs (set when the tree is created: timed at two batch sizes)
     int prefer_walk_sorted = 0;   // large distance batches of a canopy-strategy tree go to k_walk_sorted (set when the tree is created: timed, or by rule)
     int wire48 = 1;           // tuning: 0 = host-path ids always cross the link as int32 (8 bytes per pair), also on trees of fewer than 2^24 nodes

@@ -314,6 +314,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_crown_rmq);
         (void)hipFree(t->d_crown_ladder);
         (void)hipFree(t->d_fault);
+        (void)hipFree(t->d_work);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
         (void)hipFree(t->d_fault_mb);
@@ -374,6 +375,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "ladder_scalar") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_scalar must be 0 or 1");
         t->ladder_scalar = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "ladder_dynamic") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_dynamic must be 0 or 1");
+        t->ladder_dynamic = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "ladder_min_pairs") == 0) {
