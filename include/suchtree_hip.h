@@ -325,6 +325,8 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "ladder_scalar": 1 = distance batches of at least "ladder_min_pairs" pairs (0 = 131072) on records of 128 bytes and
  * more are served by the scalar kernel over the ladder form of the canopy (records read once, no sort: large batches);
  * both defaults are set with the three above when a deep tree is created (timed at two batch sizes).
+ * "ladder_dynamic": 1 (default) = on records of 512 bytes and more, batches of 2^22 pairs and more (2^21 on 1 KB
+ * records) of that kernel draw their work from per-XCD counters instead of a static deal; 0 = never; 2 = always.
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
  * "sort_tile": tile of both tile-sorted kernels in units of 1024 pairs: 1, 2 or 4 (taken when it fits LDS and the
  * kernel's form has that tile), 0 (default) = the largest tile LDS admits, cut finer for batches that would

@@ -263,9 +263,11 @@ __device__ __forceinline__ PairResult ladder_pair(const CanopyParams &P, const u
 
 // `work`: NULL = pairs are dealt statically (workgroup b takes tiles b, b + G, ...), else eight counters (one per XCD,
 // zeroed before the launch) from which every WAVE draws chunks of kLadderChunk pairs: the kernel sorts nothing, a wave
-// is as slow as its longest lane, and with a static deal the launch ends when the unluckiest wave does -- with 19 tiles
-// per wave (1e7 pairs) that tail is a quarter of the run.  XCD x owns the x-th eighth of the batch (its waves draw from
-// counter x first, then help the next XCDs), so one counter sees an eighth of the requests.
+// is as slow as its longest lane, and with a static deal the launch ends when the unluckiest wave does.  XCD x owns
+// the x-th eighth of the batch (its waves draw from counter x first, then help the next XCDs), so one counter sees an
+// eighth of the requests.  Pays where a pair is heavy (profiles/ladder_dynamic_r04.log, 1e7 pairs: 1e6 leaves at depth
+// 338, 1 KB records 8.45e9 -> 9.46e9 pairs/s; depth 173, 512-byte records 1.68 -> 1.77e10; nj.tree even; ml.tree
+// 2.73 -> 2.53e10: a draw's round trip is as long as its 128 pairs): launch_canopy.hip turns it on by record size.
 template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_ladder(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, MrcaSink out_m, Fault *fault,
@@ -299,14 +301,27 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
     const int lane = threadIdx.x & 63;
     const unsigned xcd = __builtin_amdgcn_s_getreg(20 | ((4 - 1) << 11)) & 7u;      // HW_REG_XCC_ID
     const long long chunks = (n + kLadderChunk - 1) / kLadderChunk;
+    // which counters this workgroup has seen run dry: one failed draw per counter and WORKGROUP instead of one per
+    // wave (the 57,000 failing draws of 8192 waves at the end of a launch took 0.1-0.2 ms; a plain load of the counter
+    // before every draw is worse still -- 5e9 pairs/s flat: loads and atomics of all waves queue on one line)
+    __shared__ unsigned dry[8];
+    if (threadIdx.x < 8) dry[threadIdx.x] = 0;
+    __syncthreads();
     for (unsigned turn = 0; turn < 8; turn++) {
         const unsigned x = (xcd + turn) & 7u;
         const long long first = chunks * x / 8, last = chunks * (x + 1) / 8;      // this counter's chunks
+        const unsigned long long count = (unsigned long long)(last - first);
+        // (drawing the next chunk while this one is computed measured no better: the extra draw every wave then wastes
+        // at the end costs what the hidden round trips save)
         for (;;) {
-            unsigned long long c = 0;
-            if (lane == 0) c = atomicAdd(&work[x * 8], 1ull);      // (counters 64 bytes apart)
-            c = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(unsigned)c) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(c >> 32)) << 32);
-            if ((long long)c >= last - first) break;
+            unsigned long long c = ~0ull;
+            if (lane == 0 && !reinterpret_cast<volatile unsigned *>(dry)[x]) {
+                c = atomicAdd(&work[x * 8], 1ull);      // (counters 64 bytes apart)
+                if (c >= count) reinterpret_cast<volatile unsigned *>(dry)[x] = 1;
+            }
+            c = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)c) |
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(c >> 32)) << 32);
+            if (c >= count) break;      // (also the "nothing drawn" value ~0)
             const long long base = (first + (long long)c) * kLadderChunk;
 #pragma unroll 1
             for (int j = 0; j < kLadderChunk / 64; j++) one(base + j * 64 + lane);

@@ -43,9 +43,9 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
     return hipGetLastError();
 }
 
-// k_canopy_ladder: batches of kLadderDynamicMin pairs and more draw their work from counters (a slot of the handle's
-// ring, zeroed on the stream in front of the launch); smaller ones are dealt statically (no second enqueue).
-constexpr int64_t kLadderDynamicMin = (int64_t)1 << 20;
+// k_canopy_ladder: on long records batches of kLadderDynamicMin pairs and more draw their work from counters (a slot of
+// the handle's ring, zeroed on the stream in front of the launch); everything else is dealt statically.
+constexpr int64_t kLadderDynamicMin = (int64_t)1 << 22;      // (records of 512 bytes and more; 1 KB records: half of it)
 template <int CAP, typename Src>
 static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                        DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
@@ -60,7 +60,8 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
     int64_t blocks = std::min<int64_t>((n + kCanopyBlock - 1) / kCanopyBlock, (int64_t)t->n_cu * wg_per_cu);
     blocks = std::max<int64_t>(blocks, 1);
     unsigned long long *work = nullptr;
-    if (t->d_work && t->ladder_dynamic && n >= kLadderDynamicMin) {
+    if (t->d_work && (t->ladder_dynamic == 2 ||      // (2: whatever the records and the batch -- measurements)
+                      (t->ladder_dynamic == 1 && t->rec_bytes >= 512 && n >= (t->rec_bytes > 512 ? kLadderDynamicMin / 2 : kLadderDynamicMin)))) {
         const unsigned slot = t->work_next.fetch_add(1, std::memory_order_relaxed) % kWorkSlots;
         work = t->d_work + (size_t)slot * 64;      // eight counters, 64 bytes apart
         const hipError_t e = hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), stream);
