@@ -38,8 +38,8 @@ def main():
         settings = [("", {}), ("", {}), ("", {"ST_TRACE_WIRE24": "0"}),
                     ("taskset -c " + cpus[gpu_node], {}), ("taskset -c " + cpus[other], {}),
                     ("", {"SUCHTREE_AMD_PIPE_SKIP_CPU": "1"}), ("", {"SUCHTREE_AMD_PIPE_SKIP_GPU": "1"}),
-                    ("", {"SUCHTREE_AMD_PACK_CACHED": "1"}), ("", {"SUCHTREE_AMD_PACK_CACHED": "1"}), ("", {}),
-                    ("", {"SUCHTREE_AMD_COPY_THREADS": "24"})]
+                    ("", {"SUCHTREE_AMD_H2D_ENGINE": "1"}), ("", {}), ("", {"SUCHTREE_AMD_H2D_ENGINE": "1"}), ("", {}),
+                    ("", {"SUCHTREE_AMD_H2D_ENGINE": "1", "SUCHTREE_AMD_PIPE_SKIP_CPU": "1"})]
         for prefix, extra in settings:
             env = dict(os.environ, **extra)
             cmd = (prefix.split() if prefix else []) + [sys.executable, os.path.abspath(__file__), str(n), "--child"]

@@ -234,7 +234,20 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
             else if (out.wire24) mrca.m24 = static_cast<unsigned char *>(s.h_m);
             else mrca.m32 = static_cast<int32_t *>(s.h_m);
         }
-        return enqueue_src(r, make_src(s.h_in), m, sink, mrca, r->d_fault_host, s.stream, false);
+        // The chunk's packed pairs come in through the copy engine into a device copy of the slot (the kernel reads them
+        // there; its results still go straight to the pinned slot): the way in then runs at the engine's rate beside the
+        // kernels of the other slots instead of at what 16 waves per CU keep in flight over the link -- link side alone
+        // 5.87 -> 6.50e9 pairs/s (both outputs), whole calls: distances alone +8 % (6.1-6.4 -> 6.6-7.1e9), both outputs
+        // even (the CPU passes bind there).  SUCHTREE_AMD_H2D_ENGINE=0: the kernel reads the pinned slot itself.
+        static const bool h2d_engine = !(std::getenv("SUCHTREE_AMD_H2D_ENGINE") && std::getenv("SUCHTREE_AMD_H2D_ENGINE")[0] == '0');
+        const void *in = s.h_in;
+        if (h2d_engine && in_bytes_per_pair) {
+            hipError_t e = r->dp->pipe.ensure_device_in();
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * in_bytes_per_pair, hipMemcpyHostToDevice, s.stream);
+            if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
+            in = s.d_in;
+        }
+        return enqueue_src(r, make_src(in), m, sink, mrca, r->d_fault_host, s.stream, false);
     }
     // Pairs come in through the copy engine, results go out through copy kernels: the two
     // directions then overlap and the engine takes no CUs from the tile-sorted kernel (ml.tree,
