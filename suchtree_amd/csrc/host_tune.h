@@ -37,7 +37,6 @@ static void rule_for_deep_tree(st_tree *t)
     if (t->rec_cap > 31 || sorted_q(t) <= 0) { t->pairs_per_lane = 1; t->tile_sort = 0; }
     t->prefer_walk_sorted = walk_sorted_by_rule(t) ? 1 : 0;
     t->ladder_scalar = t->rec_bytes > kMaxRecordBytes ? 1 : 0;      // (1 KB records: no other canopy kernel reads them well)
-    t->ladder_sums = 0;
 }
 
 // ---- persistent record of what a tree measured -------------------------------------------------------------
@@ -72,21 +71,21 @@ static std::string tune_cache_path(const st_tree *t, const TreeTables &T, const 
     return dir + name;
 }
 
-static bool tune_cache_read(const std::string &path, int &tile_sort, int &ppl, int &walk, int &ladder, long long &ladder_min, int &ladder_sums)
+static bool tune_cache_read(const std::string &path, int &tile_sort, int &ppl, int &walk, int &ladder, long long &ladder_min)
 {
     if (path.empty()) return false;
     FILE *f = std::fopen(path.c_str(), "r");
     if (!f) return false;
-    int a = -1, b = -1, c = -1, d = -1, g = -1;
+    int a = -1, b = -1, c = -1, d = -1;
     long long e = -1;
-    const int got = std::fscanf(f, "%d %d %d %d %lld %d", &a, &b, &c, &d, &e, &g);
+    const int got = std::fscanf(f, "%d %d %d %d %lld", &a, &b, &c, &d, &e);
     std::fclose(f);
-    if (got != 6 || (a != 0 && a != 1) || b < 0 || b > 2 || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0 || (g != 0 && g != 1)) return false;
-    tile_sort = a; ppl = b; walk = c; ladder = d; ladder_min = e; ladder_sums = g;
+    if (got != 5 || (a != 0 && a != 1) || b < 0 || b > 2 || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0) return false;
+    tile_sort = a; ppl = b; walk = c; ladder = d; ladder_min = e;
     return true;
 }
 
-static void tune_cache_write(const std::string &path, int tile_sort, int ppl, int walk, int ladder, long long ladder_min, int ladder_sums)
+static void tune_cache_write(const std::string &path, int tile_sort, int ppl, int walk, int ladder, long long ladder_min)
 {
     if (path.empty()) return;
     const size_t slash = path.rfind('/');
@@ -96,7 +95,7 @@ static void tune_cache_write(const std::string &path, int tile_sort, int ppl, in
     const std::string tmp = path + ".tmp." + std::to_string((long long)::getpid());
     FILE *f = std::fopen(tmp.c_str(), "w");
     if (!f) return;
-    std::fprintf(f, "%d %d %d %d %lld %d\n", tile_sort, ppl, walk, ladder, ladder_min, ladder_sums);
+    std::fprintf(f, "%d %d %d %d %lld\n", tile_sort, ppl, walk, ladder, ladder_min);
     std::fclose(f);
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
@@ -112,7 +111,6 @@ static void copy_tuned_settings(st_tree *to, const st_tree *from)
     to->prefer_walk_sorted = from->prefer_walk_sorted;
     to->ladder_scalar = from->ladder_scalar;
     to->ladder_min_pairs = from->ladder_min_pairs;
-    to->ladder_sums = from->ladder_sums;
     to->info.tuned = from->info.tuned;
 }
 
@@ -123,15 +121,14 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         if (env[0] == '0') return;
     const std::string cache = tune_cache_path(t, T, device_name);
     {
-        int a, b, c, d, g;
+        int a, b, c, d;
         long long e;
-        if (tune_cache_read(cache, a, b, c, d, e, g)) {
+        if (tune_cache_read(cache, a, b, c, d, e)) {
             // (a recorded choice the handle cannot serve -- other table budget, other options -- is ignored)
             const int keep_sort = t->tile_sort, keep_ppl = t->pairs_per_lane, keep_walk = t->prefer_walk_sorted, keep_ladder = t->ladder_scalar;
             t->tile_sort = a; t->pairs_per_lane = b; t->prefer_walk_sorted = c; t->ladder_scalar = 0;
-            const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_tables_ready(t)) &&
-                            (!g || (t->d_rec_p && t->d_rmq64 && t->d_lineage && t->d_cpos));
-            if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->ladder_sums = g; t->info.tuned = 2; return; }
+            const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_tables_ready(t));
+            if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->info.tuned = 2; return; }
             t->tile_sort = keep_sort; t->pairs_per_lane = keep_ppl; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = keep_ladder;
         }
     }
@@ -171,12 +168,11 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     }
     // milliseconds of the fastest of three launches of m pairs after one warm-up, or a negative number
-    auto time_settings = [&](int tile_sort, int ppl, int walk, int ladder, int sums, int64_t m) -> float {
+    auto time_settings = [&](int tile_sort, int ppl, int walk, int ladder, int64_t m) -> float {
         t->tile_sort = tile_sort;
         t->pairs_per_lane = ppl;
         t->prefer_walk_sorted = walk;
         t->ladder_scalar = ladder;
-        t->ladder_sums = sums;
         t->ladder_min_pairs = 0;
         float best = -1.0f;
         for (int rep = 0; rep < 4; rep++) {
@@ -194,23 +190,18 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         // Two batch sizes: the whole sample (what bulk callers send) and a quarter of it.  The scalar ladder kernel sorts
         // nothing, so its waves finish unevenly and few tiles per wave leave a long tail: it can win at 2^23 pairs and
         // lose at 2^21 (launch_policy.h) -- then it only takes the batches beyond the size in between.
-        struct Cand { int sort, ppl, walk, ladder, sums; float ms, ms_small; };
+        struct Cand { int sort, ppl, walk, ladder; float ms, ms_small; };
         const int64_t n_small = n / 4;
         std::vector<Cand> cands;
         t->ladder_scalar = 0;
-        if (sorted_q(t) > 0) cands.push_back({1, 0, 0, 0, 0, -1.0f, -1.0f});
-        cands.push_back({0, 1, 0, 0, 0, -1.0f, -1.0f});
-        if (ladder_tables_ready(t)) {
-            cands.push_back({0, 1, 0, 1, 0, -1.0f, -1.0f});
-            t->ladder_sums = 1;
-            if (ladder_sums_ready(t)) cands.push_back({0, 1, 0, 1, 1, -1.0f, -1.0f});      // a's side from the lineage sums
-            t->ladder_sums = 0;
-        }
+        if (sorted_q(t) > 0) cands.push_back({1, 0, 0, 0, -1.0f, -1.0f});
+        cands.push_back({0, 1, 0, 0, -1.0f, -1.0f});
+        if (ladder_tables_ready(t)) cands.push_back({0, 1, 0, 1, -1.0f, -1.0f});
         t->prefer_walk_sorted = 1;
-        if (prefers_walk_sorted(t, n_small, true)) cands.push_back({rule_sort, rule_ppl, 1, 0, 0, -1.0f, -1.0f});
+        if (prefers_walk_sorted(t, n_small, true)) cands.push_back({rule_sort, rule_ppl, 1, 0, -1.0f, -1.0f});
         for (Cand &c : cands) {
-            c.ms = time_settings(c.sort, c.ppl, c.walk, c.ladder, c.sums, n);
-            c.ms_small = time_settings(c.sort, c.ppl, c.walk, c.ladder, c.sums, n_small);
+            c.ms = time_settings(c.sort, c.ppl, c.walk, c.ladder, n);
+            c.ms_small = time_settings(c.sort, c.ppl, c.walk, c.ladder, n_small);
         }
         const Cand *best = nullptr, *rule = nullptr, *base = nullptr, *base_small = nullptr;
         for (const Cand &c : cands) {
@@ -219,7 +210,7 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
             if (!c.ladder && (!base || c.ms < base->ms)) base = &c;                            // fastest without the ladder kernel, whole sample ...
             if (!c.ladder && (!base_small || c.ms_small < base_small->ms_small)) base_small = &c;   // ... and at the smaller size
             // the rule's choice among the candidates (with the walk kernel chosen, the canopy settings behind it do not matter)
-            if (c.walk == rule_walk && !c.sums && (c.walk || (c.ladder == rule_ladder && c.sort == rule_sort && c.ppl == rule_ppl))) rule = &c;
+            if (c.walk == rule_walk && (c.walk || (c.ladder == rule_ladder && c.sort == rule_sort && c.ppl == rule_ppl))) rule = &c;
         }
         if (best && rule && best != rule && best->ms > kTuneMargin * rule->ms) best = rule;      // too close to call: the rule stands
         if (best) {
@@ -234,18 +225,16 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
             t->pairs_per_lane = canopy ? canopy->ppl : rule_ppl;
             t->prefer_walk_sorted = other && other->walk ? 1 : 0;
             t->ladder_scalar = best->ladder;
-            t->ladder_sums = best->ladder ? best->sums : 0;
             t->ladder_min_pairs = 0;
             if (best->ladder && base_small && best->ms_small > kTuneMargin * base_small->ms_small) t->ladder_min_pairs = n / 2;
             if (t->rec_bytes > kMaxRecordBytes) t->ladder_scalar = 1;      // (1 KB records: the family's other kernels read them through a pointer, far slower)
             t->info.tuned = 1;
-            tune_cache_write(cache, t->tile_sort, t->pairs_per_lane, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs, t->ladder_sums);
+            tune_cache_write(cache, t->tile_sort, t->pairs_per_lane, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs);
         } else {
             t->tile_sort = rule_sort;
             t->pairs_per_lane = rule_ppl;
             t->prefer_walk_sorted = rule_walk;
             t->ladder_scalar = rule_ladder;
-            t->ladder_sums = 0;
             t->ladder_min_pairs = 0;
         }
     } else {

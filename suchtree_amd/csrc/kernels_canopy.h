@@ -245,45 +245,20 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
 constexpr int kLadderChunk = 128;      // pairs a wave takes per visit to its work counter (two passes of 64)
 
 // One pair of the scalar ladder kernel (valid ids): records, meeting node, both climbs.
-// SUMS (deep canopies with in-order ids and a lineage-sum table): a's whole side is ONE read -- rec_p[a] gives the rank
-// of a's portal, a's depth and the offset of its lineage sums; the meeting node (depth << 32 | node id: the MRCA id
-// itself) comes from the two ranks in the 64-bit sparse table; lineage[off + depth(a) - depth(meet)] is the
-// reference's accumulator after a's edges -- so only b's side climbs in LDS: half the dependent LDS reads of a pair
-// and no canopy_id lookup at the end, for one more gather (51 MB table on ml.tree: Infinity Cache).
-template <int CAP, bool SUMS>
+template <int CAP>
 __device__ __forceinline__ PairResult ladder_pair(const CanopyParams &P, const unsigned char *lds_raw, long long a, long long b,
                                                   bool parity, int rec_bytes)
 {
     const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
     PairRecs<CAP> L;
     L.rb = P.rec_b + sb * (rec_bytes / 2);
-    if constexpr (SUMS) {
-        const uint2 pa_rec = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
-        load_rec_b_lazy<CAP>(L);
-        const uint32_t pb = L.wb & 0xFFFFu;
-        const uint32_t ra = pa_rec.x & 0xFFFFu, rb = P.cpos[pb];
-        if (ra != rb) {
-            const uint64_t e = canopy_meet_ranks64(P.rmq64, P.canopy_nodes, ra, rb);
-            const uint32_t dm = (uint32_t)(e >> 32);
-            const float s_a = P.lineage[(size_t)(pa_rec.y & 0x0FFFFFFFu) + ((pa_rec.x >> 16) - dm)];
-            PairResult r;
-            r.dist = ladder_sum_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), (uint32_t)P.cdepth[pb] - dm, s_a, pb, L.chain(), L.wb >> 16);
-            r.mrca = (int32_t)(uint32_t)e;
-            return r;
-        }
-        const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];      // shared portal (rare): the general form
-        L.wa = va.x;
-        L.pbot_a = __uint_as_float(va.y);
-        return canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, 0xFFFFFFFFu);
-    } else {
-        const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
-        L.wa = va.x;
-        L.pbot_a = __uint_as_float(va.y);
-        load_rec_b_lazy<CAP>(L);
-        const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
-        const uint32_t meet = (P.rmq && pa != pb) ? canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb) : 0xFFFFFFFFu;
-        return canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, meet);
-    }
+    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa];
+    L.wa = va.x;
+    L.pbot_a = __uint_as_float(va.y);
+    load_rec_b_lazy<CAP>(L);
+    const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
+    const uint32_t meet = (P.rmq && pa != pb) ? canopy_meet(P.cpos, P.rmq, P.canopy_nodes, pa, pb) : 0xFFFFFFFFu;
+    return canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, meet);
 }
 
 // `work`: NULL = pairs are dealt statically (workgroup b takes tiles b, b + G, ...), else eight counters (one per XCD,
@@ -293,7 +268,7 @@ __device__ __forceinline__ PairResult ladder_pair(const CanopyParams &P, const u
 // eighth of the requests.  Pays where a pair is heavy (profiles/ladder_dynamic_r04.log, 1e7 pairs: 1e6 leaves at depth
 // 338, 1 KB records 8.45e9 -> 9.46e9 pairs/s; depth 173, 512-byte records 1.68 -> 1.77e10; nj.tree even; ml.tree
 // 2.73 -> 2.53e10: a draw's round trip is as long as its 128 pairs): launch_canopy.hip turns it on by record size.
-template <int CAP, typename Src, bool SUMS = false>
+template <int CAP, typename Src>
 __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_ladder(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, MrcaSink out_m, Fault *fault,
                                                                 unsigned long long *work)
@@ -314,7 +289,7 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
             if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes)
                 record_fault(fault, a, b, P.n_nodes);
             else
-                r = ladder_pair<CAP, SUMS>(P, lds_raw, a, b, parity, rec_bytes);
+                r = ladder_pair<CAP>(P, lds_raw, a, b, parity, rec_bytes);
         }
         store_result_wave(out_d, out_m, i, r.dist, r.mrca, live);
     };

@@ -51,12 +51,7 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
                                        DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
     const size_t lds = ladder_image_bytes(t->canopy_nodes);
-    // the lineage-sum form (a's side in one read): deep canopies with in-order ids whose lineage table was built, on by
-    // the handle's own timing (option ladder_sums); chains in registers only
-    auto kern = k_canopy_ladder<CAP, Src, false>;
-    if constexpr (CAP == 15 || CAP == 31 || CAP == 63) {
-        if (ladder_sums_ready(t)) kern = k_canopy_ladder<CAP, Src, true>;
-    }
+    auto kern = k_canopy_ladder<CAP, Src>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -94,11 +94,6 @@ static inline bool ladder_applies(const st_tree *t, int64_t n)
     return t->ladder_scalar && n >= std::max<int64_t>(t->ladder_min_pairs, kLadderMinPairs) && ladder_tables_ready(t);
 }
 static inline bool ladder_scalar_ready(const st_tree *t) { return ladder_applies(t, (int64_t)1 << 40); }
-// its lineage-sum form: a's side from the lineage table (rec_p, rmq64, lineage sums: deep canopies with in-order ids)
-static inline bool ladder_sums_ready(const st_tree *t)
-{
-    return t->ladder_sums && t->lineage_sums && t->d_rec_p && t->d_rmq64 && t->d_lineage && t->d_cpos && t->rec_cap <= 63;
-}
 
 // Smallest batch the canopy kernels take: 4096 pairs -- or, on deep trees whose heavy kernels (tile-sorted, scalar
 // ladder) have a fixed cost of 15-30 us and whose walk kernel has a's side in one read (lineage sums by node id),

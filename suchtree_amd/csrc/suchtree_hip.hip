@@ -377,11 +377,6 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->ladder_scalar = (int)value;
         return ST_OK;
     }
-    if (std::strcmp(name, "ladder_sums") == 0) {
-        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_sums must be 0 or 1");
-        t->ladder_sums = (int)value;
-        return ST_OK;
-    }
     if (std::strcmp(name, "ladder_dynamic") == 0) {
         if (value != 0 && value != 1 && value != 2) return fail(ST_ERR_ARG, "ladder_dynamic must be 0, 1 or 2");
         t->ladder_dynamic = (int)value;

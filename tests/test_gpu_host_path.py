@@ -194,10 +194,9 @@ def test_24_bit_mrca_ids_on_the_way_back(tree17, ml_arrays):
     from conftest import oracle_both
     want_d, want_m = oracle_both(ml_parent, ml_dist, pairs[:k])
     dev = _capi.DeviceTree(ml_parent, ml_dist)
-    base = {"tile_sort": 1, "pairs_per_lane": 0, "ladder_scalar": 0, "ladder_sums": 0, "ladder_min_pairs": 0, "prefer_walk_sorted": 0, "lineage_sums": 1}
+    base = {"tile_sort": 1, "pairs_per_lane": 0, "ladder_scalar": 0, "prefer_walk_sorted": 0, "lineage_sums": 1}
     for opts in ({}, {"lineage_sums": 0}, {"tile_sort": 0, "pairs_per_lane": 1}, {"tile_sort": 0, "pairs_per_lane": 0},
-                 {"tile_sort": 0, "pairs_per_lane": 1, "ladder_scalar": 1}, {"tile_sort": 0, "pairs_per_lane": 1, "ladder_scalar": 1, "ladder_sums": 1},
-                 {"prefer_walk_sorted": 1}):
+                 {"tile_sort": 0, "pairs_per_lane": 1, "ladder_scalar": 1}, {"prefer_walk_sorted": 1}):
         for name, v in dict(base, **opts).items():      # (every kernel by name: what the handle chose itself does not matter here)
             dev.set_option(name, v)
         check(dev, pairs, want_d, want_m, "ml.tree %s" % (opts or "tile-sorted canopy kernel"))

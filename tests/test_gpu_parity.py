@@ -610,20 +610,18 @@ def test_every_candidate_kernel_on_nj_tree(nj_arrays):
     dev = _capi.DeviceTree(parent, dist)
     assert dev.info()["record_bytes"] == 256
     seen = set()
-    dev.set_option("ladder_min_pairs", 0)
-    for sort, ppl, walk, ladder, sums in ((1, 0, 0, 0, 0), (0, 1, 0, 0, 0), (0, 0, 0, 0, 0), (1, 0, 1, 0, 0), (0, 1, 0, 1, 0), (0, 1, 0, 1, 1)):
+    for sort, ppl, walk, ladder in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 1, 0), (0, 1, 0, 1)):
         dev.set_option("tile_sort", sort)
         dev.set_option("pairs_per_lane", ppl)
         dev.set_option("prefer_walk_sorted", walk)
         dev.set_option("ladder_scalar", ladder)
-        dev.set_option("ladder_sums", sums)      # (a's side from the lineage sums instead of a climb)
         kernel = dev.info()["big_batch_kernel"]
         seen.add(kernel)
         out_d.fill_(-1.0)
         out_m.fill_(-1)
         dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
         dev.fault_check()
-        assert_bits_equal(out_d.cpu().numpy(), want_d, kernel + " sums=%d" % sums)
+        assert_bits_equal(out_d.cpu().numpy(), want_d, kernel)
         assert np.array_equal(out_m.cpu().numpy(), want_m), kernel
         d, m = dev.distances_host(allp, True, True)      # (packed ids on the way back)
         assert_bits_equal(d, want_d, "host path, " + kernel)

@@ -48,7 +48,7 @@ def test_register_budgets_of_the_canopy_kernels(tmp_path):
 
     # two 1024-lane workgroups per CU (canopy / ladder images of at most 80 KiB) are 8 waves per SIMD: at most 64
     # VGPRs and at most 80 SGPRs (the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD)
-    for frag in ("k_canopy_ilpILi7ELi1E", "k_canopy_ilpILi3ELi1E", "k_canopy_ilpILi1ELi1E", "k_canopy_ladderILi15E"):      # (both forms of the ladder kernel: climbed a side / lineage sums)
+    for frag in ("k_canopy_ilpILi7ELi1E", "k_canopy_ilpILi3ELi1E", "k_canopy_ilpILi1ELi1E", "k_canopy_ladderILi15E"):
         for k, n in of(frag).items():
             assert n["vgpr"] <= 64 and n["sgpr"] <= 80, (k, n)
     # every kernel of the family is launched with 1024 lanes: at most 128 VGPRs
