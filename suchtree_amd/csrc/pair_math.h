@@ -419,6 +419,7 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
                                   const float *D_b, uint32_t nb_b)
 {
     const uint32_t dm = meet >> 16;
+    const int32_t mrca = canopy_id[meet & 0xFFFFu];      // (asked for first: the read is in flight while both sides climb)
     float s = pbot_a;
     uint32_t k = da - dm;
     uint32_t u = pa;
@@ -454,7 +455,7 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
     }
     PairResult r;
     r.dist = s;
-    r.mrca = canopy_id[meet & 0xFFFFu];
+    r.mrca = mrca;
     return r;
 }
 
