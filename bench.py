@@ -64,6 +64,8 @@ def parse(argv=None):
                     help="N > 1: fraction of the batch rank 0 computes itself: 'auto' (balance its kernels against the "
                          "peers' transfers, from rates measured before the timed region), 'even' (1/N) or a number")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank its own batch, no gather")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="N > 1: CUs rank 0's kernels leave free for RCCL's receive kernels (handle option reserve_cus)")
     ap.add_argument("--wire-int32", action="store_true",
                     help="N > 1: MRCA ids travel as int32 (8 bytes per pair) instead of 24 bits each (7 bytes per pair)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -257,6 +259,8 @@ class HipBackend:
         self.device = torch.device("cuda", local_rank)
         self.stream = torch.cuda.current_stream(self.device)
         self.tree = _capi.DeviceTree(parent, dist, device=local_rank, strategy=args.strategy)
+        if args.reserve_cus and int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+            self.tree.set_option("reserve_cus", args.reserve_cus)
         self.n_leaves = 1 << args.levels
         self._events = []
 

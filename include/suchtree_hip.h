@@ -338,6 +338,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * each (6 bytes per pair instead of 8; the packing step then checks the range and keeps the id to report); 0 = int32.
  * "wire24": 1 (default) = on such trees MRCA ids come back over the link as 24 bits each (7 bytes per pair with the
  * float32 distance instead of 8; assembled by the kernels, widened by the host's unpack pass); 0 = int32.
+ * "reserve_cus": CUs the launches leave to others (default 0): the kernels are persistent workgroups sized to the
+ * device; a rank that receives result slices while it computes (the root of the multi-GPU gather) can leave RCCL's
+ * kernels a few CUs of their own.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe. */

@@ -292,6 +292,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
     t->device = device;
     t->dp = pipe_acquire(device);
     t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    t->n_cu_device = t->n_cu;
     t->n_nodes = T.n;
     t->n_leaves = T.n_leaves;
     int64_t bytes = 0;

@@ -26,7 +26,8 @@ struct st_tree {
     int device = 0;
     int strategy = ST_STRATEGY_WALK;       // family in use
     bool has_canopy = false;
-    int n_cu = 256;
+    int n_cu = 256;           // CUs the launches are sized for (option "reserve_cus": the device's count minus what is left to others)
+    int n_cu_device = 256;
     st_tree_info info{};
     // device tables
     Node8 *d_nodes = nullptr;

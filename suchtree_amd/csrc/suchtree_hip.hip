@@ -377,6 +377,13 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->ladder_scalar = (int)value;
         return ST_OK;
     }
+    if (std::strcmp(name, "reserve_cus") == 0) {
+        // the persistent kernels are sized to the CUs of the device; on a rank that also receives (the root of the
+        // multi-GPU gather) RCCL's kernels need somewhere to run beside a 1024-lane / 144 KiB workgroup per CU
+        if (value < 0 || value >= t->n_cu_device) return fail(ST_ERR_ARG, "reserve_cus must be in [0, CUs of the device)");
+        t->n_cu = t->n_cu_device - (int)value;
+        return ST_OK;
+    }
     if (std::strcmp(name, "ladder_dynamic") == 0) {
         if (value != 0 && value != 1 && value != 2) return fail(ST_ERR_ARG, "ladder_dynamic must be 0, 1 or 2");
         t->ladder_dynamic = (int)value;
