@@ -26,7 +26,10 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_gpu_parity import _random_shape_tree
     trees.append(_random_shape_tree(np.random.default_rng(7), 120_000, 0.97))      # only the walk family serves it
-    devs = [_capi.DeviceTree(p, d) for p, d in trees]
+    trees.append(_random_shape_tree(np.random.default_rng(5), 200_000, 0.9))       # 1 KB records (no id chains)
+    trees.append(synth.balanced_tree(15))                                          # under a table budget: no id chains
+    devs = [_capi.DeviceTree(p, d, table_mb=(4.5 if i == 6 else None)) for i, (p, d) in enumerate(trees)]
+    print([(x.info()["strategy"], x.info()["record_bytes"], x.info()["dropped_tables"]) for x in devs], flush=True)
     oracles = [OracleTree(p, d) for p, d in trees]
     stop = time.time() + args.seconds
     errors, counts = [], [0] * args.threads
@@ -38,6 +41,9 @@ def main():
             dev, O, n_nodes = devs[k], oracles[k], len(trees[k][0])
             n = int(10 ** rng.uniform(0, 6.3))
             pairs = rng.integers(0, n_nodes, (n, 2))
+            if rng.random() < 0.35:      # pairs of nearby nodes: one portal (ids follow from another phase / the walk fallback)
+                a = rng.integers(0, max(1, n_nodes - 40), n)
+                pairs = np.stack([a, np.minimum(n_nodes - 1, a + rng.integers(0, 40, n))], 1)
             layout = rng.integers(0, 4)
             if layout == 1:
                 view = np.asfortranarray(pairs)
@@ -63,6 +69,11 @@ def main():
                     dev.set_option("sort_tile", int(rng.choice([0, 0, 1, 2, 4])))
                     dev.set_option("rec_a4", int(rng.integers(0, 2)))
                     dev.set_option("wire48", int(rng.integers(0, 2)))
+                    dev.set_option("wire24", int(rng.random() < 0.8))
+                    if k in (0, 2):
+                        dev.set_option("ladder_scalar", int(rng.integers(0, 2)))
+                        dev.set_option("ladder_min_pairs", int(rng.choice([0, 0, 300000])))
+                        dev.set_option("ladder_dynamic", int(rng.choice([0, 1, 2])))
                     if k in (0, 4):
                         for name in ("walk_sort", "walk_ladder", "walk_crown", "lineage_lens"):
                             dev.set_option(name, int(rng.random() < 0.8))
