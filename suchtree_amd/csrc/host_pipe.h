@@ -2,23 +2,21 @@
 //
 // Callers of st_distances_host / st_triangle_host own ordinary (pageable) memory, which
 // the HIP runtime copies at ~10 GB/s.  The pipe keeps a few slots of pinned staging memory
-// that the GPU reads and writes DIRECTLY over PCIe (kPipeSlots of them, one stream each)
-// and a pool of copy threads:
+// (kPipeSlots of them, one stream each) and a pool of copy threads:
 //
-//   pack(c)   : caller's pairs  -> pinned (parallel narrowing copy / strided gather)
-//   gpu(c)    : one kernel on the slot's stream that loads its pairs from the pinned slot and
-//               stores its results into the pinned slot; distances travel as float32
-//               (they are float32 sums), MRCA ids as int32
-//   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / copy)
+//   pack(c)   : caller's pairs  -> pinned (parallel narrowing copy / strided gather: 24 bits per id on trees of
+//               fewer than 2^24 nodes, else int32)
+//   gpu(c)    : the packed pairs go to a device copy of the slot through the copy engine; one kernel on the
+//               slot's stream reads them there and stores its results DIRECTLY into the pinned slot over PCIe:
+//               distances as float32 (they are float32 sums), MRCA ids as 24 bits each (or int32)
+//   unpack(c) : pinned -> caller's result arrays (parallel widen to float64 / ids to int32)
 //
-// unpack(c-2) and pack(c+1) run on the CPU while gpu(c-1) and gpu(c) are in flight.
-// On this direct form there are no hipMemcpyAsync calls and no device staging buffers (trees
-// served by the tile-sorted kernel stage their slots in device memory, ensure_device_stage): a kernel that reads 8 B and writes
-// 8 B per lane from / to pinned host memory moves 96 GB/s over the link (both directions at
-// once), the same as one large H2D and one large D2H copy running concurrently, while
-// per-chunk H2D -> kernel -> D2H sequences on two streams fall into lock step (both
-// streams copy in the same direction at the same time) and reach 59 GB/s
-// (scripts/micro/pcie_bench.hip, profiles/pcie_bench_r02.log).
+// unpack(c-2) and pack(c+1) run on the CPU while gpu(c-1) and gpu(c) are in flight.  Why zero-copy on the way back
+// (scripts/micro/pcie_bench.hip, profiles/pcie_bench_r02.log): per-chunk H2D -> kernel -> D2H sequences on two
+// streams fall into lock step (both streams copy in the same direction at the same time) and reach 59 GB/s as the
+// sum of both directions, while a kernel that writes its results to pinned host memory beside another slot's copy
+// in moves both directions at once.  (Trees served by the tile-sorted kernel's non-lineage-sum forms stage their
+// slots in device memory both ways: ensure_device_stage.)
 #pragma once
 #include <hip/hip_runtime.h>
 

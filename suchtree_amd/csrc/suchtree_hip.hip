@@ -10,12 +10,14 @@
 //           folded into one fixed-stride understory record per node (split into an
 //           8-byte a-side table and a b-side table), so a pair costs two record reads
 //           plus an LDS climb instead of ~h dependent global gathers.
-//           k_canopy_ilp     1-2 pairs per lane, predicated (the default)
-//           k_canopy_sorted  deep canopies: ladder form of the canopy (three edges per
-//                            16-byte LDS entry), pairs sorted by climb length within a
-//                            workgroup tile; with in-order ids the meeting node comes from
-//                            a sparse table and a's side from per-node lineage sums
-//           k_canopy         scalar, branchy (records longer than 128 bytes)
+//           k_canopy_ilp     1-2 pairs per lane, predicated (shallow canopies: the default)
+//           k_canopy_ladder  deep canopies, large batches, long records: records read once, chain in
+//                            registers, meeting node from a sparse table, both sides climbed on the
+//                            ladder form of the canopy (three edges per 16-byte LDS entry)
+//           k_canopy_sorted  deep canopies: pairs sorted by climb length within a workgroup tile; with
+//                            in-order ids the meeting node comes from a sparse table and a's side from
+//                            per-node lineage sums
+//           k_canopy         scalar, branchy (pairs_per_lane = 0; records through a pointer)
 //
 // Every kernel is templated on a pair source (SrcContig / SrcContig32 / SrcStrided /
 // SrcTriangle / SrcGrid / SrcQuartet): an explicit (n,2) array, or pairs derived from their
@@ -28,9 +30,10 @@
 // request gets, enqueueing, faults), host_path.h (host-buffer pipeline, mailbox, copy kernels), host_upload.h
 // (tables -> device), kernels_misc.h (k nearest, graph matrices).
 //
-// Host side of the C ABI: tree upload to one or several GPUs (tree_prep.cpp builds the
-// tables), the zero-copy host path (host_pipe.h, host_copy.h: kernels read and write pinned
-// host memory), the small-batch mailbox, fault read-back, k-nearest selection, graph matrices.
+// Host side of the C ABI: tree upload to one or several GPUs (tree_prep.cpp builds the tables, under a table budget
+// if one is given), the host path (host_pipe.h, host_copy.h: packed ids in through the copy engine, kernels write
+// float32 + 24-bit ids straight into pinned host memory), the small-batch mailbox, fault read-back, the creation-time
+// choice of a deep tree's kernels (host_tune.h), k-nearest selection, graph matrices.
 //
 // Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <hip/hip_runtime.h>
