@@ -137,10 +137,10 @@ __device__ __forceinline__ PairResult canopy_pair_finish(const CanopyParams &P, 
     const uint32_t pa = L.wa & 0xFFFFu, pb = L.wb & 0xFFFFu;
     if (pa != pb) {
         if (LADDER) {
-            const LadderEntry *lad = reinterpret_cast<const LadderEntry *>(image);
+            const LdsLadder lad(image);
             if (meet != 0xFFFFFFFFu)      // meeting node known from the sparse table: only the sums remain
                 return pair_ladder_sums<CAP>(lad, P.canopy_id, meet, pa, P.cdepth[pa], L.pbot_a, pb, P.cdepth[pb], L.chain(), L.wb >> 16);
-            return pair_ladder_split<CAP>(lad, P.cdepth, P.canopy_id, pa, L.pbot_a, pb, L.chain(), L.wb >> 16);
+            return pair_ladder_split<CAP>(lad, P.cdepth, P.canopy, P.canopy_id, pa, L.pbot_a, pb, L.chain(), L.wb >> 16);
         }
         return pair_canopy_split<CAP>(reinterpret_cast<const CanopyEntry *>(image), P.canopy_id, pa, L.pbot_a, pb,
                                       L.chain(), L.wb >> 16);
@@ -162,9 +162,7 @@ __device__ __forceinline__ PairResult canopy_pair_scalar(const CanopyParams &P, 
 
 __device__ __forceinline__ void stage_ladder(const CanopyParams &P, unsigned char *lds_raw)
 {
-    uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
-    const uint4 *src_e = reinterpret_cast<const uint4 *>(P.ladder);
-    for (int k = threadIdx.x; k < P.canopy_nodes; k += blockDim.x) dst[k] = src_e[k];
+    stage_ladder_image(lds_raw, P.ladder, P.canopy_nodes);
     __syncthreads();
 }
 
@@ -304,7 +302,8 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
     // which counters this workgroup has seen run dry: one failed draw per counter and WORKGROUP instead of one per
     // wave (the 57,000 failing draws of 8192 waves at the end of a launch took 0.1-0.2 ms; a plain load of the counter
     // before every draw is worse still -- 5e9 pairs/s flat: loads and atomics of all waves queue on one line)
-    __shared__ unsigned dry[8];
+    // (they live behind the image, which then starts at LDS address 0: a masked link IS the address of the next read)
+    unsigned *dry = reinterpret_cast<unsigned *>(lds_raw + (size_t)P.canopy_nodes * sizeof(LadderEntry));
     if (threadIdx.x < 8) dry[threadIdx.x] = 0;
     __syncthreads();
     for (unsigned turn = 0; turn < 8; turn++) {

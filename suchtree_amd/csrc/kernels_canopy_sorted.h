@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kCanopyBlock) void k_canopy_sorted(CanopyParams P, 
                     const uint32_t kb = MEET[j];
                     float dist;
                     if (kb != 0xFFFFFFFFu) {
-                        dist = ladder_sum_b<CAP>(reinterpret_cast<const LadderEntry *>(lds_raw), kb - (cur.wb >> 16), SIDE_A[j],
+                        dist = ladder_sum_b<CAP>(LdsLadder(lds_raw), kb - (cur.wb >> 16), SIDE_A[j],
                                                  cur.wb & 0xFFFFu, cur.chain(), cur.wb >> 16);
                     } else {     // shared portal
                         long long a, b;

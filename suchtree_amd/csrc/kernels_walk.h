@@ -69,12 +69,10 @@ __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Sr
                                                                  MrcaSink out_m, Fault *fault, int key_shift)
 {
     extern __shared__ __align__(16) unsigned char walk_lds_all[];
-    const LadderEntry *LAD = reinterpret_cast<const LadderEntry *>(walk_lds_all);
+    const LdsLadder LAD(walk_lds_all);
     unsigned char *walk_lds = walk_lds_all + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
     if (LADDER) {
-        uint4 *dst = reinterpret_cast<uint4 *>(walk_lds_all);
-        const uint4 *from = reinterpret_cast<const uint4 *>(P.crown_ladder);
-        for (int k = threadIdx.x; k < P.lineage.crown_nodes; k += blockDim.x) dst[k] = from[k];
+        stage_ladder_image(walk_lds_all, P.crown_ladder, P.lineage.crown_nodes);
         __syncthreads();
     }
     constexpr int kTile = Q * kWalkSortBlock;

@@ -159,28 +159,95 @@ ST_HD float stream_b(const LineageView &lin, const NodeKey &kb, float s, int32_t
     return stream_sum(lin.lens + kb.portal_off, s, k - nb);
 }
 
-// The same with the crown part climbed on the crown's ladder (tree_prep.h: crown_ladder, indexed by rank;
-// LDS on the device) instead of streamed: k edges of b's lineage = its first min(k, nb) lineage lengths,
-// then k - nb ladder edges from its portal, three per 16-byte entry, in lineage order.
-template <typename LadPtr>
-ST_HD float stream_b_ladder(const float *__restrict__ lens, LadPtr lad, uint32_t off_b, uint32_t nb, uint32_t portal_rank,
-                            float s, int32_t k)
+// ---- ladder images (tree_prep.h: LadderEntry) -------------------------------
+// Where an image lives: PtrLadder = anywhere, places are byte offsets from its first entry (host emulation, tests);
+// the kernels read theirs from LDS through LdsLadder (device_common.h), whose places are LDS addresses.
+struct PtrLadder {
+    const LadderEntry *p;
+    ST_HD LadderEntry at(uint32_t place) const { return *reinterpret_cast<const LadderEntry *>(reinterpret_cast<const unsigned char *>(p) + place); }
+    ST_HD uint32_t place(uint32_t index) const { return index * (uint32_t)sizeof(LadderEntry); }
+    ST_HD uint32_t index(uint32_t place) const { return place / (uint32_t)sizeof(LadderEntry); }
+};
+
+#if defined(__HIPCC__)
+// An image staged into LDS by stage_ladder_image: places are LDS addresses (the links were moved by the image's own
+// address as they were copied), so a read takes its address from the entry before it without arithmetic.
+typedef uint32_t LadderWords __attribute__((ext_vector_type(4)));
+struct LdsLadder {
+    uint32_t base;      // LDS address of entry 0
+    __device__ __forceinline__ explicit LdsLadder(const void *image) : base((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)image) {}
+    __device__ __forceinline__ LadderEntry at(uint32_t place) const      // (one ds_read_b128)
+    {
+        const LadderWords w = *(const __attribute__((address_space(3))) LadderWords *)(uintptr_t)place;
+        return LadderEntry{__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), w.w};
+    }
+    __device__ __forceinline__ uint32_t place(uint32_t index) const { return base + index * (uint32_t)sizeof(LadderEntry); }
+    __device__ __forceinline__ uint32_t index(uint32_t place) const { return (place - base) / (uint32_t)sizeof(LadderEntry); }
+};
+
+// (all lanes of the workgroup; the caller's barrier follows)
+__device__ __forceinline__ void stage_ladder_image(unsigned char *lds_image, const LadderEntry *from, int entries)
 {
-    if (k <= (int32_t)nb) return stream_sum(lens + off_b, s, k);
-    s = stream_sum(lens + off_b, s, (int32_t)nb);
-    uint32_t left = (uint32_t)k - nb, v = portal_rank;
-    while (left >= 3) {
-        const LadderEntry e = lad[v];
+    const uint32_t base = LdsLadder(lds_image).base;
+    uint4 *dst = reinterpret_cast<uint4 *>(lds_image);
+    const uint4 *src = reinterpret_cast<const uint4 *>(from);
+    for (int k = threadIdx.x; k < entries; k += blockDim.x) {
+        uint4 e = src[k];
+        if (e.w != kLadderAbove) e.w += base;
+        dst[k] = e;
+    }
+}
+#endif
+
+// k edges of a lineage from the entry at `at`, added onto s in lineage order, three per 16-byte read; the climb counts
+// its edges (any numbering of the image).
+template <typename Lad>
+ST_HD float ladder_climb_counted(const Lad &lad, uint32_t at, uint32_t k, float s)
+{
+    while (k >= 3) {
+        const LadderEntry e = lad.at(at);
         s += e.d0; s += e.d1; s += e.d2;
-        v = e.link & 0xFFFFu;
-        left -= 3;
+        at = e.link;
+        k -= 3;
+    }
+    if (k) {
+        const LadderEntry e = lad.at(at);
+        s += e.d0;
+        if (k == 2) s += e.d1;
+    }
+    return s;
+}
+
+// The same on an image that numbers parents before children (the canopy's), towards a known ancestor whose entry is at
+// `stop`, k edges above: a round is taken while the third ancestor is still at or below that node -- one signed
+// compare of the link as it was read (kLadderAbove is negative) -- and the k % 3 edges left come from the entry the
+// loop ends on, which is already there.  Per round: one LDS read, the compare, three adds.
+template <typename Lad>
+ST_HD float ladder_climb_to(const Lad &lad, uint32_t at, uint32_t stop, uint32_t k, float s)
+{
+    const uint32_t left = k - 3u * ((k * 0xAAABu) >> 17);      // k % 3 (k < 2^16)
+    LadderEntry e = lad.at(at);
+    while ((int32_t)e.link >= (int32_t)stop) {
+        s += e.d0; s += e.d1; s += e.d2;
+        e = lad.at(e.link);
     }
     if (left) {
-        const LadderEntry e = lad[v];
         s += e.d0;
         if (left == 2) s += e.d1;
     }
     return s;
+}
+
+// The same with the crown part climbed on the crown's ladder (tree_prep.h: crown_ladder, indexed by rank;
+// LDS on the device) instead of streamed: k edges of b's lineage = its first min(k, nb) lineage lengths,
+// then k - nb ladder edges from its portal, three per 16-byte entry, in lineage order.
+template <typename Lad>
+ST_HD float stream_b_ladder(const float *__restrict__ lens, const Lad &lad, uint32_t off_b, uint32_t nb, uint32_t portal_rank,
+                            float s, int32_t k)
+{
+    if (k <= (int32_t)nb) return stream_sum(lens + off_b, s, k);
+    s = stream_sum(lens + off_b, s, (int32_t)nb);
+    return ladder_climb_counted(lad, lad.place(portal_rank), (uint32_t)k - nb, s);
 }
 
 ST_HD PairResult pair_walk(const Node8 *__restrict__ nodes, const int32_t *__restrict__ depth,
@@ -413,46 +480,21 @@ ST_HD uint32_t canopy_meet(const uint16_t *__restrict__ pos, const uint32_t *__r
 // depths of the two portals are known, so both sums know how many edges they climb and add
 // them three per 16-byte entry, in lineage order: a's canopy edges onto pbot_a, b's
 // understory, b's canopy edges.
-template <int CAP, typename LadPtr>
-ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy_id, uint32_t meet,
+template <int CAP, typename Lad>
+ST_HD PairResult pair_ladder_sums(const Lad &lad, const int32_t *__restrict__ canopy_id, uint32_t meet,
                                   uint32_t pa, uint32_t da, float pbot_a, uint32_t pb, uint32_t db,
                                   const float *D_b, uint32_t nb_b)
 {
-    const uint32_t dm = meet >> 16;
+    const uint32_t dm = meet >> 16, stop = lad.place(meet & 0xFFFFu);
     const int32_t mrca = canopy_id[meet & 0xFFFFu];      // (asked for first: the read is in flight while both sides climb)
-    float s = pbot_a;
-    uint32_t k = da - dm;
-    uint32_t u = pa;
-    while (k >= 3) {
-        const LadderEntry e = lad[u];
-        s += e.d0; s += e.d1; s += e.d2;
-        u = e.link & 0xFFFFu;
-        k -= 3;
-    }
-    if (k) {
-        const LadderEntry e = lad[u];
-        s += e.d0;
-        if (k == 2) s += e.d1;
-    }
+    float s = ladder_climb_to(lad, lad.place(pa), stop, da - dm, pbot_a);
     if (CAP > 0) {
 #pragma unroll
         for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
         s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
-    k = db - dm;
-    uint32_t v = pb;
-    while (k >= 3) {
-        const LadderEntry e = lad[v];
-        s += e.d0; s += e.d1; s += e.d2;
-        v = e.link & 0xFFFFu;
-        k -= 3;
-    }
-    if (k) {
-        const LadderEntry e = lad[v];
-        s += e.d0;
-        if (k == 2) s += e.d1;
-    }
+    s = ladder_climb_to(lad, lad.place(pb), stop, db - dm, s);
     PairResult r;
     r.dist = s;
     r.mrca = mrca;
@@ -462,8 +504,8 @@ ST_HD PairResult pair_ladder_sums(LadPtr lad, const int32_t *__restrict__ canopy
 // b's side of a pair whose a side came from the lineage-sum table (tree_prep.h): `s_a` is the
 // reference's accumulator after a's edges up to the meeting node; b's understory and its `kb`
 // canopy edges continue it, in lineage order, three canopy edges per 16-byte entry.
-template <int CAP, typename LadPtr>
-ST_HD float ladder_sum_b(LadPtr lad, uint32_t kb, float s_a, uint32_t pb, const float *D_b, uint32_t nb_b)
+template <int CAP, typename Lad>
+ST_HD float ladder_sum_b(const Lad &lad, uint32_t kb, float s_a, uint32_t pb, const float *D_b, uint32_t nb_b)
 {
     float s = s_a;
     if (CAP > 0) {
@@ -472,31 +514,19 @@ ST_HD float ladder_sum_b(LadPtr lad, uint32_t kb, float s_a, uint32_t pb, const 
     } else {
         s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
-    uint32_t k = kb;
-    uint32_t v = pb;
-    while (k >= 3) {
-        const LadderEntry e = lad[v];
-        s += e.d0; s += e.d1; s += e.d2;
-        v = e.link & 0xFFFFu;
-        k -= 3;
-    }
-    if (k) {
-        const LadderEntry e = lad[v];
-        s += e.d0;
-        if (k == 2) s += e.d1;
-    }
-    return s;
+    return ladder_climb_counted(lad, lad.place(pb), kb, s);
 }
 
 // Ladder form of pair_canopy_split for trees whose ids are NOT an in-order numbering (no
-// sparse table): lock-step search for the meeting node.  `lad` is the ladder table, `cdepth` the
-// canopy depths (both LDS on the device).  Phase 1 finds the meeting node with integer work
-// only: the deeper lineage is lifted to the other's depth, then both climb in lock step three
-// levels at a time while their third ancestors differ, one level at a time once they agree.
-// Phase 2 then knows how many edges each side climbs and adds them, three per entry, in
-// lineage order: a's canopy edges onto pbot_a, b's understory, b's canopy edges.
-template <int CAP, typename LadPtr, typename DepthPtr>
-ST_HD PairResult pair_ladder_split(LadPtr lad, DepthPtr cdepth, const int32_t *__restrict__ canopy_id,
+// sparse table): lock-step search for the meeting node.  `lad` is the ladder image, `cdepth` the
+// canopy depths, `canopy` the 8-byte entries (parents; global memory on the device).  Phase 1 finds
+// the meeting node with integer work only: the deeper lineage is lifted to the other's depth, then
+// both climb in lock step three levels at a time while their third ancestors differ, one level at a
+// time once they agree (or lie above the root).  Phase 2 then knows where each side ends and adds its
+// edges, three per entry, in lineage order: a's canopy edges onto pbot_a, b's understory, b's canopy edges.
+template <int CAP, typename Lad, typename DepthPtr>
+ST_HD PairResult pair_ladder_split(const Lad &lad, DepthPtr cdepth, const CanopyEntry *__restrict__ canopy,
+                                   const int32_t *__restrict__ canopy_id,
                                    uint32_t pa, float pbot_a, uint32_t pb,
                                    const float *D_b, uint32_t nb_b)
 {
@@ -504,55 +534,30 @@ ST_HD PairResult pair_ladder_split(LadPtr lad, DepthPtr cdepth, const int32_t *_
     const uint32_t da = cdepth[pa], db = cdepth[pb];
     uint32_t du = da, dv = db;
     while (du > dv) {
-        const uint32_t l = lad[u].link;
-        if (du - dv >= 3) { u = l & 0xFFFFu; du -= 3; } else { u = l >> 16; du -= 1; }
+        if (du - dv >= 3) { u = lad.index(lad.at(lad.place(u)).link); du -= 3; }      // (du >= 3: the link is a place)
+        else { u = canopy[u].link & kCanopyParentMask; du -= 1; }
     }
     while (dv > du) {
-        const uint32_t l = lad[v].link;
-        if (dv - du >= 3) { v = l & 0xFFFFu; dv -= 3; } else { v = l >> 16; dv -= 1; }
+        if (dv - du >= 3) { v = lad.index(lad.at(lad.place(v)).link); dv -= 3; }
+        else { v = canopy[v].link & kCanopyParentMask; dv -= 1; }
     }
     while (u != v) {
-        const uint32_t lu = lad[u].link, lv = lad[v].link;
-        if ((lu & 0xFFFFu) != (lv & 0xFFFFu)) { u = lu & 0xFFFFu; v = lv & 0xFFFFu; du -= 3; }
-        else { u = lu >> 16; v = lv >> 16; du -= 1; }
+        const uint32_t lu = lad.at(lad.place(u)).link, lv = lad.at(lad.place(v)).link;
+        if (lu != lv) { u = lad.index(lu); v = lad.index(lv); du -= 3; }      // (two places; both above the root compare equal)
+        else { u = canopy[u].link & kCanopyParentMask; v = canopy[v].link & kCanopyParentMask; du -= 1; }
     }
-    const uint32_t mc = u;
-    float s = pbot_a;
-    uint32_t k = da - du;
-    u = pa;
-    while (k >= 3) {
-        const LadderEntry e = lad[u];
-        s += e.d0; s += e.d1; s += e.d2;
-        u = e.link & 0xFFFFu;
-        k -= 3;
-    }
-    if (k) {
-        const LadderEntry e = lad[u];
-        s += e.d0;
-        if (k == 2) s += e.d1;
-    }
+    const uint32_t stop = lad.place(u);
+    float s = ladder_climb_to(lad, lad.place(pa), stop, da - du, pbot_a);
     if (CAP > 0) {
 #pragma unroll
         for (int i = 0; i < CAP; i++) s += D_b[i];      // (slots beyond nb_b hold -0.0f: kChainPad)
     } else {
         s = chain_sum_ptr_ahead(D_b, nb_b, s);
     }
-    k = db - du;
-    v = pb;
-    while (k >= 3) {
-        const LadderEntry e = lad[v];
-        s += e.d0; s += e.d1; s += e.d2;
-        v = e.link & 0xFFFFu;
-        k -= 3;
-    }
-    if (k) {
-        const LadderEntry e = lad[v];
-        s += e.d0;
-        if (k == 2) s += e.d1;
-    }
+    s = ladder_climb_to(lad, lad.place(pb), stop, db - du, s);
     PairResult r;
     r.dist = s;
-    r.mrca = canopy_id[mc];
+    r.mrca = canopy_id[u];
     return r;
 }
 

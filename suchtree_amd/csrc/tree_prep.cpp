@@ -315,11 +315,13 @@ bool prepare_canopy(const int32_t *parent, const float *distance, TreeTables &T,
         const uint32_t p1 = T.canopy[(size_t)c].link & kCanopyParentMask;          // root: 0 (itself)
         const uint32_t p2 = T.canopy[(size_t)p1].link & kCanopyParentMask;
         const uint32_t p3 = T.canopy[(size_t)p2].link & kCanopyParentMask;
+        const uint32_t dc = T.canopy[(size_t)c].link >> 16;
         LadderEntry &e = T.ladder[(size_t)c];
-        e.d0 = T.canopy[(size_t)c].dist;
-        e.d1 = T.canopy[(size_t)p1].dist;
-        e.d2 = T.canopy[(size_t)p2].dist;
-        e.link = p3 | (p1 << 16);
+        e.d0 = T.canopy[(size_t)c].dist;                       // (root: 0, see above)
+        e.d1 = dc >= 2 ? T.canopy[(size_t)p1].dist : 0.0f;
+        e.d2 = dc >= 3 ? T.canopy[(size_t)p2].dist : 0.0f;
+        e.link = dc >= 3 ? p3 * (uint32_t)sizeof(LadderEntry) : kLadderAbove;
+        if (dc >= 1 && p1 >= (uint32_t)c) return false;        // (parents first: what "while link >= place(m)" rests on)
         T.canopy_depth[(size_t)c] = (uint16_t)(T.canopy[(size_t)c].link >> 16);
     }
     T.understory_max = H;
@@ -632,7 +634,8 @@ bool prepare_walk_crown(TreeTables &T, int64_t hot_bytes, int max_ladder_nodes)
             e.d0 = T.nodes[(size_t)x].parent >= 0 ? T.nodes[(size_t)x].dist : 0.0f;
             e.d1 = (q1 != x && T.nodes[(size_t)q1].parent >= 0) ? T.nodes[(size_t)q1].dist : 0.0f;
             e.d2 = (q2 != q1 && T.nodes[(size_t)q2].parent >= 0) ? T.nodes[(size_t)q2].dist : 0.0f;
-            e.link = (uint32_t)rank[(size_t)q3] | ((uint32_t)rank[(size_t)q1] << 16);
+            // (ranks are not ordered by depth: climbs on this image count their edges)
+            e.link = T.depth[(size_t)x] >= 3 ? (uint32_t)rank[(size_t)q3] * (uint32_t)sizeof(LadderEntry) : kLadderAbove;
         }
     }
     if (T.inorder_ids) {

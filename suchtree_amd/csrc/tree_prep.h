@@ -55,14 +55,22 @@ static_assert(sizeof(CanopyEntry) == 8, "CanopyEntry must be 8 bytes");
 
 // Ladder form of the canopy, for deep trees (hundreds of levels): one 16-byte entry per canopy
 // node carries the branch lengths of THREE consecutive edges of its lineage -- its own, its
-// parent's and its grandparent's -- and the canopy indices of its parent and of its third
-// ancestor, so a climb of k edges costs k/3 LDS reads and k float adds (in lineage order,
-// exactly as before) instead of k reads.  Near the root the third ancestor is clamped to the
-// root (index 0) and the unused lengths are 0 (never added: climbs know their edge counts).
-struct LadderEntry {
-    float d0, d1, d2;   // dist[v], dist[parent(v)], dist[parent(parent(v))]
-    uint32_t link;      // bits 0..15: third ancestor (clamped to the root); bits 16..31: parent (root: itself)
+// parent's and its grandparent's -- and where its third ancestor's entry is, so a climb of k
+// edges costs k/3 LDS reads and k float adds (in lineage order, exactly as before) instead of
+// k reads.  Single steps (the lock-step search of trees without the sparse table) take the
+// parent from the 8-byte CanopyEntry table in global memory.
+// The third ancestor is kept as the PLACE of its entry -- the byte offset in the image (index * 16); a kernel that
+// stages the image into LDS adds the image's LDS address (pair_math.h: PtrLadder / device_common.h: LdsLadder) -- so a
+// climb's next read takes the link as it comes.  An ancestor above the root is kLadderAbove: negative as int32, below
+// every place.  Canopy images number parents before children, so along one lineage places grow with depth and a
+// climb towards a known ancestor m runs "while link >= place(m)" (signed): the climb loops of the ladder kernels are
+// bound by VALU issue (ml.tree: 94 % busy at 7 instructions per round -- shift, mask, count, compare and the three
+// adds; profiles/counters_ml_ladder_r04.txt) and this leaves the compare and the adds.
+struct alignas(16) LadderEntry {
+    float d0, d1, d2;   // dist[v], dist[parent(v)], dist[parent(parent(v))] (0 above the root)
+    uint32_t link;      // place of the third ancestor's entry, or kLadderAbove
 };
+constexpr uint32_t kLadderAbove = 0x80000000u;
 static_assert(sizeof(LadderEntry) == 16, "LadderEntry must be 16 bytes");
 
 // Understory record of a node, cap = R/8 - 1 chain slots, kept in three tables so that

@@ -97,7 +97,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                     int32_t dm;
                     (void)pair_walk_mrca(T.nodes.data(), T.depth.data(), T.stride.data(), (int32_t)a, (int32_t)b, &dm);
                     float s = W.sums[(size_t)ka.off + (size_t)((int32_t)ka.depth - dm)];
-                    s = stream_b_ladder(W.lens.data(), W.ladder.data(), kb.off, kb.nb_rank & 0xFFu, kb.nb_rank >> 8, s, (int32_t)kb.depth - dm);
+                    s = stream_b_ladder(W.lens.data(), PtrLadder{W.ladder.data()}, kb.off, kb.nb_rank & 0xFFu, kb.nb_rank >> 8, s, (int32_t)kb.depth - dm);
                     if (std::memcmp(&s, &r.dist, 4) != 0) {
                         g_err = "walk: ladder form of the crown part disagrees with the climb";
                         return 16;
@@ -168,9 +168,9 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                 PairResult l;
                 if (T.inorder_ids) {
                     const uint32_t meet = canopy_meet(T.canopy_pos.data(), T.canopy_rmq.data(), T.canopy_nodes, pa, pb);
-                    l = pair_ladder_sums<0>(T.ladder.data(), T.canopy_id.data(), meet, pa, T.canopy_depth[pa],
+                    l = pair_ladder_sums<0>(PtrLadder{T.ladder.data()}, T.canopy_id.data(), meet, pa, T.canopy_depth[pa],
                                             pbot_a, pb, T.canopy_depth[pb], B.D, B.nb);
-                    const PairResult l2 = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(),
+                    const PairResult l2 = pair_ladder_split<0>(PtrLadder{T.ladder.data()}, T.canopy_depth.data(), T.canopy.data(), T.canopy_id.data(),
                                                                pa, pbot_a, pb, B.D, B.nb);
                     if (l2.mrca != l.mrca || std::memcmp(&l2.dist, &l.dist, 4) != 0) {
                         g_err = "sparse-table form disagrees with the lock-step ladder form";
@@ -190,14 +190,14 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                             g_err = "rec_p: chunk count does not cover b's chain";
                             return 9;
                         }
-                        const float d3 = ladder_sum_b<0>(T.ladder.data(), kb_total - B.nb, T.lineage_sum[(size_t)(ya & 0x0FFFFFFFu) + k_a], pb, B.D, B.nb);
+                        const float d3 = ladder_sum_b<0>(PtrLadder{T.ladder.data()}, kb_total - B.nb, T.lineage_sum[(size_t)(ya & 0x0FFFFFFFu) + k_a], pb, B.D, B.nb);
                         if (dm != (meet >> 16) || (int32_t)(uint32_t)m64 != l.mrca || std::memcmp(&d3, &l.dist, 4) != 0) {
                             g_err = "lineage-sum form disagrees with the ladder form";
                             return 6;
                         }
                     }
                 } else {
-                    l = pair_ladder_split<0>(T.ladder.data(), T.canopy_depth.data(), T.canopy_id.data(), pa, pbot_a, pb, B.D, B.nb);
+                    l = pair_ladder_split<0>(PtrLadder{T.ladder.data()}, T.canopy_depth.data(), T.canopy.data(), T.canopy_id.data(), pa, pbot_a, pb, B.D, B.nb);
                 }
                 if (l.mrca != r.mrca || std::memcmp(&l.dist, &r.dist, 4) != 0) {
                     g_err = "sparse-table / ladder form disagrees with the plain canopy climb";

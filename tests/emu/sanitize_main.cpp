@@ -121,7 +121,7 @@ static int check_tree(std::mt19937_64 &rng, int n_leaves, double skew, int max_c
                 std::memcpy(&wpb, T.rec_p.data() + record_slot(b, T.parity_layout, T.n_leaves) * 8, 4);
                 const uint64_t m64 = canopy_meet_ranks64(T.canopy_rmq64.data(), T.canopy_nodes, wpa & 0xFFFFu, wpb & 0xFFFFu);
                 const uint32_t dm = (uint32_t)(m64 >> 32);
-                const float d = ladder_sum_b<0>(T.ladder.data(), (wpb >> 16) - dm - B.nb,
+                const float d = ladder_sum_b<0>(PtrLadder{T.ladder.data()}, (wpb >> 16) - dm - B.nb,
                                                 T.lineage_sum[(size_t)(ya & 0x0FFFFFFFu) + ((wpa >> 16) - dm)], B.portal, B.D, B.nb);
                 if ((int32_t)(uint32_t)m64 != w.mrca || std::memcmp(&d, &w.dist, 4) != 0) return 5;
             }
