@@ -275,3 +275,62 @@ def linked_laplacian(aj):
     np.fill_diagonal(lp, aj.sum(axis=0))
     lp = lp - aj
     return lp
+
+
+# ---- callers of the path restated for the navigation tests (tests/test_gpu_navigation.py) -------------------------
+def leaves_below(left, right, node):
+    """MuchTree.pyx:429-466 (get_leaves): leaf ids below `node` in the order the reference's to_visit list grows."""
+    to_visit, out = [int(node)], []
+    for current in to_visit:
+        if left[current] == -1:
+            out.append(current)
+        else:
+            to_visit.append(int(left[current]))
+            to_visit.append(int(right[current]))
+    return out
+
+
+def preorder(left, right, root):
+    """MuchTree.pyx:1505-1540 (traverse_preorder)."""
+    stack, out = [int(root)], []
+    while stack:
+        current = stack.pop()
+        if right[current] != -1:
+            stack.append(int(right[current]))
+        if left[current] != -1:
+            stack.append(int(left[current]))
+        out.append(current)
+    return out
+
+
+def distance_to_root(parent, distance, node):
+    """MuchTree.pyx:826-847 (_get_distance_to_root): C float accumulator, ends at the first length equal to -1."""
+    d, i = np.float32(0.0), int(node)
+    while True:
+        d_i = distance[i]
+        if d_i == -1:
+            break
+        d = np.float32(d + d_i)
+        i = int(parent[i])
+    return float(d)
+
+
+def relative_evolutionary_divergence(tree, left, right, root):
+    """MuchTree.pyx:303-330, statement by statement: RED[root] = 0, then in pre-order
+    P + (a / (a + b)) * (1 - P) with a = distance(node, parent), b = np.mean of the list of distance(node, leaf) over
+    get_leafs(node).  `tree` is an OracleTree (its distances are the reference's float32 ordered sums); the per-node
+    lists are evaluated with one oracle batch per node instead of one call per leaf -- same values, same order.
+    The reference holds no golden for RED: what pins this restatement is that it is the quoted statements over an
+    oracle pinned elsewhere, and the properties its docstring states (0 at the root, 1 at every leaf)."""
+    red = {int(root): 0}
+    parent = tree.nodes["parent"]
+    for node in preorder(left, right, root)[1:]:
+        P = red[int(parent[node])]
+        a = tree.distance(node, int(parent[node]))
+        leaves = leaves_below(left, right, node)
+        pairs = np.stack((np.full(len(leaves), node, dtype=np.int64), np.array(leaves, dtype=np.int64)), axis=1)
+        b = np.mean([float(x) for x in tree.distances(pairs)])
+        if a + b == 0:
+            raise Exception("node {n} : a={a}, b={b}".format(n=node, a=a, b=b))
+        red[node] = P + (a / (a + b)) * (1 - P)
+    return red

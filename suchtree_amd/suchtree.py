@@ -3,10 +3,11 @@
 Host-side mirror of the reference's extension type
 (/root/reference/SuchTree/MuchTree.pyx:89-2518): same constructor dispatch,
 property names (and deprecated aliases), method names, argument conventions,
-return types, exceptions and warnings for everything on the hot path.  All
-arithmetic happens in libsuchtree_hip.so on the GPU; nothing here computes a
-distance or an MRCA on the CPU, and a missing library or GPU raises
-``HipBackendError``.
+return types, exceptions and warnings for everything on the hot path; the
+reference's navigation methods around it (node tests, lineages, traversals,
+bipartitions, RED) come from navigate.py.  All arithmetic happens in
+libsuchtree_hip.so on the GPU; nothing here computes a distance or an MRCA on
+the CPU, and a missing library or GPU raises ``HipBackendError``.
 """
 import os
 from itertools import chain
@@ -19,6 +20,7 @@ import numpy as np
 
 from . import _capi
 from .exceptions import InvalidNodeError, NodeNotFoundError
+from .navigate import TreeNavigation
 from .newick import EPSILON, FlatTree, flat_tree_from_arrays, flat_tree_from_newick
 
 _NAMES_EXT = False      # not looked for yet
@@ -52,7 +54,7 @@ def _deprecation_warning(old_name: str, new_name: str, version: str = "2.0") -> 
     )
 
 
-class SuchTree:
+class SuchTree(TreeNavigation):
     """Immutable phylogenetic tree resident in GPU memory.
 
     ``tree_input`` follows the reference (MuchTree.pyx:138-155): a URL, a Newick

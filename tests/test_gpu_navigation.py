@@ -1,0 +1,101 @@
+"""Callers of the path in suchtree_amd/navigate.py on the GPU: distance_to_root, path_between_nodes and the relative
+evolutionary divergence, against the oracle's statement-by-statement restatements (oracle/oracle.py) -- exact
+equality -- and the reference's own assertions (SuchTree/tests/test_new_api.py:354-360, 539-556;
+tests/test_SuchTree.py:46-49: distance to root of every leaf)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from oracle import oracle
+from oracle.oracle import OracleTree
+from suchtree_amd import SuchTree
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_of(T):
+    f = T._flat
+    return OracleTree(f.parent, f.distance, f.left, f.right)
+
+
+@pytest.mark.parametrize("tree", ["test.tree", "host.tree", "fish_worm/guest.tree"])
+def test_distance_to_root_and_paths(tree):
+    T = SuchTree(golden_path(tree))
+    f = T._flat
+    for x in range(T.size):
+        d = T.distance_to_root(x)
+        assert isinstance(d, float) and d == oracle.distance_to_root(f.parent, f.distance, x)
+    for name in T.leaves:
+        with pytest.warns(DeprecationWarning, match=r"get_distance_to_root\(\) is deprecated"):
+            assert T.get_distance_to_root(name) == T.distance_to_root(name)
+    assert T.distance_to_root(T.root_node) == 0.0
+    O = _oracle_of(T)
+    rng = np.random.default_rng(7)
+    for a, b in rng.integers(0, T.size, (60, 2)):
+        a, b = int(a), int(b)
+        path = T.path_between_nodes(a, b)
+        assert isinstance(path, list) and all(isinstance(x, int) for x in path)
+        assert path[0] == a and path[-1] == b and len(set(path)) == len(path)
+        m = O.mrca(a, b)
+        assert m in path
+        k = path.index(m)
+        assert all(f.parent[path[i]] == path[i + 1] for i in range(k))                    # up to the MRCA
+        assert all(f.parent[path[i + 1]] == path[i] for i in range(k, len(path) - 1))     # and down again
+    leaves = list(T.leaves.keys())[:2]
+    path = T.path_between_nodes(leaves[0], leaves[1])
+    assert len(path) >= 2 and path[0] == T.leaves[leaves[0]] and path[-1] == T.leaves[leaves[1]]
+    assert T.path_between_nodes(3, 3) == [3]
+
+
+def test_distance_to_root_stops_at_a_length_of_minus_one():
+    # MuchTree.pyx:840-845 ends its loop at the first length equal to -1, not at the root: a branch of length -1
+    # (neighbor-joining trees have negative lengths) cuts the sum short there, in the reference and here alike
+    T = SuchTree("((A:1,B:2):-1,(C:3,D:4):0.5);")
+    f = T._flat
+    for x in range(T.size):
+        assert T.distance_to_root(x) == oracle.distance_to_root(f.parent, f.distance, x)
+    assert T.distance_to_root("A") == 1.0 and T.distance_to_root("C") == 3.5
+
+
+@pytest.mark.parametrize("tree", ["test.tree", "host.tree", "fish_worm/guest.tree", "gopher_louse/lice.tree"])
+def test_relative_evolutionary_divergence(tree):
+    T = SuchTree(golden_path(tree))
+    f = T._flat
+    red = T.relative_evolutionary_divergence
+    want = oracle.relative_evolutionary_divergence(_oracle_of(T), f.left, f.right, T.root_node)
+    assert list(red.keys()) == list(want.keys())      # filled in pre-order, like the reference's dict
+    for x in want:
+        assert red[x] == want[x], (x, red[x], want[x])
+    # what the reference's docstring states (MuchTree.pyx:306-312): 0 at the root, 1 at every leaf, between
+    assert red[T.root_node] == 0 and all(abs(red[x] - 1) < 1e-12 for x in T.leaves.values())
+    assert all(-1e-12 <= v <= 1 + 1e-12 for v in red.values())
+    assert T.RED is red and T.relative_evolutionary_divergence is red      # cached (MuchTree.pyx:316-318)
+
+
+def test_relative_evolutionary_divergence_on_a_deep_tree(ml_arrays):
+    # ml.tree: 108,653 nodes, 376 levels; the pairs of all nodes with all leaves below them are one 6e6-pair batch
+    parent, dist = ml_arrays[0], ml_arrays[1]
+    T = SuchTree((parent, dist))
+    f = T._flat
+    red = T.relative_evolutionary_divergence
+    assert len(red) == T.size and red[T.root_node] == 0
+    rng = np.random.default_rng(3)
+    O = _oracle_of(T)
+    # the oracle's restatement on a sample of lineages: RED of a node needs the REDs of its ancestors only
+    pre = oracle.preorder(f.left, f.right, T.root_node)
+    sample = set()
+    for x in rng.choice(T.size, 40, replace=False):
+        sample.add(int(x)); sample.update(int(y) for y in T.get_ancestors(int(x)))
+    want = {T.root_node: 0}
+    for x in pre[1:]:
+        if x not in sample:
+            continue
+        P = want[int(f.parent[x])]
+        a = O.distance(x, int(f.parent[x]))
+        leaves = oracle.leaves_below(f.left, f.right, x)
+        b = np.mean([float(v) for v in O.distances(np.stack((np.full(len(leaves), x), np.array(leaves)), axis=1))])
+        want[x] = P + (a / (a + b)) * (1 - P)
+    for x, v in want.items():
+        assert red[x] == v, (x, red[x], v)

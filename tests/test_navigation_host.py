@@ -1,0 +1,158 @@
+"""Tree navigation of the facade (suchtree_amd/navigate.py), host side: the reference's own assertions for these
+methods (SuchTree/tests/test_new_api.py:192-345, 470-494, 562-656, 821-839; tests/test_SuchTree.py:95-160) restated
+against the facade on the same fixtures, plus exact orders of enumeration against the oracle's restatements.
+Nothing here needs a GPU (no distance, no MRCA)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+from oracle import oracle
+from suchtree_amd import InvalidNodeError, NodeNotFoundError, SuchTree
+
+TEST_TREE = golden_path("test.tree")
+SIMPLE = "(A,B,(C,D));"
+
+
+@pytest.fixture(scope="module")
+def T():
+    return SuchTree(TEST_TREE)
+
+
+@pytest.fixture(scope="module")
+def S():
+    return SuchTree(SIMPLE)
+
+
+def test_ancestors_and_is_ancestor(T):
+    leaf = list(T.leaves.keys())[0]
+    ancestors = list(T.get_ancestors(leaf))
+    for x in ancestors:
+        assert T.is_ancestor(x, leaf) == 1 and T.is_ancestor(leaf, x) == -1
+    with pytest.warns(DeprecationWarning, match=r"get_lineage\(\) is deprecated"):
+        assert list(T.get_lineage(leaf)) == ancestors
+    root = T.root_node
+    for x in T.all_nodes:
+        if x != root:
+            assert T.is_ancestor(root, x) == 1 and T.is_ancestor(x, root) == -1
+            assert T.is_descendant(x, root) and not T.is_descendant(root, x)
+            assert not T.is_root(x) and T.has_parent(x)
+    assert T.is_root(root) and not T.has_parent(root)
+    a, b = list(T.leaves.values())[:2]
+    assert T.is_ancestor(a, b) == 0 and T.is_ancestor(a, a) == 0
+    assert T.is_ancestor("Ttal", 27) == -1 and T.is_ancestor(27, "Ttal") == 1
+
+
+def test_descendants_leaves_nodes(T):
+    root = T.root_node
+    assert set(T.get_descendants(root)) == set(T.all_nodes)
+    with pytest.warns(DeprecationWarning):
+        assert set(T.get_descendant_nodes(root)) == set(T.all_nodes)
+    leaves = T.get_leaves(root)
+    assert isinstance(leaves, np.ndarray) and set(leaves) == set(T.leaves.values())
+    with pytest.warns(DeprecationWarning, match=r"get_leafs\(\) is deprecated"):
+        np.testing.assert_array_equal(T.get_leafs(root), leaves)
+    assert set(T.get_internal_nodes()) == set(T.internal_nodes) and set(T.get_nodes()) == set(T.all_nodes)
+    assert set(T.get_internal_nodes(None)) == set(T.internal_nodes)
+    f = T._flat
+    for x in range(T.size):      # exact order of enumeration: the oracle's restatement of the to_visit loops
+        assert T.get_leaves(x).tolist() == oracle.leaves_below(f.left, f.right, x)
+        sub = list(T.get_descendants(x))
+        assert T.get_nodes(x).tolist() == sub and sub[0] == x
+        assert T.get_internal_nodes(x).tolist() == [y for y in sub if f.left[y] != -1]
+    assert T.get_leaves("Ttal").tolist() == [T.leaves["Ttal"]]
+    # a 15-leaf tree by hand: node 27 = (Ttal, Tbot)
+    assert T.get_leaves(27).tolist() == [26, 28] and list(T.get_descendants(27)) == [27, 26, 28]
+
+
+def test_node_tests(T, S):
+    for x in T.all_nodes:
+        assert T.has_children(x) == T.is_internal(x) == (not T.is_leaf(x))
+    with pytest.warns(DeprecationWarning, match=r"is_internal_node\(\) is deprecated"):
+        assert T.is_internal_node(T.root_node)
+    pairs = [(a, b) for a in S.all_nodes for b in S.all_nodes
+             if a != b and S.get_parent(a) == S.get_parent(b) and S.get_parent(a) != -1]
+    assert pairs and all(S.is_sibling(a, b) for a, b in pairs)
+    assert not S.is_sibling(S.root_node, 0) and not S.is_sibling(0, 4) and S.is_sibling("C", "D")
+    with pytest.raises(NodeNotFoundError):
+        T.is_internal("nope")
+    with pytest.raises(InvalidNodeError):
+        T.is_root(T.size)
+
+
+def test_traversals(T, S):
+    f = T._flat
+    with_d = list(T.traverse_inorder(include_distances=True))
+    with pytest.warns(DeprecationWarning, match=r"in_order\(\) is deprecated"):
+        assert list(T.in_order(distances=True)) == with_d
+    assert len(with_d) == T.size
+    assert [x for x, _ in with_d] == list(range(T.size))      # ids ARE in-order positions (MuchTree.pyx:171-216)
+    assert all(isinstance(d, float) and d == float(f.distance[x]) for x, d in with_d)
+    no_d = list(T.traverse_inorder(include_distances=False))
+    assert no_d == list(range(T.size)) and all(isinstance(x, int) for x in no_d)
+    pre = list(T.traverse_preorder())
+    with pytest.warns(DeprecationWarning, match=r"pre_order\(\) is deprecated"):
+        assert list(T.pre_order()) == pre
+    assert pre == oracle.preorder(f.left, f.right, T.root_node) and pre[0] == T.root_node and len(pre) == T.size
+    post = list(T.traverse_postorder())
+    assert len(post) == T.size and post[-1] == T.root_node and all(isinstance(x, int) for x in post)
+    seen = set()
+    for x in post:      # children before parents, left subtree before right
+        l, r = T.get_children(x)
+        assert l == -1 or (l in seen and r in seen)
+        seen.add(x)
+    level = list(T.traverse_levelorder())
+    assert level == list(T.get_descendants(T.root_node)) and level[0] == T.root_node
+    leaves = list(T.traverse_leaves_only())
+    assert leaves == [x for x in pre if T.is_leaf(x)] and set(leaves) == set(T.leaves.values())
+    internal = list(T.traverse_internal_only())
+    assert internal == [x for x in pre if not T.is_leaf(x)] and set(internal) == set(T.internal_nodes)
+    depths = dict(T.traverse_with_depth())
+    assert depths[T.root_node] == 0 and len(depths) == T.size
+    assert all(isinstance(x, int) and isinstance(d, int) and d == len(list(T.get_ancestors(x))) for x, d in depths.items())
+    assert max(depths.values()) + 1 == T.depth
+    for x, to_parent, to_root in T.traverse_with_distances():
+        assert isinstance(x, int) and isinstance(to_parent, float) and isinstance(to_root, float) and to_root >= 0
+        assert to_parent == float(f.distance[x])
+        up = [float(f.distance[y]) for y in T.get_ancestors(x)][:-1]      # branches above x, the root's -1 left out
+        assert to_root == pytest.approx(sum(up), abs=1e-12)
+    # subtrees
+    assert list(S.traverse_preorder()) == [3, 1, 0, 2, 5, 4, 6] and list(S.traverse_preorder(5)) == [5, 4, 6]
+    assert list(S.traverse_postorder()) == [0, 2, 1, 4, 6, 5, 3] and list(S.traverse_levelorder()) == [3, 1, 5, 0, 2, 4, 6]
+    assert list(S.traverse_preorder("C")) == [0] and list(S.traverse_levelorder(1)) == [1, 0, 2]
+    assert list(S.traverse_with_depth(1)) == [(1, 0), (0, 1), (2, 1)]
+
+
+def test_bipartitions(T, S):
+    parts = list(T.bipartitions())
+    assert len(parts) == len(T.internal_nodes)
+    names = set(T.leaves.keys())
+    for p in parts:
+        assert isinstance(p, frozenset) and len(p) == 2
+        a, b = tuple(p)
+        assert not (a & b) and (a | b) <= names
+    root_part = T.bipartition(T.root_node)
+    assert frozenset().union(*root_part) == names
+    by_id = T.bipartition(27, by_id=True)
+    assert by_id == frozenset((frozenset((26,)), frozenset((28,))))
+    assert T.bipartition(27) == frozenset((frozenset(("Ttal",)), frozenset(("Tbot",))))
+    with pytest.warns(DeprecationWarning, match=r"get_bipartition\(\) is deprecated"):
+        assert T.get_bipartition(27, by_id=True) == by_id
+    with pytest.raises(InvalidNodeError, match="Node 26 is not an internal node"):
+        T.bipartition(26)
+    assert set(S.bipartitions()) == {frozenset((frozenset(("C",)), frozenset(("D",)))),
+                                     frozenset((frozenset(("A",)), frozenset(("B",)))),
+                                     frozenset((frozenset(("C", "D")), frozenset(("A", "B"))))}
+
+
+def test_oracle_restatements_on_a_known_tree(S):
+    f = S._flat
+    # (A,B,(C,D)); -> C 0, D 2, A 4, B 6 (docs: test_new_api.py), root 3
+    assert S.root_node == 3
+    assert oracle.preorder(f.left, f.right, 3) == list(S.traverse_preorder())
+    assert oracle.leaves_below(f.left, f.right, 3) == S.get_leaves(3).tolist()
+    assert sorted(S.get_leaves(3).tolist()) == [0, 2, 4, 6]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")      # the new names do not warn
+        list(S.get_ancestors(0)); S.get_leaves(3); S.is_internal(3); list(S.traverse_preorder())
