@@ -261,25 +261,8 @@ class SuchLinkedTrees:
     @staticmethod
     def _tree_adjacency(tree: SuchTree, from_node):
         """SuchTree.adjacency_matrix (pyx:1750-1813) for the subtree below from_node."""
-        flat = tree._flat
-        to_visit = [int(from_node)]
-        for cur in to_visit:
-            if flat.left[cur] != -1:
-                to_visit.append(int(flat.left[cur]))
-                to_visit.append(int(flat.right[cur]))
-        node_ids = np.array(to_visit)
-        index = {int(n): i for i, n in enumerate(node_ids)}
-        adj = np.zeros((len(node_ids), len(node_ids)), dtype=float)
-        for i, n in enumerate(node_ids):
-            p = int(flat.parent[n])
-            if p == -1 or p not in index:
-                continue
-            d = float(flat.distance[n])
-            if d == 0:
-                d += tree.polytomy_epsilon
-            adj[i, index[p]] = d
-            adj[index[p], i] = d
-        return adj, node_ids
+        r = tree.adjacency_matrix(int(from_node))
+        return r["adjacency_matrix"], r["node_ids"]
 
     def _graph_edges(self, deletions=0, additions=0, swaps=0):
         """Edge list (u, v, weight) and size of the two-tree graph of pyx:3081-3131: tree edges

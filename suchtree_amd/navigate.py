@@ -285,6 +285,56 @@ class TreeNavigation:
         for node_id in self.get_internal_nodes():
             yield self.bipartition(int(node_id), by_id=by_id)
 
+    # ------------------------------------------------------------------ the tree as a graph
+    def adjacency_matrix(self, from_node=None) -> dict:
+        """Dense symmetric matrix of branch lengths over the subtree's nodes in breadth-first order; a zero length
+        becomes the polytomy epsilon (MuchTree.pyx:1750-1813)."""
+        node_ids = np.array(self._breadth_first(self._start_node(from_node)), dtype=int)
+        index = {int(x): i for i, x in enumerate(node_ids)}
+        adj = np.zeros((len(node_ids), len(node_ids)), dtype=float)
+        parent, dist = self._flat.parent, self._flat.distance
+        for i, x in enumerate(node_ids):
+            p = int(parent[x])
+            if p == -1 or p not in index:      # the root; the starting node of a subtree
+                continue
+            d = float(dist[x])
+            if d == 0:
+                d += self.polytomy_epsilon
+            adj[i, index[p]] = d
+            adj[index[p], i] = d
+        return {"adjacency_matrix": adj, "node_ids": node_ids}
+
+    def laplacian_matrix(self, from_node=None) -> dict:
+        """diag(column sums) - adjacency (MuchTree.pyx:1815-1854)."""
+        result = self.adjacency_matrix(self._start_node(from_node))
+        adj = result["adjacency_matrix"]
+        lap = np.zeros(adj.shape, dtype=float)
+        np.fill_diagonal(lap, adj.sum(axis=0))
+        return {"laplacian": lap - adj, "node_ids": result["node_ids"]}
+
+    def incidence_matrix(self, from_node=None) -> dict:
+        """Nodes x edges, +1 at an edge's parent and -1 at its child, edges in breadth-first order of their child
+        (MuchTree.pyx:1856-1917).  Like the reference it only works from the root: the edge above the starting node
+        of a subtree has no parent row (the reference's `np.where(...)[0][0]` raises IndexError there too)."""
+        node_ids = np.array(self._breadth_first(self._start_node(from_node)), dtype=int)
+        index = {int(x): i for i, x in enumerate(node_ids)}
+        parent = self._flat.parent
+        edges = [(int(parent[x]), int(x)) for x in node_ids if parent[x] != -1]
+        incidence = np.zeros((len(node_ids), len(edges)), dtype=int)
+        for k, (p, c) in enumerate(edges):
+            if p not in index:
+                raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+            incidence[index[p], k] = 1
+            incidence[index[c], k] = -1
+        return {"incidence_matrix": incidence, "node_ids": node_ids, "edge_list": edges}
+
+    def degree_sequence(self, from_node=None) -> dict:
+        """Number of edges at every node of the subtree (MuchTree.pyx:1958-1989)."""
+        result = self.adjacency_matrix(from_node)
+        degrees = np.sum(result["adjacency_matrix"] > 0, axis=1)
+        return {"degrees": degrees, "node_ids": result["node_ids"],
+                "max_degree": degrees.max(), "min_degree": degrees.min()}
+
     # ------------------------------------------------------------------ relative evolutionary divergence
     @property
     def relative_evolutionary_divergence(self) -> Dict[int, float]:
@@ -388,3 +438,12 @@ class TreeNavigation:
     def pre_order(self):
         _deprecated("pre_order()", "traverse_preorder()")
         return self.traverse_preorder()
+
+    def adjacency(self, node: int = -1):
+        """(the reference's wrapper, MuchTree.pyx:2499-2502, names a variable it does not have; this one forwards)"""
+        _deprecated("adjacency()", "adjacency_matrix()")
+        return self.adjacency_matrix(None if node == -1 else node)
+
+    def laplacian(self, node: int = -1):
+        _deprecated("laplacian()", "laplacian_matrix()")
+        return self.laplacian_matrix(None if node == -1 else node)

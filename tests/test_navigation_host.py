@@ -156,3 +156,39 @@ def test_oracle_restatements_on_a_known_tree(S):
     with warnings.catch_warnings():
         warnings.simplefilter("error")      # the new names do not warn
         list(S.get_ancestors(0)); S.get_leaves(3); S.is_internal(3); list(S.traverse_preorder())
+
+
+def test_graph_matrices(T, S):
+    f = T._flat
+    for start in (None, 27, 19, "Ttal"):      # SuchTree/tests/test_new_api.py:657-706, 729-748 + the oracle's restatement
+        r = T.adjacency_matrix(start)
+        adj, ids = r["adjacency_matrix"], r["node_ids"]
+        want, want_ids = oracle.tree_adjacency(f.parent, f.left, f.right, f.distance,
+                                               T.root_node if start is None else T._validate_node(start), T.polytomy_epsilon)
+        assert ids.tolist() == want_ids.tolist() and np.array_equal(adj, want)
+        assert adj.shape == (len(ids), len(ids)) and np.array_equal(adj, adj.T) and adj.dtype == np.float64
+        lap = T.laplacian_matrix(start)
+        assert lap["node_ids"].tolist() == ids.tolist()
+        assert np.array_equal(lap["laplacian"], np.diag(adj.sum(axis=0)) - adj)
+        np.testing.assert_allclose(lap["laplacian"].sum(axis=1), 0, atol=1e-12)
+        deg = T.degree_sequence(start)
+        assert deg["degrees"].tolist() == (adj > 0).sum(axis=1).tolist()
+        assert deg["max_degree"] == deg["degrees"].max() and deg["min_degree"] == deg["degrees"].min()
+    assert T.adjacency_matrix()["adjacency_matrix"].shape == (T.size, T.size)
+    assert T.degree_sequence()["max_degree"] == 3 and T.degree_sequence()["min_degree"] == 1
+    inc = T.incidence_matrix()
+    m, ids, edges = inc["incidence_matrix"], inc["node_ids"], inc["edge_list"]
+    assert m.shape == (T.size, T.size - 1) and len(edges) == T.size - 1
+    assert (m.sum(axis=0) == 0).all() and ((m == 1).sum(axis=0) == 1).all() and ((m == -1).sum(axis=0) == 1).all()
+    for k, (p, c) in enumerate(edges):
+        assert T.get_parent(c) == p and m[ids.tolist().index(p), k] == 1 and m[ids.tolist().index(c), k] == -1
+    with pytest.raises(IndexError):
+        T.incidence_matrix(27)
+    # zero-length branches count as epsilon (MuchTree.pyx:1801-1802)
+    Z = SuchTree("((A:0,B:1):1,C:2);")
+    assert Z.adjacency_matrix()["adjacency_matrix"].min() == 0 and \
+        np.sort(Z.adjacency_matrix()["adjacency_matrix"][np.triu_indices(5, 1)])[-4] == Z.polytomy_epsilon
+    with pytest.warns(DeprecationWarning, match=r"adjacency\(\) is deprecated"):
+        assert np.array_equal(T.adjacency()["adjacency_matrix"], T.adjacency_matrix()["adjacency_matrix"])
+    with pytest.warns(DeprecationWarning, match=r"laplacian\(\) is deprecated"):
+        assert np.array_equal(T.laplacian()["laplacian"], T.laplacian_matrix()["laplacian"])
