@@ -153,6 +153,22 @@ class TreeNavigation:
             stop = int(parent[stop])
         return self.distance(node_id, stop)
 
+    def distances_to_root_bulk(self, nodes=None) -> np.ndarray:
+        """`distance_to_root` of many nodes (default: all, by id) as ONE batch of the path kernel -- an extension:
+        the reference's callers (`to_networkx_nodes`, MuchTree.pyx:2066) loop over `distance_to_root`."""
+        ids = np.arange(self.size, dtype=np.int64) if nodes is None else np.array([self._validate_node(x) for x in nodes], dtype=np.int64)
+        dist, parent = self._flat.distance, self._flat.parent
+        stops = np.full(len(ids), self.root_node, dtype=np.int64)
+        if np.count_nonzero(dist == -1) > 1:      # a branch of length -1 somewhere: the reference's loop ends there
+            for k, x in enumerate(ids):
+                stop = int(x)
+                while dist[stop] != -1:
+                    stop = int(parent[stop])
+                stops[k] = stop
+        if len(ids) == 0:
+            return np.zeros(0)
+        return self.distances_bulk(np.stack((ids, stops), axis=1))
+
     def path_between_nodes(self, a, b) -> list:
         """Node ids from a to b through their common ancestor (MuchTree.pyx:1421-1461)."""
         node_a, node_b = self._validate_node_pair(a, b)
@@ -335,6 +351,85 @@ class TreeNavigation:
         return {"degrees": degrees, "node_ids": result["node_ids"],
                 "max_degree": degrees.max(), "min_degree": degrees.min()}
 
+    # ------------------------------------------------------------------ exports
+    def to_networkx_nodes(self, from_node=None):
+        """(node id, attributes) for networkx, breadth-first (MuchTree.pyx:2026-2080).  The reference walks every
+        node's lineage twice (distance to root, depth); here the distances to the root are one batch of the path
+        kernel and the depths one pass over the tree."""
+        order = self._breadth_first(self._start_node(from_node))
+        to_root = dict(zip(order, self.distances_to_root_bulk(order).tolist()))
+        depth = dict(self.traverse_with_depth())
+        flat = self._flat
+        for node_id in order:
+            attributes = {}
+            if self._is_leaf(node_id):
+                attributes["type"] = "leaf"
+                attributes["label"] = self.leaf_nodes[node_id]
+            else:
+                attributes["type"] = "internal"
+                attributes["label"] = f"node_{node_id}"
+            support = float(flat.support[node_id])
+            if support != -1:
+                attributes["support"] = support
+            distance = float(flat.distance[node_id])
+            if distance != -1:
+                attributes["distance_to_parent"] = distance
+            attributes["distance_to_root"] = to_root[node_id]
+            attributes["depth"] = depth[node_id]
+            yield (node_id, attributes)
+
+    def to_networkx_edges(self, from_node=None):
+        """(child id, parent id, attributes) for networkx, breadth-first (MuchTree.pyx:2082-2122)."""
+        flat = self._flat
+        for node_id in self._breadth_first(self._start_node(from_node)):
+            parent_id = int(flat.parent[node_id])
+            if parent_id == -1:
+                continue
+            distance = float(flat.distance[node_id])
+            attributes = {"weight": distance, "length": distance}
+            if not self._is_leaf(node_id):
+                support = float(flat.support[node_id])
+                if support != -1:
+                    attributes["support"] = support
+            yield (node_id, parent_id, attributes)
+
+    def to_networkx_graph(self, from_node=None):
+        """MuchTree.pyx:2124-2156."""
+        try:
+            import networkx as nx
+        except ImportError:
+            raise ImportError("NetworkX is required for to_networkx_graph()")
+        G = nx.Graph()
+        for node_id, attributes in self.to_networkx_nodes(from_node):
+            G.add_node(node_id, **attributes)
+        for child_id, parent_id, attributes in self.to_networkx_edges(from_node):
+            G.add_edge(child_id, parent_id, **attributes)
+        return G
+
+    def to_newick(self, from_node=None, include_support: bool = True, include_distances: bool = True) -> str:
+        """Newick text of the tree or a subtree: leaf names, supports behind the closing bracket, lengths as Python
+        prints the float32 values (MuchTree.pyx:2180-2229).  Iterative: the reference's recursion stops at Python's
+        recursion limit on trees a few hundred levels deep."""
+        start = self._start_node(from_node)
+        flat = self._flat
+        text = {}
+        for node_id in self.traverse_postorder(start):
+            l, r = int(flat.left[node_id]), int(flat.right[node_id])
+            if l == -1:
+                result = self.leaf_nodes[node_id]
+            else:
+                result = "(" + text.pop(l) + "," + text.pop(r) + ")"
+                if include_support:
+                    support = float(flat.support[node_id])
+                    if support != -1:
+                        result += str(support)
+            if include_distances and node_id != start:
+                distance = float(flat.distance[node_id])
+                if distance != -1:
+                    result += ":" + str(distance)
+            text[node_id] = result
+        return text[start] + ";"
+
     # ------------------------------------------------------------------ relative evolutionary divergence
     @property
     def relative_evolutionary_divergence(self) -> Dict[int, float]:
@@ -447,3 +542,11 @@ class TreeNavigation:
     def laplacian(self, node: int = -1):
         _deprecated("laplacian()", "laplacian_matrix()")
         return self.laplacian_matrix(None if node == -1 else node)
+
+    def nodes_data(self):
+        _deprecated("nodes_data()", "to_networkx_nodes()")
+        return self.to_networkx_nodes()
+
+    def edges_data(self):
+        _deprecated("edges_data()", "to_networkx_edges()")
+        return self.to_networkx_edges()

@@ -99,3 +99,32 @@ def test_relative_evolutionary_divergence_on_a_deep_tree(ml_arrays):
         want[x] = P + (a / (a + b)) * (1 - P)
     for x, v in want.items():
         assert red[x] == v, (x, red[x], v)
+
+
+def test_networkx_export_and_bulk_distances_to_root():
+    # SuchTree/tests/test_new_api.py:752-790
+    T = SuchTree(golden_path("test.tree"))
+    f = T._flat
+    nodes = list(T.to_networkx_nodes())
+    with pytest.warns(DeprecationWarning, match=r"nodes_data\(\) is deprecated"):
+        assert list(T.nodes_data()) == nodes
+    assert len(nodes) == T.size and [x for x, _ in nodes] == list(T.get_descendants(T.root_node))
+    for node_id, attrs in nodes:
+        assert isinstance(node_id, int) and isinstance(attrs, dict) and attrs["type"] in ("leaf", "internal")
+        assert attrs["type"] == ("leaf" if T.is_leaf(node_id) else "internal")
+        assert attrs["label"] == (T.leaf_nodes[node_id] if T.is_leaf(node_id) else "node_%d" % node_id)
+        assert attrs["distance_to_root"] == oracle.distance_to_root(f.parent, f.distance, node_id)
+        assert attrs["depth"] == len(list(T.get_ancestors(node_id))) and isinstance(attrs["depth"], int)
+        assert ("distance_to_parent" in attrs) == (node_id != T.root_node)
+        assert list(attrs)[:2] == ["type", "label"] and list(attrs)[-2:] == ["distance_to_root", "depth"]
+    all_d = T.distances_to_root_bulk()
+    assert all_d.dtype == np.float64 and all_d.tolist() == [oracle.distance_to_root(f.parent, f.distance, x) for x in range(T.size)]
+    assert T.distances_to_root_bulk(["Ttal", 27]).tolist() == [T.distance_to_root("Ttal"), T.distance_to_root(27)]
+    sub = list(T.to_networkx_nodes(27))
+    assert [x for x, _ in sub] == [27, 26, 28] and sub[1][1]["depth"] == 2
+    nx = pytest.importorskip("networkx")
+    G = T.to_networkx_graph()
+    assert isinstance(G, nx.Graph) and len(G.nodes) == T.size and len(G.edges) == T.size - 1
+    assert G.nodes[T.root_node]["type"] == "internal" and G.edges[26, 27]["weight"] == float(f.distance[26])
+    Z = SuchTree("((A:1,B:2):-1,(C:3,D:4):0.5);")      # a branch of length -1 ends the reference's root-ward loop
+    assert Z.distances_to_root_bulk().tolist() == [oracle.distance_to_root(Z._flat.parent, Z._flat.distance, x) for x in range(Z.size)]

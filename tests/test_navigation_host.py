@@ -192,3 +192,31 @@ def test_graph_matrices(T, S):
         assert np.array_equal(T.adjacency()["adjacency_matrix"], T.adjacency_matrix()["adjacency_matrix"])
     with pytest.warns(DeprecationWarning, match=r"laplacian\(\) is deprecated"):
         assert np.array_equal(T.laplacian()["laplacian"], T.laplacian_matrix()["laplacian"])
+
+
+def test_edges_and_newick_export(T, S):
+    # SuchTree/tests/test_new_api.py:767-806
+    edges = list(T.to_networkx_edges())
+    with pytest.warns(DeprecationWarning, match=r"edges_data\(\) is deprecated"):
+        assert list(T.edges_data()) == edges
+    assert len(edges) == T.size - 1
+    for child, parent, attrs in edges:
+        assert isinstance(child, int) and isinstance(parent, int) and isinstance(attrs, dict)
+        assert T.get_parent(child) == parent and attrs["weight"] == attrs["length"] == float(T._flat.distance[child])
+    text = T.to_newick()
+    assert isinstance(text, str) and text.endswith(";") and "(" in text and ")" in text
+    R = SuchTree(text)
+    assert R.num_leaves == T.num_leaves and R.leaves == T.leaves and R.size == T.size
+    assert np.array_equal(R._flat.parent, T._flat.parent) and np.array_equal(R._flat.distance, T._flat.distance)
+    assert S.to_newick(include_distances=False) == "((C,D),(A,B));"
+    assert S.to_newick() == "((C:2.220446049250313e-16,D:2.220446049250313e-16):2.220446049250313e-16," \
+                            "(A:2.220446049250313e-16,B:2.220446049250313e-16):2.220446049250313e-16);"
+    assert S.to_newick(1, include_distances=False) == "(C,D);" and S.to_newick("A") == "A;"
+    U = SuchTree("((A:1,B:2)0.9:0.5,(C:3,D:4)75:0.25);")
+    assert U.to_newick() == "((A:1.0,B:2.0)" + str(float(np.float32(0.9))) + ":0.5,(C:3.0,D:4.0)75.0:0.25);"
+    assert U.to_newick(include_support=False) == "((A:1.0,B:2.0):0.5,(C:3.0,D:4.0):0.25);"
+    # a caterpillar deeper than Python's recursion limit
+    n = 3000
+    deep = "(" * (n - 1) + "L0:1" + "".join(",L%d:1):1" % i for i in range(1, n))
+    D = SuchTree(deep[:deep.rindex(":")] + ";")
+    assert SuchTree(D.to_newick()).num_leaves == n
