@@ -874,6 +874,37 @@ def test_general_trees_through_the_c_abi():
         dev.close()
 
 
+def test_deep_tree_with_ids_that_are_not_in_order_positions(ml_arrays):
+    """ml.tree with its node ids permuted (what the C ABI accepts, not what the facade produces): no sparse tables, so the
+    scalar ladder kernel and the tile-sorted kernel find the meeting node by the lock-step search -- third ancestors from
+    the ladder image (links are places since round 4), single steps from the 8-byte canopy entries in global memory."""
+    parent, dist, leaf_ids = ml_arrays
+    n = len(parent)
+    rng = np.random.default_rng(11)
+    new_id = rng.permutation(n).astype(np.int64)                 # old id -> new id
+    p2 = np.empty(n, dtype=np.int32)
+    d2 = np.empty(n, dtype=np.float32)
+    p2[new_id] = np.where(parent >= 0, new_id[np.maximum(parent, 0)], -1).astype(np.int32)
+    d2[new_id] = dist
+    pairs = new_id[leaf_ids[rng.integers(0, len(leaf_ids), (300_000, 2))]]
+    pairs[:1000, 1] = pairs[:1000, 0]                            # same node; and neighbours under one portal
+    pairs[1000:3000] = new_id[leaf_ids[np.stack((np.arange(2000), np.arange(2000) + 1), axis=1)]]
+    want_d, want_m = oracle_both(p2, d2, pairs)
+    dev = _capi.DeviceTree(p2, d2, strategy="canopy")
+    assert dev.info()["record_bytes"] >= 128
+    for opts in ({"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "ladder_dynamic": 0},
+                 {"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "ladder_dynamic": 2},
+                 {"tile_sort": 1, "ladder_scalar": 0},
+                 {"tile_sort": 0, "ladder_scalar": 0, "pairs_per_lane": 1},
+                 {"tile_sort": 0, "ladder_scalar": 0, "pairs_per_lane": 0}):
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        d, m = dev.distances_host(pairs, True, True)
+        assert_bits_equal(d, want_d, str(opts))
+        assert np.array_equal(m, want_m), opts
+    dev.close()
+
+
 def test_batch_sizes_around_kernel_tile_boundaries(ml_arrays):
     """Batch lengths at and around every granule the launch code knows: the walk/canopy switch
     (4096 pairs), the 1024-pair workgroup tile, the 2048 / 4096-pair tiles of the tile-sorted
