@@ -1,0 +1,91 @@
+"""Randomised parity hunt on the GPU box: random tree shapes and numberings x random handle options x random batches,
+distances (bit for bit) and MRCA ids against the CPU oracle.  Test infrastructure (it imports oracle/).
+  python scripts/fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+os.environ.setdefault("SUCHTREE_AMD_TUNE_CACHE", "0")
+from suchtree_amd import _capi, synth
+from conftest import oracle_both
+from test_tables_emulated import _general_tree
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.default_rng(seed)
+print("seed", seed, flush=True)
+OPTS = {"pairs_per_lane": (0, 1, 2), "tile_sort": (0, 1), "ladder_scalar": (0, 1), "ladder_dynamic": (0, 1, 2),
+        "ladder_min_pairs": (0, 131072), "tree_rmq": (0, 1), "mrca_ranks": (0, 1), "rec_a4": (0, 1), "walk_ladder": (0, 1),
+        "prefer_walk_sorted": (0, 1), "walk_crown": (0, 1), "walk_sort": (0, 1), "lineage_lens": (0, 1),
+        "lineage_sums": (0, 1), "small_batch_path": (0, 1), "wire24": (0, 1), "wire48": (0, 1)}
+t_end = time.time() + budget
+cases = checks = 0
+while time.time() < t_end:
+    kind = rng.integers(0, 10)
+    if kind == 0:
+        parent, dist = synth.balanced_tree(int(rng.integers(1, 17)))
+    elif kind == 1:
+        parent, dist = _general_tree(rng, int(rng.integers(2, 30000)), int(rng.integers(1, 9)))
+    else:
+        leaves = int(2 ** rng.uniform(1, 17.5))
+        parent, dist = synth.skewed_tree(rng, leaves, float(rng.choice([0.0, 0.2, 0.5, 0.7, 0.8, 0.9, 0.97, 0.995])))
+    n = len(parent)
+    permuted = kind >= 8
+    if permuted:      # ids that are not in-order positions
+        new_id = rng.permutation(n)
+        p2 = np.empty(n, np.int32); d2 = np.empty(n, np.float32)
+        p2[new_id] = np.where(parent >= 0, new_id[np.maximum(parent, 0)], -1); d2[new_id] = dist
+        parent, dist = p2, d2
+    if rng.integers(0, 6) == 0:      # special lengths: zeros, negatives, tiny, huge
+        k = rng.integers(0, n, max(1, n // 10))
+        dist = dist.copy()
+        dist[k] = rng.choice(np.array([0.0, -0.5, 1e-30, 3e37, 2.220446e-16], np.float32), len(k))
+        dist[parent < 0] = -1.0
+    budget_mb = int(rng.choice([0, 0, 0, 1, 4, 16, 64]))
+    strategy = str(rng.choice(["auto", "auto", "canopy", "walk"]))
+    try:
+        dev = _capi.DeviceTree(parent, dist, strategy=strategy, table_mb=budget_mb or None)
+    except Exception as e:      # noqa: BLE001 -- e.g. canopy refused on this shape: say so and go on
+        print("   create refused:", n, strategy, budget_mb, str(e)[:80], flush=True)
+        continue
+    info = dev.info()
+    cases += 1
+    for _ in range(int(rng.integers(1, 5))):
+        chosen = {}
+        for k in rng.choice(list(OPTS), int(rng.integers(0, 6)), replace=False):
+            chosen[str(k)] = int(rng.choice(OPTS[str(k)]))
+            try:
+                dev.set_option(str(k), chosen[str(k)])
+            except Exception as e:      # noqa: BLE001
+                chosen[str(k)] = "refused"
+        m = int(2 ** rng.uniform(0, 19.5))
+        pairs = rng.integers(0, n, (m, 2))
+        mode = rng.integers(0, 4)
+        if mode == 1 and n > 64:
+            a = rng.integers(0, n - 40, m); pairs = np.stack([a, a + rng.integers(0, 40, m)], 1)
+        elif mode == 2:
+            pairs[:, 1] = pairs[:, 0]
+        elif mode == 3:
+            pairs[: m // 2, 0] = int(np.flatnonzero(parent < 0)[0])
+        want_dist, want_mrca = bool(rng.integers(0, 4)), bool(rng.integers(0, 3))
+        if not (want_dist or want_mrca):
+            want_dist = True
+        d, mm = dev.distances_host(pairs, want_dist, want_mrca)
+        wd, wm = oracle_both(parent, dist, pairs)
+        ok = (d is None or np.array_equal(d.view(np.uint64), wd.view(np.uint64)) or
+              np.array_equal(np.nan_to_num(d, nan=-7.0).view(np.uint64), np.nan_to_num(wd, nan=-7.0).view(np.uint64))) and \
+             (mm is None or np.array_equal(mm, wm))
+        checks += 1
+        if not ok:
+            bad_d = None if d is None else np.flatnonzero(d.view(np.uint64) != wd.view(np.uint64))[:5]
+            bad_m = None if mm is None else np.flatnonzero(mm != wm)[:5]
+            print("MISMATCH seed", seed, "case", cases, "n", n, "kind", int(kind), "permuted", permuted, "strategy", strategy,
+                  "budget", budget_mb, "opts", chosen, "pairs", m, "mode", int(mode), "info",
+                  {k: info[k] for k in ("depth", "canopy_nodes", "record_bytes", "strategy", "dropped_tables")},
+                  "bad dist at", bad_d, "bad mrca at", bad_m, flush=True)
+            if bad_d is not None and len(bad_d):
+                i = int(bad_d[0]); print("   pair", pairs[i], "got", d[i], "want", wd[i])
+            if bad_m is not None and len(bad_m):
+                i = int(bad_m[0]); print("   pair", pairs[i], "got", mm[i], "want", wm[i])
+            sys.exit(1)
+    dev.close()
+print("fuzz: %d trees, %d batches, no mismatch" % (cases, checks))
