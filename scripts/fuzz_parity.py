@@ -87,5 +87,58 @@ while time.time() < t_end:
             if bad_m is not None and len(bad_m):
                 i = int(bad_m[0]); print("   pair", pairs[i], "got", mm[i], "want", wm[i])
             sys.exit(1)
+    # the generators and other entry points of the ABI on the same handle (whatever options the last batch left)
+    def same(got, want):
+        return np.array_equal(np.nan_to_num(got, nan=-7.0).view(np.uint64), np.nan_to_num(want, nan=-7.0).view(np.uint64))
+    def fail(what, extra=""):
+        print("MISMATCH seed", seed, "case", cases, what, "n", n, "kind", int(kind), "permuted", permuted, "strategy", strategy,
+              "budget", budget_mb, "opts", chosen, extra, flush=True)
+        sys.exit(1)
+    what = rng.integers(0, 5)
+    if what == 0:      # triangle: pair k = i(i-1)/2 + j -> (ids[j], ids[i])
+        ids = rng.integers(0, n, int(rng.integers(2, 500)))
+        i, j = np.tril_indices(len(ids), -1)
+        wd, wm = oracle_both(parent, dist, np.stack((ids[j], ids[i]), 1))
+        total = len(i)
+        k0 = int(rng.integers(0, total)); cnt = int(rng.integers(1, total - k0 + 1))
+        d, mm = dev.triangle_host(ids, k0, cnt, True, True)
+        if not (same(d, wd[k0:k0 + cnt]) and np.array_equal(mm, wm[k0:k0 + cnt])): fail("triangle", (len(ids), k0, cnt))
+    elif what == 1:      # grid, rectangular and symmetric
+        rows = rng.integers(0, n, int(rng.integers(1, 300))); cols = rng.integers(0, n, int(rng.integers(1, 300)))
+        sym = bool(rng.integers(0, 2))
+        if sym: cols = rows
+        r, c = np.divmod(np.arange(len(rows) * len(cols)), len(cols))
+        a, b = rows[r], cols[c]
+        if sym:
+            a, b = np.where(r <= c, rows[r], rows[c]), np.where(r <= c, rows[c], rows[r])
+        wd, wm = oracle_both(parent, dist, np.stack((a, b), 1))
+        d, mm = dev.grid_host(rows, cols, sym, 0, None, True, True)
+        if not (same(d, wd) and np.array_equal(mm, wm)): fail("grid", (len(rows), len(cols), sym))
+    elif what == 2:      # strides and int32 ids
+        m = int(rng.integers(1, 50000))
+        base = rng.integers(0, n, (m, 6))
+        view = base[:, 1::3] if rng.integers(0, 2) else np.asfortranarray(base[:, :2])
+        wd, wm = oracle_both(parent, dist, np.ascontiguousarray(view))
+        d, mm = dev.distances_host(view, True, True)
+        if not (same(d, wd) and np.array_equal(mm, wm)): fail("strided", view.strides)
+        d, mm = dev.distances_host(np.ascontiguousarray(view).astype(np.int32), True, True)
+        if not (same(d, wd) and np.array_equal(mm, wm)): fail("int32 ids")
+    elif what == 3:      # quartet topologies
+        from oracle.oracle import OracleTree
+        q = rng.integers(0, n, (int(rng.integers(1, 20000)), 4))
+        want = OracleTree(parent, dist).quartets(q)
+        got = dev.quartets_host(q)
+        if not np.array_equal(got, want): fail("quartets")
+    else:      # k nearest: the k smallest distances, ascending
+        qs = rng.integers(0, n, int(rng.integers(1, 40))); cs = rng.integers(0, n, int(rng.integers(1, 400)))
+        k = int(rng.integers(1, min(len(cs), 16) + 1))
+        index, dd = dev.knn_host(qs, cs, k)
+        r, c = np.divmod(np.arange(len(qs) * len(cs)), len(cs))
+        wd, _ = oracle_both(parent, dist, np.stack((qs[r], cs[c]), 1))
+        wd = wd.reshape(len(qs), len(cs))
+        for row in range(len(qs)):
+            want = np.sort(wd[row], kind="stable")[:k]
+            if not (same(dd[row], want) and same(wd[row][index[row]], want)): fail("knn", (row, k, dd[row], want))
+    checks += 1
     dev.close()
 print("fuzz: %d trees, %d batches, no mismatch" % (cases, checks))
