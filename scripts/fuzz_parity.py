@@ -1,6 +1,6 @@
 """Randomised parity hunt on the GPU box: random tree shapes and numberings x random handle options x random batches,
 distances (bit for bit) and MRCA ids against the CPU oracle.  Test infrastructure (it imports oracle/).
-  python scripts/fuzz_parity.py [seconds] [seed]"""
+  python scripts/fuzz_parity.py [seconds] [seed] [big]      (big: 2^14 .. 2^20 leaves, mostly deep shapes)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -10,7 +10,8 @@ from conftest import oracle_both
 from test_tables_emulated import _general_tree
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+seed = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) else int(time.time())
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 OPTS = {"pairs_per_lane": (0, 1, 2), "tile_sort": (0, 1), "ladder_scalar": (0, 1), "ladder_dynamic": (0, 1, 2),
@@ -21,7 +22,10 @@ t_end = time.time() + budget
 cases = checks = 0
 while time.time() < t_end:
     kind = rng.integers(0, 10)
-    if kind == 0:
+    if big:
+        kind = max(int(kind), 2)
+        parent, dist = synth.skewed_tree(rng, int(2 ** rng.uniform(14, 20)), float(rng.choice([0.0, 0.5, 0.7, 0.8, 0.85, 0.9, 0.93])))
+    elif kind == 0:
         parent, dist = synth.balanced_tree(int(rng.integers(1, 17)))
     elif kind == 1:
         parent, dist = _general_tree(rng, int(rng.integers(2, 30000)), int(rng.integers(1, 9)))
@@ -57,7 +61,7 @@ while time.time() < t_end:
                 dev.set_option(str(k), chosen[str(k)])
             except Exception as e:      # noqa: BLE001
                 chosen[str(k)] = "refused"
-        m = int(2 ** rng.uniform(0, 19.5))
+        m = int(2 ** rng.uniform(0, 19.5)) if not big else int(2 ** rng.uniform(12, 21))
         pairs = rng.integers(0, n, (m, 2))
         mode = rng.integers(0, 4)
         if mode == 1 and n > 64:
