@@ -354,6 +354,24 @@ int st_host_depths(const int32_t *parent, int64_t n_nodes, int32_t *out_depths,
                    int32_t *out_tree_depth);
 
 /*
+ * Host-only helper, no GPU needed: the link-pair draws of SuchLinkedTrees.sample_linked_distances
+ * (SuchTree/MuchTree.pyx:3025-3038) with the reference's own generator, xorshift64* (`_random_int`, :2937-2949:
+ * state ^= state >> 12; state ^= state << 25; state ^= state >> 27; draw = (state * 2685821657736338717) % n_links).
+ * For each of `count` samples two draws l1, l2 in that order; query_a[k] = (linklist[l1][1], linklist[l2][1]),
+ * query_b[k] = (linklist[l1][0], linklist[l2][0]); `linklist` is (n_links, 2) int64, row-major.  `state` is read and
+ * left at the generator's state after the last draw, so consecutive calls continue one sequence.
+ */
+int st_link_sample_pairs(uint64_t *state, const int64_t *linklist, int64_t n_links, int64_t count,
+                         int64_t *query_a, int64_t *query_b);
+
+/*
+ * Host-only helper: the per-bucket running moments of sample_linked_distances (SuchTree/MuchTree.pyx:3044-3048 as
+ * compiled, SuchTree/MuchTree.c:65197-65242): for i < buckets, j < n in that order
+ * sums[i] += dist[i * n + j]; sumsq[i] += pow(dist[i * n + j], 2.0) -- doubles, the C library's pow.
+ */
+int st_bucket_moments(const double *dist, int64_t buckets, int64_t n, double *sums, double *sumsq);
+
+/*
  * Native Newick ingest (host only).  Replaces the dendropy calls of SuchTree.__init__
  * (SuchTree/MuchTree.pyx:138-157, 171-216): first tree of the text, polytomies resolved,
  * nodes numbered in order.  st_newick_open parses and reports sizes; st_newick_fill copies

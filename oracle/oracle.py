@@ -334,3 +334,60 @@ def relative_evolutionary_divergence(tree, left, right, root):
             raise Exception("node {n} : a={a}, b={b}".format(n=node, a=a, b=b))
         red[node] = P + (a / (a + b)) * (1 - P)
     return red
+
+
+def xorshift64star(state, n):
+    """MuchTree.pyx:2937-2949 (_random_int): one draw; returns (new state, draw)."""
+    mask = 0xFFFFFFFFFFFFFFFF
+    state ^= state >> 12
+    state ^= (state << 25) & mask
+    state ^= state >> 27
+    return state, ((state * 2685821657736338717) & mask) % n
+
+
+def sample_linked_distances(tree_a, tree_b, linklist, seed, sigma=0.001, buckets=64, n=4096, maxcycles=100):
+    """MuchTree.pyx:2951-3079 loop by loop, in the arithmetic of the compiled extension (SuchTree/MuchTree.c:65197-65505:
+    doubles for the bucket moments, C floats for the four accumulators over the buckets, pow / powf for squares and
+    roots).  `tree_a` / `tree_b` are OracleTrees, `seed` the generator's state.  Returns (result or None, state)."""
+    import math
+    f32 = np.float32
+    sums_a, sums_b = [0.0] * buckets, [0.0] * buckets
+    sumsq_a, sumsq_b = [0.0] * buckets, [0.0] * buckets
+    samples = [0] * buckets
+    dev_a, dev_b = [0.0] * buckets, [0.0] * buckets
+    all_a, all_b = [], []
+    cycles = 0
+    root = lambda x: math.pow(x, 0.5) if x >= 0 else float("nan")      # C pow: NaN, no exception
+    while True:
+        for i in range(buckets):
+            qa, qb = np.zeros((n, 2), dtype=np.int64), np.zeros((n, 2), dtype=np.int64)
+            for j in range(n):
+                seed, l1 = xorshift64star(seed, len(linklist))
+                seed, l2 = xorshift64star(seed, len(linklist))
+                qa[j] = (linklist[l1][1], linklist[l2][1])
+                qb[j] = (linklist[l1][0], linklist[l2][0])
+            da, db = tree_a.distances(qa), tree_b.distances(qb)
+            all_a.extend(da.tolist()); all_b.extend(db.tolist())
+            for j in range(n):
+                sums_a[i] += float(da[j]); sums_b[i] += float(db[j])
+                sumsq_a[i] += math.pow(float(da[j]), 2.0); sumsq_b[i] += math.pow(float(db[j]), 2.0)
+            samples[i] += n
+            dev_a[i] = root(sumsq_a[i] / float(samples[i]) - math.pow(sums_a[i] / float(samples[i]), 2.0))
+            dev_b[i] = root(sumsq_b[i] / float(samples[i]) - math.pow(sums_b[i] / float(samples[i]), 2.0))
+        deviation_a = deviation_b = sq_a = sq_b = f32(0.0)
+        for i in range(buckets):
+            deviation_a = f32(float(deviation_a) + dev_a[i])
+            deviation_b = f32(float(deviation_b) + dev_b[i])
+            sq_a = f32(float(sq_a) + math.pow(dev_a[i], 2.0))
+            sq_b = f32(float(sq_b) + math.pow(dev_b[i], 2.0))
+        ma, mb = f32(deviation_a / f32(buckets)), f32(deviation_b / f32(buckets))
+        deviation_a = f32(root(float(f32(f32(sq_a / f32(buckets)) - f32(ma * ma)))))
+        deviation_b = f32(root(float(f32(f32(sq_b / f32(buckets)) - f32(mb * mb)))))
+        cycles += 1
+        if deviation_a < sigma and deviation_b < sigma:
+            break
+        if cycles >= maxcycles:
+            return None, seed
+    L = len(linklist)
+    return {"TreeA": np.array(all_a), "TreeB": np.array(all_b), "n_pairs": (L * (L - 1)) / 2, "n_samples": n * buckets * cycles,
+            "deviation_a": float(deviation_a), "deviation_b": float(deviation_b)}, seed

@@ -39,7 +39,7 @@ SYMBOLS = (
     "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_distances_device_wire", "st_unpack_mrca24_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
-    "st_host_depths", "st_host_alloc", "st_host_free", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
+    "st_host_depths", "st_link_sample_pairs", "st_bucket_moments", "st_host_alloc", "st_host_free", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
 
@@ -195,6 +195,8 @@ def load():
         L.st_newick_close.argtypes = [vp]
         L.st_newick_close.restype = None
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
+        L.st_link_sample_pairs.argtypes = [ctypes.POINTER(ctypes.c_uint64), vp, i64, i64, vp, vp]
+        L.st_bucket_moments.argtypes = [vp, i64, i64, vp, vp]
         L.st_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
         L.st_host_free.argtypes = [vp]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
@@ -277,6 +279,24 @@ def newick_native(text):
         return out
     finally:
         L.st_newick_close(h)
+
+
+def link_sample_pairs(state, linklist, count):
+    """(query_a, query_b, new_state): `count` link-pair draws of the reference's xorshift64* generator
+    (st_link_sample_pairs; MuchTree.pyx:2937-2949, 3025-3038).  Host only."""
+    ll = np.ascontiguousarray(linklist, dtype=np.int64)
+    qa = np.empty((int(count), 2), dtype=np.int64)
+    qb = np.empty((int(count), 2), dtype=np.int64)
+    st = ctypes.c_uint64(int(state) & 0xFFFFFFFFFFFFFFFF)
+    check(load().st_link_sample_pairs(ctypes.byref(st), ll.ctypes.data, int(ll.shape[0]), int(count), qa.ctypes.data, qb.ctypes.data))
+    return qa, qb, int(st.value)
+
+
+def bucket_moments(dist, sums, sumsq):
+    """sums[i] += d, sumsq[i] += pow(d, 2.0) over the rows of `dist` (buckets, n), in place (st_bucket_moments)."""
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    assert sums.dtype == np.float64 and sumsq.dtype == np.float64 and sums.flags.c_contiguous and sumsq.flags.c_contiguous
+    check(load().st_bucket_moments(d.ctypes.data, int(d.shape[0]), int(d.shape[1]), sums.ctypes.data, sumsq.ctypes.data))
 
 
 def host_chunk_map(n, n_devices):

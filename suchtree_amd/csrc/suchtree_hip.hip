@@ -173,6 +173,42 @@ try {
     return ST_OK;
 } ST_CATCH_ALL
 
+int st_link_sample_pairs(uint64_t *state, const int64_t *linklist, int64_t n_links, int64_t count, int64_t *query_a,
+                         int64_t *query_b)
+try {
+    if (!state || !linklist || n_links < 1 || count < 0 || (count > 0 && (!query_a || !query_b)))
+        return fail(ST_ERR_ARG, "state / linklist / query arrays are NULL, n_links < 1 or count < 0");
+    uint64_t s = *state;
+    auto draw = [&]() -> int64_t {      // MuchTree.pyx:2946-2949
+        s ^= s >> 12;
+        s ^= s << 25;
+        s ^= s >> 27;
+        return (int64_t)((s * 2685821657736338717ull) % (uint64_t)n_links);
+    };
+    for (int64_t k = 0; k < count; k++) {
+        const int64_t l1 = draw(), l2 = draw();
+        query_a[2 * k] = linklist[2 * l1 + 1];
+        query_a[2 * k + 1] = linklist[2 * l2 + 1];
+        query_b[2 * k] = linklist[2 * l1];
+        query_b[2 * k + 1] = linklist[2 * l2];
+    }
+    *state = s;
+    return ST_OK;
+} ST_CATCH_ALL
+
+int st_bucket_moments(const double *dist, int64_t buckets, int64_t n, double *sums, double *sumsq)
+try {
+    if (buckets < 0 || n < 0 || (buckets > 0 && n > 0 && (!dist || !sums || !sumsq)))
+        return fail(ST_ERR_ARG, "dist / sums / sumsq are NULL or a size is negative");
+    for (int64_t i = 0; i < buckets; i++)
+        for (int64_t j = 0; j < n; j++) {
+            const double d = dist[i * n + j];
+            sums[i] += d;
+            sumsq[i] += std::pow(d, 2.0);
+        }
+    return ST_OK;
+} ST_CATCH_ALL
+
 int st_host_chunk_plan(int64_t n, int n_devices, int64_t *chunk_pairs, int64_t *n_chunks)
 try {
     if (n < 0 || n_devices < 1) return fail(ST_ERR_ARG, "n < 0 or n_devices < 1");

@@ -13,6 +13,7 @@ from typing import Dict
 
 import numpy as np
 
+from . import _capi
 from .suchtree import SuchTree
 
 
@@ -75,6 +76,7 @@ class SuchLinkedTrees:
         self._subset_b_leafs = self._col_ids
         self._np_linklist = np.ndarray((self._n_links, 2), dtype=int)
         self._subset_n_links = 0
+        self._seed = int(np.random.randint(0xFFFFFFFFFFFFFFFF >> 1))      # xorshift64* state (pyx:2572)
         self._build_linklist()
 
     # ------------------------------------------------------------ properties
@@ -198,55 +200,57 @@ class SuchLinkedTrees:
                 "n_pairs": size, "n_samples": size, "deviation_a": None, "deviation_b": None}
 
     def sample_linked_distances(self, sigma=0.001, buckets=64, n=4096, maxcycles=100, seed=None):
-        """Monte-Carlo form of :meth:`linked_distances` (pyx:2952-3079): cycles of ``buckets`` x ``n``
-        random link pairs, distances in both trees, until the spread of the per-bucket standard
-        deviations falls below ``sigma`` in both trees (``None`` after ``maxcycles`` cycles).
+        """Monte-Carlo form of :meth:`linked_distances` (pyx:2951-3079): cycles of ``buckets`` x ``n`` random link
+        pairs, distances in both trees, until the spread of the per-bucket standard deviations falls below ``sigma``
+        in both trees (``None`` after ``maxcycles`` cycles).
 
-        Same algorithm and stop rule; what differs from the reference is the generator (numpy's
-        instead of its xorshift64*, so individual samples are not reproducible across the two)
-        and the batching: one cycle is a single launch per tree (``buckets*n`` pairs) instead of
-        ``buckets`` calls of ``n`` pairs.
+        The reference's algorithm in the reference's arithmetic: link pairs from its xorshift64* generator
+        (``st_link_sample_pairs``; the generator's state lives in the object as it does there and starts at a random
+        value -- ``seed=`` sets it, an extension, so that a run can be repeated), the running sums in doubles
+        element by element, the four bucket accumulators in C floats, ``pow`` for squares and roots
+        (SuchTree/MuchTree.c:65197-65505).  What differs is the batching: one cycle is one launch per tree
+        (``buckets * n`` pairs) instead of ``buckets`` calls of ``n`` pairs.
         """
-        rng = np.random.default_rng(seed)
+        import math
+        if seed is not None:
+            self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         ll = np.ascontiguousarray(self.linklist, dtype=np.int64)
-        L = ll.shape[0]
-        if L < 1:
+        if ll.shape[0] < 1:
             raise ValueError("no links in the current subset")
+        buckets, n = int(buckets), int(n)
         sums_a, sums_b = np.zeros(buckets), np.zeros(buckets)
         sumsq_a, sumsq_b = np.zeros(buckets), np.zeros(buckets)
         samples = 0
         all_a, all_b = [], []
         cycles = 0
+
+        def c_pow_half(x):      # C pow(x, 0.5): NaN for negative x, no exception
+            return math.pow(x, 0.5) if x >= 0 else float("nan")
+
+        f32 = np.float32
         while True:
-            l1 = rng.integers(0, L, size=buckets * n)
-            l2 = rng.integers(0, L, size=buckets * n)
-            query_a = np.stack([ll[l1, 1], ll[l2, 1]], axis=1)
-            query_b = np.stack([ll[l1, 0], ll[l2, 0]], axis=1)
+            query_a, query_b, self._seed = _capi.link_sample_pairs(self._seed, ll, buckets * n)
             d_a = self._tree_a.distances_bulk(query_a).reshape(buckets, n)
             d_b = self._tree_b.distances_bulk(query_b).reshape(buckets, n)
             all_a.append(d_a.ravel())
             all_b.append(d_b.ravel())
-            # running sums per bucket, accumulated element by element like the reference's loop
-            sums_a += np.cumsum(d_a, axis=1)[:, -1]
-            sums_b += np.cumsum(d_b, axis=1)[:, -1]
-            sumsq_a += np.cumsum(d_a ** 2, axis=1)[:, -1]
-            sumsq_b += np.cumsum(d_b ** 2, axis=1)[:, -1]
+            # sums[i] += d[i, j]; sumsq[i] += pow(d[i, j], 2.0), element by element onto the running values (pyx:3044-3048)
+            _capi.bucket_moments(d_a, sums_a, sumsq_a)
+            _capi.bucket_moments(d_b, sums_b, sumsq_b)
             samples += n
-            with np.errstate(invalid="ignore"):
-                dev_a = (sumsq_a / samples - (sums_a / samples) ** 2) ** 0.5
-                dev_b = (sumsq_b / samples - (sums_b / samples) ** 2) ** 0.5
-            # the reference keeps these four accumulators in C floats
-            acc_a = acc_b = sq_a = sq_b = np.float32(0)
+            dev_a = [c_pow_half(float(sumsq_a[i]) / float(samples) - math.pow(float(sums_a[i]) / float(samples), 2.0)) for i in range(buckets)]
+            dev_b = [c_pow_half(float(sumsq_b[i]) / float(samples) - math.pow(float(sums_b[i]) / float(samples), 2.0)) for i in range(buckets)]
+            # C floats: x = (float)((double)x + y)
+            acc_a = acc_b = sq_a = sq_b = f32(0)
             for i in range(buckets):
-                acc_a = np.float32(acc_a + np.float32(dev_a[i]))
-                acc_b = np.float32(acc_b + np.float32(dev_b[i]))
-                sq_a = np.float32(sq_a + np.float32(dev_a[i] ** 2))
-                sq_b = np.float32(sq_b + np.float32(dev_b[i] ** 2))
-            with np.errstate(invalid="ignore"):
-                deviation_a = np.float32((float(sq_a) / buckets - (float(acc_a) / buckets) ** 2) ** 0.5) \
-                    if (float(sq_a) / buckets - (float(acc_a) / buckets) ** 2) >= 0 else np.float32("nan")
-                deviation_b = np.float32((float(sq_b) / buckets - (float(acc_b) / buckets) ** 2) ** 0.5) \
-                    if (float(sq_b) / buckets - (float(acc_b) / buckets) ** 2) >= 0 else np.float32("nan")
+                acc_a = f32(float(acc_a) + dev_a[i])
+                acc_b = f32(float(acc_b) + dev_b[i])
+                sq_a = f32(float(sq_a) + math.pow(dev_a[i], 2.0))
+                sq_b = f32(float(sq_b) + math.pow(dev_b[i], 2.0))
+            # (float)pow((double)(sq / (float)buckets - powf(acc / (float)buckets, 2.0f)), 0.5)
+            mean_a, mean_b = f32(acc_a / f32(buckets)), f32(acc_b / f32(buckets))
+            deviation_a = f32(c_pow_half(float(f32(f32(sq_a / f32(buckets)) - f32(mean_a * mean_a)))))
+            deviation_b = f32(c_pow_half(float(f32(f32(sq_b / f32(buckets)) - f32(mean_b * mean_b)))))
             cycles += 1
             if deviation_a < sigma and deviation_b < sigma:
                 break

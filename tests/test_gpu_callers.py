@@ -236,6 +236,48 @@ def test_config5_linked_distances(which):
         assert L == 191 and res["n_pairs"] == 18145
 
 
+@pytest.mark.parametrize("which", ["gopher_louse", "fish_worm"])
+def test_sample_linked_distances_against_the_restatement(which):
+    """SuchLinkedTrees.sample_linked_distances (MuchTree.pyx:2951-3079, a caller of distances_bulk at :3039-3040): the
+    reference's generator, its draws, its bucket moments and its stop rule -- against oracle.sample_linked_distances,
+    the same loops in pure Python over the CPU oracle's distances, from the same generator state.  Everything the
+    reference returns must be identical, and the generator must be left in the same state."""
+    from oracle.oracle import sample_linked_distances
+    d = golden_path(which)
+    names = ("gopher.tree", "lice.tree") if which == "gopher_louse" else ("host.tree", "guest.tree")
+    links = pd.read_csv(d + "/links.csv", index_col=0)
+    SLT = SuchLinkedTrees(SuchTree(d + "/" + names[0]), SuchTree(d + "/" + names[1]), links)
+    fa, fb = SLT.TreeA._flat, SLT.TreeB._flat
+    OA, OB = OracleTree(fa.parent, fa.distance), OracleTree(fb.parent, fb.distance)
+    ll = [tuple(int(x) for x in row) for row in SLT.linklist]
+    for seed, sigma, buckets, n, maxcycles in ((12345678901234567, 0.05, 8, 128, 30), (2 ** 63 - 25, 1e-9, 4, 64, 3),
+                                               (977, 0.02, 16, 256, 40)):
+        want, state = sample_linked_distances(OA, OB, ll, seed, sigma, buckets, n, maxcycles)
+        got = SLT.sample_linked_distances(sigma=sigma, buckets=buckets, n=n, maxcycles=maxcycles, seed=seed)
+        assert SLT._seed == state
+        if want is None:
+            assert got is None      # did not converge within maxcycles (pyx:3071)
+            continue
+        assert list(got) == ["TreeA", "TreeB", "n_pairs", "n_samples", "deviation_a", "deviation_b"]
+        assert_bits_equal(got["TreeA"], want["TreeA"])
+        assert_bits_equal(got["TreeB"], want["TreeB"])
+        for k in ("n_pairs", "n_samples", "deviation_a", "deviation_b"):
+            assert got[k] == want[k], k
+        assert got["n_samples"] == len(got["TreeA"]) and got["n_samples"] % (buckets * n) == 0
+        assert got["deviation_a"] < sigma and got["deviation_b"] < sigma
+    # without seed= the sequence continues from where the object's generator is (pyx:2572: the state lives in the object)
+    state = SLT._seed
+    want, after = sample_linked_distances(OA, OB, ll, state, 0.05, 8, 128, 30)
+    got = SLT.sample_linked_distances(sigma=0.05, buckets=8, n=128, maxcycles=30)
+    assert SLT._seed == after and (want is None) == (got is None)
+    if want is not None:
+        assert_bits_equal(got["TreeA"], want["TreeA"])
+    # the sampled distances estimate the exhaustive ones (what the method is for)
+    full = SLT.linked_distances()
+    est = SLT.sample_linked_distances(sigma=0.01, buckets=16, n=1024, seed=5)
+    assert est is not None and abs(est["TreeA"].mean() - np.concatenate((full["TreeA"], full["TreeA"], np.zeros(SLT.n_links))).mean()) < 0.05 * full["TreeA"].mean() + 0.05
+
+
 def test_quartet_topologies(ml_arrays):
     parent, dist, leaf_ids = ml_arrays
     T = SuchTree((parent, dist))
