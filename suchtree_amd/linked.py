@@ -328,7 +328,13 @@ class SuchLinkedTrees:
         return self._matrices(deletions, additions, swaps, on_gpu, False, True)[1]
 
     def spectrum(self, deletions=0, additions=0, swaps=0, on_gpu=True) -> np.ndarray:
-        """Eigenvalues of the Laplacian (the reference calls LAPACK dsyev, pyx:3147-3173; the
-        eigen-solve stays on the host)."""
-        return np.linalg.eigvalsh(self.laplacian(deletions=deletions, additions=additions, swaps=swaps,
-                                                 on_gpu=on_gpu))
+        """Eigenvalues of the Laplacian by LAPACK's dsyev, as the reference calls it (pyx:3147-3173: jobz 'N', uplo 'U',
+        workspace (4 + 2) N; scipy's LAPACK, the library the reference's `cython_lapack.dsyev` binds); the LAPACK info
+        code if the solver fails.  The eigen-solve stays on the host."""
+        lp = self.laplacian(deletions=deletions, additions=additions, swaps=swaps, on_gpu=on_gpu)
+        try:
+            from scipy.linalg.lapack import dsyev
+        except ImportError:      # no scipy: numpy's symmetric solver (dsyevd), same values to rounding
+            return np.linalg.eigvalsh(lp)
+        w, _, info = dsyev(lp, compute_v=0, lower=0, lwork=6 * lp.shape[0])
+        return w if info == 0 else info

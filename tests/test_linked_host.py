@@ -68,6 +68,11 @@ def test_fish_worm_sizes_and_laplacian_shape():
     assert (aj[41:, :41] > 0).sum() == 191
     ev = SLT.spectrum(on_gpu=False)
     assert ev.shape == (422,) and abs(ev[0]) < 1e-9
+    # LAPACK's dsyev with the reference's arguments (pyx:3165: 'N', 'U', lwork = 6 N), ascending eigenvalues
+    from scipy.linalg.lapack import dsyev
+    w, _, info = dsyev(lp, compute_v=0, lower=0, lwork=6 * 422)
+    assert info == 0 and np.array_equal(ev, w) and np.all(np.diff(ev) >= 0)
+    assert np.allclose(ev, np.linalg.eigvalsh(lp), atol=1e-10)
     # the oracle's dense-block restatement of MuchTree.pyx:1750-1813 + 3081-3145 (no shared code)
     from oracle.oracle import linked_adjacency, linked_laplacian
     fa, fb = SLT.TreeA._flat, SLT.TreeB._flat
