@@ -56,6 +56,8 @@ class SuchLinkedTrees:
         # leaf id -> link-table column (the reference stores it in the leaf's right_child, pyx:1993-2003)
         self._col_of_leaf_b = {int(leaf): i for i, leaf in enumerate(self._col_ids)}
         self._row_of_leaf_a = {int(leaf): i for i, leaf in enumerate(self._row_ids)}
+        for i, leaf in enumerate(self._col_ids):      # TreeB's leaves know their columns (pyx:2639)
+            B.link_leaf(int(leaf), i)
 
         # the link table: per TreeB column (in TreeB leaf order) the linked TreeA leaf ids, in the
         # row order of the DataFrame (pyx:2637-2653)
@@ -338,3 +340,23 @@ class SuchLinkedTrees:
             return np.linalg.eigvalsh(lp)
         w, _, info = dsyev(lp, compute_v=0, lower=0, lwork=6 * lp.shape[0])
         return w if info == 0 else info
+
+    def to_igraph(self, deletions=0, additions=0, swaps=0):
+        """The current subgraph as a weighted, labelled igraph object (pyx:3175-3198); igraph must be installed."""
+        try:
+            from igraph import ADJ_UNDIRECTED, Graph
+        except ImportError:
+            raise Exception("igraph package not installed.")
+        g = Graph.Weighted_Adjacency(self.adjacency(deletions=deletions, additions=additions, swaps=swaps).tolist(),
+                                     mode=ADJ_UNDIRECTED)
+        na = len(list(self._tree_a.get_descendants(self._subset_a_root)))
+        nb = len(list(self._tree_b.get_descendants(self._subset_b_root)))
+        g.vs["color"] = ["#e1e329ff"] * na + ["#24878dff"] * nb
+        g.vs["label"] = ["h" + str(i) for i in range(na)] + ["g" + str(i) for i in range(nb)]
+        g.vs["tree"] = [0] * na + [1] * nb
+        return g
+
+    def dump_table(self) -> None:
+        """Print the link matrix, one line per TreeB column (pyx:3200-3208)."""
+        for i in range(self._n_cols):
+            print("column", i, ":", ",".join(str(int(x)) for x in self._table[i]))

@@ -501,6 +501,57 @@ class TreeNavigation:
         self.RED = red
         return self.RED
 
+    # ------------------------------------------------------------------ leftovers of the reference's surface
+    def relationships(self):
+        """pandas DataFrame of all leaf pairs: distance, MRCA, and the distances of a, b and the MRCA to the root and of
+        a and b to the MRCA (MuchTree.pyx:2158-2178, the definition that works; the later one at :2515 forwards to a
+        method that does not exist).  Every column is one batch of the path kernels where the reference loops."""
+        import pandas as pd
+        from itertools import combinations
+        from random import sample
+        pairs = [sample([a, b], 2) for a, b in combinations(self.leaves.keys(), 2)]
+        first, second = [p[0] for p in pairs], [p[1] for p in pairs]
+        ids = np.array([(self.leaves[a], self.leaves[b]) for a, b in pairs], dtype=np.int64).reshape(-1, 2)
+        distances, mrca = (self.distances_and_ancestors_bulk(ids) if len(ids) else (np.zeros(0), np.zeros(0, dtype=np.int32)))
+        mrca = [int(m) for m in mrca]
+        mrca_to_root = self.distances_to_root_bulk(mrca).tolist()
+        a_to_root = self.distances_to_root_bulk(ids[:, 0].tolist()).tolist()
+        b_to_root = self.distances_to_root_bulk(ids[:, 1].tolist()).tolist()
+        return pd.DataFrame({"a": first, "b": second, "distance": distances.tolist(),
+                             "a_to_root": a_to_root, "b_to_root": b_to_root, "mrca": mrca, "mrca_to_root": mrca_to_root,
+                             "a_to_mrca": [x - m for x, m in zip(a_to_root, mrca_to_root)],
+                             "b_to_mrca": [x - m for x, m in zip(b_to_root, mrca_to_root)]})
+
+    def dump_array(self) -> None:
+        """Print the node table (MuchTree.pyx:2231-2240)."""
+        f = self._flat
+        for n in range(self.size):
+            print("id : %d ->" % n)
+            print("   distance    : %0.3f" % f.distance[n])
+            print("   parent      : %d" % f.parent[n])
+            print("   left child  : %d" % f.left[n])
+            print("   right child : %d" % f.right[n])
+
+    def link_leaf(self, leaf_id: int, col_id: int) -> None:
+        """Attach a leaf to a column of a SuchLinkedTrees link matrix (MuchTree.pyx:1993-2003; the reference keeps the
+        column index in the leaf's unused right-child slot, here it is a dict beside the tree)."""
+        leaf_id = int(leaf_id)
+        if not (0 <= leaf_id < self.size) or not self._is_leaf(leaf_id):
+            raise Exception("Cannot link non-leaf node.", leaf_id)
+        if leaf_id not in self.leaf_nodes:
+            raise Exception("Unknown leaf id.", leaf_id)
+        if getattr(self, "_linked_columns", None) is None:
+            self._linked_columns = {}
+        self._linked_columns[leaf_id] = int(col_id)
+
+    def get_links(self, leaf_ids) -> np.ndarray:
+        """Column ids for an array of leaf ids (MuchTree.pyx:2005-2014); -1 for a leaf that was never linked (the
+        reference reads the leaf's right child there, which is -1)."""
+        if not set(int(x) for x in leaf_ids) <= set(self.leaves.values()):
+            raise Exception("Unknown leaf id(s).", leaf_ids)
+        cols = getattr(self, "_linked_columns", None) or {}
+        return np.array([cols.get(int(x), -1) for x in leaf_ids], dtype=int)
+
     # ------------------------------------------------------------------ deprecated names (MuchTree.pyx:2416-2497)
     def get_lineage(self, node):
         _deprecated("get_lineage()", "get_ancestors()")

@@ -519,3 +519,11 @@ class SuchTree(TreeNavigation):
     def mrca(self, a: Union[int, str], b: Union[int, str]) -> int:
         _deprecation_warning("mrca()", "common_ancestor()")
         return self.common_ancestor(a, b)
+
+    def get_quartet_topology(self, a, b, c, d):
+        _deprecation_warning("get_quartet_topology()", "quartet_topology()")
+        return self.quartet_topology(a, b, c, d)
+
+    def quartet_topologies(self, quartets):
+        _deprecation_warning("quartet_topologies()", "quartet_topologies_bulk()")
+        return self.quartet_topologies_bulk(quartets)

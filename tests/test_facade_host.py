@@ -161,3 +161,27 @@ def test_names_extension_matches_the_python_loop():
         _names.lookup_pairs(pairs, leaves, np.empty(10, dtype=np.int64))              # buffer too small
     with pytest.raises(TypeError):
         _names.lookup_pairs(tuple(pairs), leaves, out)                                # not a list
+
+
+def test_surface_is_complete():
+    """Every public method / property name of the reference's SuchTree and SuchLinkedTrees (the names listed here were
+    read off SuchTree/MuchTree.pyx; the file itself does not travel) exists on the facade's classes."""
+    from suchtree_amd import SuchLinkedTrees
+    tree_names = """RED adjacency adjacency_matrix all_nodes bipartition bipartitions common_ancestor degree_sequence depth
+        distance distance_matrix distance_to_root distances distances_bulk distances_by_name dump_array edges_data
+        get_ancestors get_bipartition get_children get_descendant_nodes get_descendants get_distance_to_root
+        get_internal_nodes get_leafs get_leaves get_lineage get_links get_nodes get_parent get_quartet_topology
+        get_support has_children has_parent in_order incidence_matrix internal_nodes is_ancestor is_descendant
+        is_internal is_internal_node is_leaf is_root is_sibling laplacian laplacian_matrix leaf_names leaf_node_ids
+        leaf_nodes leafnodes leafs leaves length link_leaf mrca n_leafs nearest_neighbors nodes_data num_leaves
+        pairwise_distances path_between_nodes polytomy_distance polytomy_epsilon pre_order quartet_topologies
+        quartet_topologies_bulk quartet_topologies_by_name quartet_topology relationships
+        relative_evolutionary_divergence root root_node size to_networkx_edges to_networkx_graph to_networkx_nodes
+        to_newick traverse_inorder traverse_internal_only traverse_leaves_only traverse_levelorder traverse_postorder
+        traverse_preorder traverse_with_depth traverse_with_distances""".split()
+    slt_names = """TreeA TreeB adjacency col_ids col_names dump_table get_column_leafs get_column_links laplacian
+        linked_distances linklist linkmatrix n_cols n_links n_rows row_ids row_names sample_linked_distances spectrum
+        subset_a subset_a_leafs subset_a_root subset_a_size subset_b subset_b_leafs subset_b_root subset_b_size
+        subset_columns subset_n_links to_igraph""".split()
+    assert [x for x in tree_names if not hasattr(SuchTree, x)] == []
+    assert [x for x in slt_names if not hasattr(SuchLinkedTrees, x)] == []

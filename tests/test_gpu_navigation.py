@@ -128,3 +128,28 @@ def test_networkx_export_and_bulk_distances_to_root():
     assert G.nodes[T.root_node]["type"] == "internal" and G.edges[26, 27]["weight"] == float(f.distance[26])
     Z = SuchTree("((A:1,B:2):-1,(C:3,D:4):0.5);")      # a branch of length -1 ends the reference's root-ward loop
     assert Z.distances_to_root_bulk().tolist() == [oracle.distance_to_root(Z._flat.parent, Z._flat.distance, x) for x in range(Z.size)]
+
+
+def test_relationships_and_deprecated_quartet_names():
+    """relationships (MuchTree.pyx:2158-2178): every column against the facade's own single calls and the oracle."""
+    T = SuchTree(golden_path("test.tree"))
+    f = T._flat
+    R = T.relationships()
+    n = T.num_leaves
+    assert list(R.columns) == ["a", "b", "distance", "a_to_root", "b_to_root", "mrca", "mrca_to_root", "a_to_mrca", "b_to_mrca"]
+    assert len(R) == n * (n - 1) // 2 and {frozenset((a, b)) for a, b in zip(R["a"], R["b"])} == \
+        {frozenset(p) for p in __import__("itertools").combinations(T.leaves.keys(), 2)}
+    O = _oracle_of(T)
+    for row in R.itertuples():
+        a, b = T.leaves[row.a], T.leaves[row.b]
+        assert row.distance == O.distance(a, b) and row.mrca == O.mrca(a, b)
+        assert row.a_to_root == oracle.distance_to_root(f.parent, f.distance, a)
+        assert row.b_to_root == oracle.distance_to_root(f.parent, f.distance, b)
+        assert row.mrca_to_root == oracle.distance_to_root(f.parent, f.distance, row.mrca)
+        assert row.a_to_mrca == row.a_to_root - row.mrca_to_root and row.b_to_mrca == row.b_to_root - row.mrca_to_root
+    leaves = list(T.leaves.keys())[:4]
+    with pytest.warns(DeprecationWarning, match=r"get_quartet_topology\(\) is deprecated"):
+        assert T.get_quartet_topology(*leaves) == T.quartet_topology(*leaves)
+    q = np.array([[T.leaves[x] for x in leaves]], dtype=np.int64)
+    with pytest.warns(DeprecationWarning, match=r"quartet_topologies\(\) is deprecated"):
+        assert np.array_equal(T.quartet_topologies(q), T.quartet_topologies_bulk(q))

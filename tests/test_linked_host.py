@@ -141,3 +141,30 @@ def test_link_pair_draws_and_bucket_moments_of_the_sampler():
     assert sums.tolist() == want_s and sumsq.tolist() == want_q
     with pytest.raises(Exception):
         _capi.link_sample_pairs(1, np.zeros((0, 2), dtype=np.int64), 4)
+
+
+def test_leftover_surface_of_the_reference(capsys):
+    """link_leaf / get_links (MuchTree.pyx:1993-2014, used by SuchLinkedTrees.__init__ :2639), dump_table (:3200-3208),
+    to_igraph without igraph (:3180-3181), dump_array (:2231-2240), the deprecated quartet wrappers (:2470-2478)."""
+    SLT, links = _gopher_louse()
+    B = SLT.TreeB
+    cols = B.get_links(list(B.leaves.values()))
+    assert cols.tolist() == list(range(B.num_leaves)) and cols.dtype == np.dtype(int)
+    assert SLT.TreeA.get_links(list(SLT.TreeA.leaves.values())[:3]).tolist() == [-1, -1, -1]      # never linked: the right child
+    with pytest.raises(Exception, match="Unknown leaf id"):
+        B.get_links([B.root_node])
+    with pytest.raises(Exception, match="Cannot link non-leaf node"):
+        B.link_leaf(B.root_node, 0)
+    SLT.dump_table()
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == SLT.n_cols and out[0].startswith("column 0 :")
+    assert sum(len(line.split(":")[1].strip().split(",")) for line in out if line.split(":")[1].strip()) == SLT.n_links
+    try:
+        import igraph      # noqa: F401
+    except ImportError:
+        with pytest.raises(Exception, match="igraph package not installed."):
+            SLT.to_igraph()
+    T = SuchTree("(A:1,B:2,(C:3,D:4):5);")
+    T.dump_array()
+    out = capsys.readouterr().out.splitlines()
+    assert len(out) == 5 * T.size and out[0] == "id : 0 ->" and out[1] == "   distance    : 3.000" and out[2] == "   parent      : 1"
