@@ -7,6 +7,7 @@ What is written (all of it DATA -- inputs and expected outputs -- never source):
                            (SuchTree/tests/test.tree, SuchTree/tests/test.matrix;
                            the matrix is the only numeric known-answer file the
                            reference holds for this path)
+  support_*.tree           the reference's three fixtures for node supports (SuchTree/tests/support_{int,float,comment}.tree)
   host.tree                data/bigtrees/host.tree, the tree behind the known
                            answers printed in docs/examples/SuchTree_examples.md
   known_answers.json       the values printed in the reference docs, with citations
@@ -52,7 +53,9 @@ def main():
     shutil.copyfile(os.path.join(REF, "SuchTree/tests/test.tree"), os.path.join(OUT, "test.tree"))
     shutil.copyfile(os.path.join(REF, "SuchTree/tests/test.matrix"), os.path.join(OUT, "test.matrix"))
     shutil.copyfile(os.path.join(REF, "data/bigtrees/host.tree"), os.path.join(OUT, "host.tree"))
-    for f in ("test.tree", "test.matrix", "host.tree"):
+    for f in ("support_int.tree", "support_float.tree", "support_comment.tree"):      # SuchTree/tests: node supports
+        shutil.copyfile(os.path.join(REF, "SuchTree/tests", f), os.path.join(OUT, f))
+    for f in ("test.tree", "test.matrix", "host.tree", "support_int.tree", "support_float.tree", "support_comment.tree"):
         os.chmod(os.path.join(OUT, f), 0o644)
 
     known = {

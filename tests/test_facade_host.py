@@ -185,3 +185,24 @@ def test_surface_is_complete():
         subset_columns subset_n_links to_igraph""".split()
     assert [x for x in tree_names if not hasattr(SuchTree, x)] == []
     assert [x for x in slt_names if not hasattr(SuchLinkedTrees, x)] == []
+
+
+def test_node_supports_from_the_reference_fixtures():
+    """SuchTree/tests/test_SuchTree.py:90-108 and test_new_api.py:229-242 on the reference's own three fixtures: supports
+    written as integers and floats are read (float32), supports in comments are dropped with the comments (-1)."""
+    for name, want in (("support_int.tree", {1.0, 2.0, 3.0}), ("support_float.tree", {1.342, 2.883, 3.123}), ("support_comment.tree", set())):
+        S = SuchTree(golden_path(name))
+        assert S.size == 11 and S.num_leaves == 6
+        got = {round(S.get_support(int(x)), 3) for x in S.internal_nodes if S.get_support(int(x)) != -1}
+        assert got == want, name
+        for x in S.get_nodes():
+            assert S.get_support(int(x)) != 0 and isinstance(S.get_support(int(x)), float)
+        for leaf in S.leaves.values():
+            assert S.get_support(leaf) == -1
+        if want:      # every internal node on a real (non-epsilon) branch carries its support
+            for x in S.internal_nodes:
+                x = int(x)
+                if x != S.root_node and float(S._flat.distance[x]) != pytest.approx(S.polytomy_epsilon):
+                    assert S.get_support(x) != -1.0
+    F = SuchTree(golden_path("support_float.tree"))
+    assert F.get_support(F.get_parent("C")) == float(np.float32(1.342)) and F.get_parent("C") == F.get_parent("D")
