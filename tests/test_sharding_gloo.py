@@ -109,12 +109,16 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_pairs,chunks,root,root_share", [
+_CASES = [
     (2, 1001, 3, 0, None), (2, 4, 4, 0, None), (2, 777, 1, 1, None), (2, 1001, 4, 0, 0.8), (2, 1001, 2, 1, 0.37), (2, 50, 3, 0, 1.0),
     # more than one peer: the root posts receives from several ranks per piece, peers are indexed around the root
     (3, 1001, 4, 0, None), (3, 1001, 1, 1, 0.5), (3, 1000, 4, 2, 0.31), (4, 1001, 4, 0, 0.5), (4, 1003, 1, 2, None),
-    (4, 1003, 4, 1, 0.41), (4, 3, 4, 0, None), (4, 1001, 3, 3, 0.9)])
-@pytest.mark.parametrize("packed", [False, True])
+    (4, 1003, 4, 1, 0.41), (4, 3, 4, 0, None), (4, 1001, 3, 3, 0.9)]
+
+
+# every case in the packed wire format (the default of bench.py), every other one in the int32 format as well
+@pytest.mark.parametrize("world,n_pairs,chunks,root,root_share,packed",
+                         [c + (True,) for c in _CASES] + [c + (False,) for c in _CASES[::2]])
 def test_run_sharded_gloo(world, n_pairs, chunks, root, root_share, packed):
     """packed: MRCA ids travel as 24 bits each (7 bytes per pair with the float32 distance), pieces start on
     4-pair boundaries of their slice, the root unpacks piece by piece."""
