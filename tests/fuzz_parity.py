@@ -6,7 +6,6 @@ import os, sys, time
 import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
-os.environ.setdefault("SUCHTREE_AMD_TUNE_CACHE", "0")
 from suchtree_amd import _capi, synth
 from conftest import oracle_both
 from test_tables_emulated import _general_tree
@@ -157,6 +156,7 @@ def run(budget=240.0, seed=None, big=False):
 
 
 if __name__ == "__main__":
+    os.environ.setdefault("SUCHTREE_AMD_TUNE_CACHE", "0")      # (a session by hand leaves no records behind; read per tree creation)
     ok = run(float(sys.argv[1]) if len(sys.argv) > 1 else 240.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
              len(sys.argv) > 3 and sys.argv[3] == "big")
     sys.exit(0 if ok else 1)
