@@ -233,9 +233,12 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
 // Scalar kernel over the LADDER image (deep canopies whose records are too long for the tile-sorted kernel's second
 // read of them: 1e6-leaf trees a few hundred levels deep, 63-slot chains).  Records are read once, in input order,
 // the chain stays in registers; with in-order ids the meeting node comes from the canopy's sparse table (two rank
-// reads and two table reads, all cache resident), so both sides climb with known edge counts, three edges per
-// 16-byte LDS read: max k_a / 3 + max k_b / 3 dependent LDS reads per wave where the predicated kernel's depth cut
-// takes max(k_a, k_b) + max k_b rounds of two reads each.  Without the table: the lock-step search on the ladder.
+// reads and two table reads, all cache resident), so both sides climb towards a known node, three edges per
+// 16-byte LDS read (pair_math.h: ladder_climb_to -- read, compare, three adds): max k_a / 3 + max k_b / 3 dependent
+// LDS reads per wave where the predicated kernel's depth cut takes max(k_a, k_b) + max k_b rounds of two reads each.
+// Without the table: the lock-step search on the ladder.  What binds it: on ml.tree the LDS pipe (83 % busy); a wave
+// takes as long as the longest of its 64 climbs -- two pairs per lane, climbs dealt again among the workgroup's lanes
+// and a software pipeline over the passes were all measured slower or even (profiles/ladder_*_r04.log).
 // (launch bounds: two 1024-lane workgroups per CU = 8 waves per SIMD need at most 64 VGPRs AND at most 80 SGPRs --
 // the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD -- so the short-record form, whose
 // ladder image can leave room for two workgroups (ml.tree: 74 KiB), is compiled for 8; at 92 SGPRs it ran one
