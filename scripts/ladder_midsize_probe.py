@@ -25,7 +25,7 @@ for name in sys.argv[1:] or ("ml", "nj"):
     out_m = torch.empty(nmax, dtype=torch.int32, device="cuda")
     tree = _capi.DeviceTree(parent, dist)
     print(name, tree.info()["big_batch_kernel"], tree.info()["record_bytes"])
-    cols = [("ladder", dict(tile_sort=0, pairs_per_lane=1, ladder_scalar=1, prefer_walk_sorted=0), "canopy"),
+    cols = [("ladder", dict(tile_sort=0, pairs_per_lane=1, ladder_scalar=1, ladder_min_pairs=0, prefer_walk_sorted=0), "canopy"),
             ("sorted", dict(tile_sort=1, pairs_per_lane=0, ladder_scalar=0, prefer_walk_sorted=0), "canopy"),
             ("k_walk", dict(walk_sort_min=1 << 40), "walk"), ("walk_sorted", dict(walk_sort_min=32768), "walk")]
     print("%9s " % "pairs" + "".join("%14s" % c[0] for c in cols))
