@@ -563,17 +563,40 @@ ST_HD PairResult pair_ladder_split(const Lad &lad, DepthPtr cdepth, const Canopy
 
 // Both lineages enter the canopy at the same node: the MRCA is that portal or
 // lies in the understory.  The two id chains are compared from the portal end.
+// (four id slots per round trip: the slots end on the record's last 16 bytes, so chunk q from the end is one aligned
+// 16-byte read of each record -- pairs of nearby leaves share nearly their whole chains, and one dependent pair of
+// 4-byte loads per shared level was what the scalar kernels spent on them: nj.tree, leaves within 8 of each other,
+// 9.4e9 pairs/s where the tile-sorted kernel's register form did 1.85e10)
+struct alignas(16) IdQuad { int32_t x, y, z, w; };
+
 ST_HD PairResult pair_canopy_same_portal(const int32_t *__restrict__ canopy_id,
                                          const RecView &A, const RecView &B)
 {
     uint32_t c = 0;
-    while (c < A.nb && c < B.nb && A.I[A.cap - 1 - (int32_t)c] == B.I[B.cap - 1 - (int32_t)c]) c++;
+    int32_t last = 0;      // the id in slot cap - c (the deepest common node so far)
+    const uint32_t lim = A.nb < B.nb ? A.nb : B.nb;
+    if (A.cap >= 3) {
+        const IdQuad *qa = reinterpret_cast<const IdQuad *>(A.I + A.cap), *qb = reinterpret_cast<const IdQuad *>(B.I + B.cap);
+        while (c < lim) {
+            const IdQuad x = qa[-1 - (int32_t)(c >> 2)], y = qb[-1 - (int32_t)(c >> 2)];      // slots cap-1-c (.w) down to cap-4-c (.x)
+            uint32_t m = x.w != y.w ? 0u : x.z != y.z ? 1u : x.y != y.y ? 2u : x.x != y.x ? 3u : 4u;
+            if (m > lim - c) m = lim - c;      // (slots below the shorter chain -- and pbot in the record's first word -- do not count)
+            if (m) last = m == 1 ? x.w : m == 2 ? x.z : m == 3 ? x.y : x.x;
+            c += m;
+            if (m < 4) break;
+        }
+    } else {      // 8-byte records: one slot
+        while (c < lim && A.I[A.cap - 1 - (int32_t)c] == B.I[B.cap - 1 - (int32_t)c]) {
+            last = A.I[A.cap - 1 - (int32_t)c];
+            c++;
+        }
+    }
     const uint32_t ia = A.nb - c, ib = B.nb - c;
     float s = chain_sum_ptr(A.D, ia, 0.0f);
     s = chain_sum_ptr(B.D, ib, s);
     PairResult r;
     r.dist = s;
-    r.mrca = c ? A.I[A.cap - (int32_t)c] : canopy_id[A.portal];
+    r.mrca = c ? last : canopy_id[A.portal];
     return r;
 }
 
