@@ -577,13 +577,38 @@ ST_HD PairResult pair_canopy_same_portal(const int32_t *__restrict__ canopy_id,
     const uint32_t lim = A.nb < B.nb ? A.nb : B.nb;
     if (A.cap >= 3) {
         const IdQuad *qa = reinterpret_cast<const IdQuad *>(A.I + A.cap), *qb = reinterpret_cast<const IdQuad *>(B.I + B.cap);
-        while (c < lim) {
-            const IdQuad x = qa[-1 - (int32_t)(c >> 2)], y = qb[-1 - (int32_t)(c >> 2)];      // slots cap-1-c (.w) down to cap-4-c (.x)
-            uint32_t m = x.w != y.w ? 0u : x.z != y.z ? 1u : x.y != y.y ? 2u : x.x != y.x ? 3u : 4u;
-            if (m > lim - c) m = lim - c;      // (slots below the shorter chain -- and pbot in the record's first word -- do not count)
-            if (m) last = m == 1 ? x.w : m == 2 ? x.z : m == 3 ? x.y : x.x;
-            c += m;
-            if (m < 4) break;
+        // chunk q = slots cap-1-4q (.w) down to cap-4-4q (.x); its first `room` slots count (the shorter chain ends there;
+        // the record's first word is pbot).  Shared ancestry is a run from the portal end, so "chunk q matches whole" is
+        // monotone in q: the first chunk decides most pairs that are not close relatives, a bisection over the others
+        // finds the chunk where the run ends in log2 steps (31-slot chains: 4 dependent round trips at most, not 8)
+        auto matches = [&](uint32_t q, IdQuad &x, uint32_t &room) {
+            x = qa[-1 - (int32_t)q];
+            const IdQuad y = qb[-1 - (int32_t)q];
+            room = lim - 4 * q < 4 ? lim - 4 * q : 4;
+            const uint32_t m = x.w != y.w ? 0u : x.z != y.z ? 1u : x.y != y.y ? 2u : x.x != y.x ? 3u : 4u;
+            return m < room ? m : room;
+        };
+        const uint32_t chunks = (lim + 3) / 4;
+        IdQuad x{0, 0, 0, 0}, xe{0, 0, 0, 0};      // xe: the last chunk seen that ends the run
+        uint32_t room = 0, m = 0, lo = 0, hi = chunks, me = 0, qe = chunks;
+        if (chunks) {
+            m = matches(0, x, room);
+            if (m < 4 || chunks == 1) { qe = 0; me = m; xe = x; hi = 0; }
+            else lo = 1;
+        }
+        while (lo < hi) {      // invariant: chunks below lo match whole; chunk qe (= hi, if hi < chunks) ends the run with me slots
+            const uint32_t mid = (lo + hi) / 2;
+            m = matches(mid, x, room);
+            if (m == 4) lo = mid + 1;
+            else { hi = mid; qe = mid; me = m; xe = x; }
+        }
+        if (qe < chunks) {
+            c = 4 * qe + me;
+            if (me) last = me == 1 ? xe.w : me == 2 ? xe.z : me == 3 ? xe.y : xe.x;
+            else if (qe) last = qa[-(int32_t)qe].x;      // the run ends exactly between two chunks: the id is the previous chunk's last slot
+        } else if (chunks) {      // every chunk matched whole (lim is a multiple of four)
+            c = lim;
+            last = qa[-(int32_t)chunks].x;
         }
     } else {      // 8-byte records: one slot
         while (c < lim && A.I[A.cap - 1 - (int32_t)c] == B.I[B.cap - 1 - (int32_t)c]) {
