@@ -226,7 +226,20 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
             t->prefer_walk_sorted = other && other->walk ? 1 : 0;
             t->ladder_scalar = best->ladder;
             t->ladder_min_pairs = 0;
-            if (best->ladder && base_small && best->ms_small > kTuneMargin * base_small->ms_small) t->ladder_min_pairs = n / 2;
+            if (best->ladder && base_small && best->ms_small > kTuneMargin * base_small->ms_small) {
+                t->ladder_min_pairs = n / 2;
+            } else if (best->ladder && base_small) {
+                // ahead at a quarter of the sample too: one more size, a sixteenth (ml.tree: the tile-sorted kernel is
+                // 10-20 % ahead from 2^17 to 2^19 pairs, even at 2^20, behind from 2^21 -- profiles/ladder_midsize_r04.log)
+                const Cand ladder = *best, other_small = *base_small;      // (time_settings overwrites the handle's settings)
+                const float ms_ladder = time_settings(ladder.sort, ladder.ppl, ladder.walk, ladder.ladder, n / 16);
+                const float ms_other = time_settings(other_small.sort, other_small.ppl, other_small.walk, other_small.ladder, n / 16);
+                t->tile_sort = canopy ? canopy->sort : rule_sort;
+                t->pairs_per_lane = canopy ? canopy->ppl : rule_ppl;
+                t->prefer_walk_sorted = other && other->walk ? 1 : 0;
+                t->ladder_scalar = best->ladder;
+                t->ladder_min_pairs = (ms_ladder > 0.0f && ms_other > 0.0f && ms_ladder > kTuneMargin * ms_other) ? n / 8 : 0;
+            }
             if (t->rec_bytes > kMaxRecordBytes) t->ladder_scalar = 1;      // (1 KB records: the family's other kernels read them through a pointer, far slower)
             t->info.tuned = 1;
             tune_cache_write(cache, t->tile_sort, t->pairs_per_lane, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs);
