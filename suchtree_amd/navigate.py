@@ -8,7 +8,7 @@ No distance is computed here: `relative_evolutionary_divergence` sends its pairs
 `distance_to_root` and `path_between_nodes` go through `distance` / `common_ancestor` (the GPU).
 """
 from collections import deque
-from typing import Dict, Union
+from typing import Dict
 
 import numpy as np
 

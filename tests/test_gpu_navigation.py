@@ -2,8 +2,6 @@
 evolutionary divergence, against the oracle's statement-by-statement restatements (oracle/oracle.py) -- exact
 equality -- and the reference's own assertions (SuchTree/tests/test_new_api.py:354-360, 539-556;
 tests/test_SuchTree.py:46-49: distance to root of every leaf)."""
-import warnings
-
 import numpy as np
 import pytest
 
