@@ -220,3 +220,41 @@ def test_edges_and_newick_export(T, S):
     deep = "(" * (n - 1) + "L0:1" + "".join(",L%d:1):1" % i for i in range(1, n))
     D = SuchTree(deep[:deep.rindex(":")] + ";")
     assert SuchTree(D.to_newick()).num_leaves == n
+
+
+def test_traversals_and_newick_round_trip_on_a_deep_real_tree(ml_arrays):
+    """ml.tree (108,653 nodes, 376 levels): every traversal visits every node once, in the order its name says; the
+    Newick export parses back to the same node table (ids are in-order positions, lengths print as float32 values)."""
+    parent, dist, leaf_ids = ml_arrays
+    names = ["t%d" % i for i in range(len(leaf_ids))]
+    T = SuchTree((parent, dist, names))
+    f = T._flat
+    n = T.size
+    pre = np.fromiter(T.traverse_preorder(), dtype=np.int64)
+    post = np.fromiter(T.traverse_postorder(), dtype=np.int64)
+    level = np.fromiter(T.traverse_levelorder(), dtype=np.int64)
+    ino = np.fromiter(T.traverse_inorder(include_distances=False), dtype=np.int64)
+    for order in (pre, post, level, ino):
+        assert len(order) == n and np.array_equal(np.sort(order), np.arange(n))
+    where_pre, where_post = np.empty(n, np.int64), np.empty(n, np.int64)
+    where_pre[pre] = np.arange(n)
+    where_post[post] = np.arange(n)
+    kids = np.flatnonzero(f.parent >= 0)
+    assert (where_pre[f.parent[kids]] < where_pre[kids]).all() and (where_post[f.parent[kids]] > where_post[kids]).all()
+    depth = dict(T.traverse_with_depth())
+    assert max(depth.values()) + 1 == T.depth == 376
+    assert [depth[int(x)] for x in level] == sorted(depth.values())
+    assert np.array_equal(np.sort(T.get_leaves(T.root_node)), np.sort(leaf_ids))
+    assert len(T.get_internal_nodes()) == n - len(leaf_ids)
+    text = T.to_newick()
+    R = SuchTree(text)
+    assert R.size == n and R.num_leaves == T.num_leaves and R.depth == T.depth
+    # the parser numbers nodes in order; relabel T's nodes by in-order position and the tables must coincide
+    pos = np.empty(n, np.int64)
+    pos[ino] = np.arange(n)
+    want_parent = np.full(n, -1, np.int64)
+    want_parent[pos[kids]] = pos[f.parent[kids]]
+    want_dist = np.empty(n, np.float32)
+    want_dist[pos] = f.distance
+    assert np.array_equal(R._flat.parent, want_parent) and np.array_equal(R._flat.distance.view(np.uint32), want_dist.view(np.uint32))
+    assert {R.leaves[name] for name in names[:50]} == {int(pos[T.leaves[name]]) for name in names[:50]}
