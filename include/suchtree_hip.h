@@ -325,8 +325,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "ladder_scalar": 1 = distance batches of at least "ladder_min_pairs" pairs (0 = 131072) on records of 128 bytes and
  * more are served by the scalar kernel over the ladder form of the canopy (records read once, no sort: large batches);
  * both defaults are set with the three above when a deep tree is created (timed at two or three batch sizes, on
- * uniform random leaf pairs: a caller whose batches are all close relatives -- every pair within a few leaves -- may do
- * better with 0 on trees whose ladder image leaves one workgroup per CU, e.g. nj.tree 1.4e10 -> 1.8e10 pairs/s).
+ * uniform random leaf pairs: a caller whose batches are all close relatives -- every pair within a few leaves, short
+ * paths -- does better with "ladder_scalar" 0 and "prefer_walk_sorted" 1: the walk family's cost follows the path
+ * length; nj.tree, leaves within 8 of each other: 1.4e10 -> 1.9e10 pairs/s, ml.tree 1.7e10 -> 2.0e10).
  * "ladder_dynamic": 1 (default) = on records of 512 bytes and more, batches of 2^22 pairs and more (2^21 on 1 KB
  * records) of that kernel draw their work from per-XCD counters instead of a static deal; 0 = never; 2 = always.
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
