@@ -4,8 +4,11 @@ relative evolutionary divergence -- the last one a caller of the bulk distance p
 Mixed into :class:`suchtree_amd.SuchTree`.  Everything but `relative_evolutionary_divergence` is host bookkeeping
 over the flat arrays (`parent`, `left`, `right`, `distance`) with the reference's names, argument conventions,
 orders of enumeration, return types and exceptions (/root/reference/SuchTree/MuchTree.pyx, cited per method).
-No distance is computed here: `relative_evolutionary_divergence` sends its pairs through `distances_bulk`,
-`distance_to_root` and `path_between_nodes` go through `distance` / `common_ancestor` (the GPU).
+No patristic distance and no MRCA is computed here: `relative_evolutionary_divergence`, `to_networkx_nodes` and
+`relationships` send their pairs through the bulk path, `distance_to_root` and `path_between_nodes` go through
+`distance` / `common_ancestor` (the GPU).  (`traverse_with_distances` carries the reference's own running sum of
+branch lengths down its traversal -- Python floats, top-down: bookkeeping of that generator, not the path's float32
+sums.)
 """
 from collections import deque
 from typing import Dict
