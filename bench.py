@@ -241,6 +241,23 @@ def latest_traffic():
         return None, None
 
 
+def footprint_sweep():
+    """The committed footprint sweep of the same kernel family (scripts/footprint_sweep.sh -> profiles/footprint_sweep_rNN.json):
+    balanced trees of 2^20 / 2^22 / 2^24 leaves, whose record tables go from inside the Infinity Cache to four times its size."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "footprint_sweep_r*.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:      # noqa: BLE001
+        return None
+    keys = ("leaves", "gather_footprint_bytes", "fits_infinity_cache", "avg_ns", "pairs_per_s", "counter_bytes_per_pair",
+            "counter_TBps", "frac_of_hbm_peak", "fabric_read_requests_per_pair", "l2_hit_rate")
+    return {"source": os.path.relpath(files[-1], ROOT), "trees": [{k: t.get(k) for k in keys} for t in d.get("trees", [])],
+            "what": "rocprofv3 kernel time and counter bytes of st_distances_device, 1e8 random leaf pairs per launch; beyond 256 MiB "
+                    "of gathered records the counter bytes are HBM traffic"}
+
+
 # --------------------------------------------------------------------------------------------
 # the MI355X backend
 # --------------------------------------------------------------------------------------------
@@ -342,13 +359,15 @@ class HipBackend:
                     roof["measured_copy_GBps"] = hw["stream_copy_GBps"]
                 rr = three.get("request_rate", {})
                 if rr.get("frac"):
-                    # what binds: the fabric's random-sector request rate at this footprint
-                    roof.update({"bound": "fabric_random_sector", "achieved": rr["Greads_per_s"], "peak": rr["ceiling_Greads_per_s"],
-                                 "unit": "Greads/s", "frac": rr["frac"], "gather_footprint_MiB": foot / 2**20,
-                                 "ceiling_source": "suchtree_amd/csrc/microbench.hip run in this process: random 32-byte reads, one "
-                                                   "per 64-byte sector, from a table of the kernel's own gather footprint; best of "
-                                                   "a sweep over unroll and grid shape; requests per pair: rocprofv3 "
-                                                   "TCC_EA0_RDREQ_sum in %s" % traffic_file})
+                    # what limits a gather kernel below the byte peak: the fabric's random-sector request rate at this footprint
+                    # (measured here, in this process; the round's full sweep is committed as profiles/ceilings_sweep_rNN.json)
+                    roof["secondary_ceiling"] = {
+                        "name": "fabric_random_sector", "achieved": rr["Greads_per_s"], "peak": rr["ceiling_Greads_per_s"],
+                        "unit": "Greads/s", "frac": rr["frac"], "gather_footprint_MiB": foot / 2**20,
+                        "committed_sweep": bench_legs.committed_sector_ceiling(foot),
+                        "ceiling_source": "suchtree_amd/csrc/microbench.hip run in this process: random 32-byte reads, one per 64-byte "
+                                          "sector, from a table of the kernel's own gather footprint; best of a sweep over unroll and "
+                                          "grid shape; requests per pair: rocprofv3 TCC_EA0_RDREQ_sum in %s" % traffic_file}
         line["mrca_ids_only"] = bench_legs.mrca_ids_only(self, pairs, out_m)
         if not args.no_host_path:
             line["end_to_end_host_path"] = bench_legs.host_path_leg(self, pairs, out_d, out_m)
@@ -478,36 +497,61 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     ms_per_step = elapsed / args.steps * 1e3
     achieved = bytes_per_pair * pairs_this_rank / (kernel_ms * 1e-3) / 1e9
     kernel_name = {"canopy": "k_canopy_ilp", "walk": "k_walk"}.get(info["strategy"], info["strategy"])
-    # bytes the algorithm has to request from the fabric per pair when no record is cache
-    # resident: the coalesced streams plus one 64-byte sector per record read
+    rate = pairs_this_rank / (kernel_ms * 1e-3)      # this rank's pairs per second of kernel time (HIP events on the launch stream)
+    # bytes the kernel has to request from the fabric per pair when no record is cache resident: the coalesced
+    # streams plus one 64-byte sector per record read
     required = 16 + 12 + 2 * 64
-    # The block names the ceiling that binds.  Without the in-process ceiling measurement (--no-microbench, or no
-    # committed PMC pass) that is HBM bandwidth against the bytes the kernel must request; with it, extra_legs
-    # replaces bound / achieved / peak / unit / frac by the fabric's random-sector request rate (frac <= 1).  The
-    # SURVEY 8d algorithmic figure stays beside it as algorithmic_* whatever binds.
-    roof = {"bound": "hbm", "achieved": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+    # The block follows SURVEY 8d with HBM as the bound.  Primary figure: the bytes the kernel MOVES -- fabric bytes per
+    # launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic_rNN.json; per pair, scaled to
+    # this launch) over this run's kernel time.  SURVEY 8d's algorithmic bytes (28 + 8 h per pair: the reference's walk)
+    # stay beside it in `algorithmic`: the canopy kernel climbs in LDS and reads pre-summed understories, so it does not
+    # move them and that fraction exceeds 1 -- it is not a bandwidth claim.
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
             "kernel": kernel_name, "kernel_ms": kernel_ms, "pairs_per_launch": pairs_this_rank // plan.chunks,
-            "launches_per_step": plan.chunks,
-            "algorithmic_bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean,
-            "algorithmic_GBps": achieved, "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBPS,
-            "required_bytes_per_pair": required,
-            "required_GBps": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9,
-            "required_frac": required * pairs_this_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "note": "bound/achieved/peak/frac: the ceiling that binds this kernel. algorithmic_*: SURVEY 8d's bytes of the "
-                    "reference's walk (28 + 8*h per pair) / kernel time against the 8 TB/s HBM peak -- the canopy kernel "
-                    "climbs in LDS and reads pre-summed understory records, so it does not move those bytes and "
-                    "algorithmic_frac_of_hbm_peak can exceed 1. required_*: the bytes this kernel must request per pair "
-                    "(16 in + 12 out + two 64-byte record sectors). traffic / counter_traffic: fabric bytes per launch "
-                    "from request counts of the committed PMC passes (64 B per record request, 128 B per stream request, "
-                    "+ WRITE_SIZE; calibration in profiles/README.md). request_rate: fabric read requests per pair x "
-                    "pairs/s against the random-sector rate measured in this process at the kernel's own footprint."}
-    if traffic and traffic.get("hbm_bytes_per_launch"):
-        roof["traffic"] = traffic["hbm_bytes_per_launch"] * (pairs_this_rank / plan.chunks) / traffic.get("pairs_per_launch", 1e8)
+            "launches_per_step": plan.chunks}
+    per_pair = None
+    if traffic and traffic.get("hbm_bytes_per_launch") and traffic.get("pairs_per_launch"):
+        per_pair = traffic["hbm_bytes_per_launch"] / traffic["pairs_per_launch"]
+        roof["traffic"] = per_pair * (pairs_this_rank / plan.chunks)
+        roof["traffic_bytes_per_pair"] = per_pair
         roof["traffic_source"] = traffic_file
         c = traffic.get("counters_mean_per_launch", {})
         if c.get("TCC_HIT_sum") and c.get("TCC_MISS_sum"):
             roof["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])       # same PMC passes
+        k = (traffic.get("kernels") or {}).get(traffic.get("kernel_full_name"), {})
+        if k.get("avg_ns"):
+            # the same quotient from the committed files alone: counter bytes per launch / rocprofv3's average duration
+            roof["rocprof"] = {"kernel": traffic.get("kernel_full_name"), "calls": k.get("calls"), "kernel_avg_ms": k["avg_ns"] * 1e-6,
+                               "counter_GBps": traffic["hbm_bytes_per_launch"] / (k["avg_ns"] * 1e-9) / 1e9,
+                               "frac": traffic["hbm_bytes_per_launch"] / (k["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS,
+                               "source": "%s (rocprofv3 --kernel-trace --stats + one --pmc pass per counter set of `python3 bench.py "
+                                         "--steps 5 --warmup 2`; kernel_stats_%s.csv is the stats table)"
+                                         % (traffic_file, str(traffic.get("tag")))}
+    moved = per_pair if per_pair is not None else float(required)
+    roof["achieved"] = moved * rate / 1e9
+    roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS
+    roof["achieved_is"] = ("fabric bytes per pair by counters (%s: read requests x calibrated bytes per request + WRITE_SIZE) x this "
+                           "run's pairs per second of kernel time" % traffic_file) if per_pair is not None else \
+                          "no committed PMC pass: the bytes the kernel must request per pair (16 in + 12 out + two 64-byte record sectors)"
+    alg_frac = achieved / HBM_PEAK_GBPS
+    roof["algorithmic"] = {"bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean, "GBps": achieved, "frac_of_hbm_peak": alg_frac,
+                           "exceeds_peak": bool(alg_frac > 1.0),
+                           "why": "SURVEY 8d's 28 + 8*h bytes are the reference's walk; the canopy kernel climbs a 128 KiB LDS image "
+                                  "and reads a's understory pre-summed, so those bytes never cross the fabric (results are bit-exact "
+                                  "all the same: `parity`)" if info["strategy"] == "canopy" else
+                                  "SURVEY 8d's 28 + 8*h bytes per pair over the kernel time"}
+    roof.update({"algorithmic_bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean,
+                 "algorithmic_GBps": achieved, "algorithmic_frac_of_hbm_peak": alg_frac,
+                 "required_bytes_per_pair": required, "required_GBps": required * rate / 1e9,
+                 "required_frac": required * rate / 1e9 / HBM_PEAK_GBPS})
+    sweep = footprint_sweep()
+    if sweep:
+        roof["hbm_regime"] = sweep
+    roof["note"] = ("bound hbm: achieved / peak / frac = fabric bytes the kernel moves per second (counters) against the 8 TB/s HBM3E peak. "
+                    "At this tree's 36 MiB gather footprint most record sectors are served by the 256 MiB Infinity Cache, which the "
+                    "TCC_EA counters include; hbm_regime shows the same kernel family on trees whose records exceed it. "
+                    "secondary_ceiling (added when the in-process microbenchmark ran): fabric read requests per second against the "
+                    "random-64-byte-sector rate at the kernel's footprint -- what actually limits a gather kernel below the byte peak.")
     if info["strategy"] == "canopy":
         # SURVEY 8d asks for the achieved occupancy next to the fraction: the canopy kernels run one 1024-lane
         # workgroup per CU when the LDS image exceeds 80 KiB (two below that)

@@ -115,6 +115,28 @@ def three_ceilings(traffic, pairs_per_s, algorithmic_bytes_per_pair, ceiling=Non
     return out
 
 
+def committed_sector_ceiling(footprint_bytes):
+    """The committed round sweep's random-sector ceiling at the footprint nearest to `footprint_bytes`
+    (scripts/ceilings_sweep.py -> profiles/ceilings_sweep_rNN.json), so that the line's secondary ceiling can be
+    checked against a file under profiles/ and not only against this process's own measurement."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "ceilings_sweep_r[0-9][0-9].json")))
+    if not files:
+        return None
+    try:
+        best = json.load(open(files[-1])).get("best", {})
+    except Exception:      # noqa: BLE001
+        return None
+    rows = [(abs(v["table"]["MiB"] * 2**20 - footprint_bytes), k, v) for k, v in best.items()
+            if isinstance(v, dict) and isinstance(v.get("table"), dict)]
+    if not rows:
+        return None
+    _, name, v = min(rows, key=lambda r: r[0])
+    return {"source": os.path.relpath(files[-1], ROOT), "entry": name, "table_MiB": v["table"]["MiB"],
+            "Greads_per_s": v["table"]["Greads_per_s"], "stream_copy_GBps": v.get("stream_copy_GBps")}
+
+
 def load_traffic(tag):
     """profiles/traffic_<tag>_rNN.json of the latest round that has one (committed PMC passes of a leg's kernel)."""
     import glob

@@ -13,9 +13,10 @@ export SUCHTREE_AMD_AUTOTUNE=0      # (the timing launches of host_tune.h would 
 T=${PMC_TIMEOUT:-240}
 timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/scripts/tune_gpu.py --pairs $PAIRS --rounds 4 "$@" > $OUT/trace.log 2>&1
 echo "trace rc=$?"
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
-         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum" "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_LATENCY_sum" \
-         "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"; do
+# (PMC_SETS: semicolon-separated counter sets, one pass each, instead of the default nine)
+DEFAULT_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum;TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum;TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum;TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum;TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum;GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_LATENCY_sum;SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS"
+IFS=';' read -ra SETS <<< "${PMC_SETS:-$DEFAULT_SETS}"
+for C in "${SETS[@]}"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-60)
   timeout $T rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$N -- python3 $REPO/scripts/tune_gpu.py --pairs $PAIRS --rounds 3 "$@" > $OUT/pmc_$N.log 2>&1
   echo "pmc $N rc=$?"

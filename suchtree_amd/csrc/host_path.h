@@ -16,7 +16,8 @@ static int upload(T **dst, const std::vector<T> &src, int64_t *bytes)
 constexpr int64_t kHostChunk = (int64_t)1 << 22;      // most pairs per pipeline chunk
 constexpr int64_t kHostChunkMin = (int64_t)1 << 18;   // fewest, when a batch is dealt over several GPUs
 constexpr int kDeepCanopyDepth = kShallowCanopyDepth;     // canopies deeper than this (edges) are "deep" (tree_prep.h)
-constexpr int kDeepCanopyNodes = 10240;   // 80 KiB LDS image: two 1024-lane workgroups per CU
+constexpr int kDeepCanopyNodes = 10238;   // the largest ladder image (16 B per node) that leaves k_canopy_ladder its 32 bytes of flags in 160 KiB of LDS
+static_assert(st::ladder_kernel_lds_bytes(kDeepCanopyNodes) <= st::kLdsBytesPerCu, "a deep canopy must fit the scalar ladder kernel's LDS");
 constexpr int64_t kMaxWalkLineageEntries = (int64_t)1 << 30;   // 4 GiB of lineage sums at most on trees the canopy family refuses
 constexpr int64_t kMaxLineageEntries = (int64_t)1 << 28;   // 1 GiB of lineage sums at most (ml.tree: 48 MB)
 constexpr int64_t kMailboxPairs = 8192;   // largest batch served through the mailbox (beyond it the staged pipe's fixed ~60 us pay off)

@@ -50,7 +50,8 @@ template <int CAP, typename Src>
 static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                        DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
 {
-    const size_t lds = ladder_image_bytes(t->canopy_nodes) + 32;      // (+ the kernel's eight "counter ran dry" flags)
+    const size_t lds = ladder_kernel_lds_bytes(t->canopy_nodes);      // (image + the kernel's eight "counter ran dry" flags)
+    if (lds > kLdsBytesPerCu) return hipErrorInvalidValue;            // (launch_policy.h::ladder_tables_ready keeps such trees away)
     auto kern = k_canopy_ladder<CAP, Src>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

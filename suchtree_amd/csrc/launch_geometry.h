@@ -15,10 +15,15 @@ constexpr int kWalkSortBuckets = 256;
 
 // LDS image of the ladder form: canopy_nodes 16-byte entries (the depths stay in global
 // memory: they are read twice per pair, from a table of a few KiB)
-__host__ __device__ inline size_t ladder_image_bytes(int canopy_nodes)
+__host__ __device__ constexpr size_t ladder_image_bytes(int canopy_nodes)
 {
     return (size_t)canopy_nodes * 16;
 }
+
+// LDS of one k_canopy_ladder workgroup: the image and, behind it, the eight "counter ran dry" flags of the dynamic deal
+constexpr size_t kLdsBytesPerCu = 160 * 1024;
+constexpr size_t kLadderFlagBytes = 32;
+__host__ __device__ constexpr size_t ladder_kernel_lds_bytes(int canopy_nodes) { return ladder_image_bytes(canopy_nodes) + kLadderFlagBytes; }
 
 // block table of the four-byte a side (k_canopy_ilp<..., true>), padded to the 16-byte staging granule
 __host__ __device__ inline size_t leaf_block_image_bytes(int count) { return ((size_t)count * 2 + 15) & ~(size_t)15; }

@@ -87,7 +87,7 @@ constexpr int64_t kLadderMinPairs = 131072;
 static inline bool ladder_tables_ready(const st_tree *t)
 {
     return t->strategy == ST_STRATEGY_CANOPY && t->d_ladder && (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap >= 63) &&
-           ladder_image_bytes(t->canopy_nodes) <= 160 * 1024;
+           ladder_kernel_lds_bytes(t->canopy_nodes) <= kLdsBytesPerCu;      // (the flags behind the image count too)
 }
 static inline bool ladder_applies(const st_tree *t, int64_t n)
 {
