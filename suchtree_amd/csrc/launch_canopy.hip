@@ -16,7 +16,6 @@
 #include "launch_decl.h"
 #include "launch_policy.h"
 #include "kernels_canopy.h"
-#include "kernels_canopy_refill.h"
 #include "launch_canopy_sorted.h"
 
 namespace st {
@@ -73,28 +72,6 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
     return hipGetLastError();
 }
 
-// k_canopy_refill (kernels_canopy_refill.h): K * 64 pairs per wave and visit, climbs drawn lane by lane.  Needs the sparse
-// table (in-order ids) and K * 256 bytes of LDS per wave behind the image.
-template <int K>
-static inline size_t refill_lds_bytes(int canopy_nodes) { return ladder_image_bytes(canopy_nodes) + (size_t)(kCanopyBlock / 64) * K * 64 * sizeof(float); }
-template <int CAP, int K, bool REFILL, typename Src>
-static hipError_t launch_canopy_refill(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
-{
-    const size_t lds = REFILL ? refill_lds_bytes<K>(t->canopy_nodes) : ladder_image_bytes(t->canopy_nodes);
-    auto kern = k_canopy_refill<CAP, K, Src, REFILL>;
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    const int64_t per_block = (int64_t)kCanopyBlock * K;
-    int64_t blocks = std::min<int64_t>((n + per_block - 1) / per_block, (int64_t)t->n_cu);
-    blocks = std::max<int64_t>(blocks, 1);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault,
-                       t->refill_threshold > 0 ? t->refill_threshold : 16);
-    return hipGetLastError();
-}
-
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
                                   DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
@@ -102,18 +79,8 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     // the scalar ladder kernel: large distance batches of handles that chose it (launch_policy.h: ladder_applies;
     // records of more than 512 bytes: every batch the family takes -- nothing else reads them well)
     if constexpr (CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63) {
-        if ((out_d.any() && ladder_applies(t, n)) || (t->rec_bytes > 512 && t->ladder_scalar && ladder_tables_ready(t))) {
-            if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
-                const bool can = out_d.any() && P.rmq && P.cpos;
-                if (can && t->ladder_refill == 4 && refill_lds_bytes<4>(t->canopy_nodes) <= kLdsBytesPerCu)
-                    return launch_canopy_refill<CAP, 4, true>(t, P, src, n, out_d, out_m, fault, stream);
-                if (can && t->ladder_refill == 2 && refill_lds_bytes<2>(t->canopy_nodes) <= kLdsBytesPerCu)
-                    return launch_canopy_refill<CAP, 2, true>(t, P, src, n, out_d, out_m, fault, stream);
-                if (can && t->ladder_lockstep == 2) return launch_canopy_refill<CAP, 2, false>(t, P, src, n, out_d, out_m, fault, stream);
-                if (can && t->ladder_lockstep == 4) return launch_canopy_refill<CAP, 4, false>(t, P, src, n, out_d, out_m, fault, stream);
-            }
+        if ((out_d.any() && ladder_applies(t, n)) || (t->rec_bytes > 512 && t->ladder_scalar && ladder_tables_ready(t)))
             return launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream);
-        }
     }
     // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
     if (t->tile_sort && sorted_q(t) > 0)

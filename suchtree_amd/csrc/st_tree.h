@@ -63,9 +63,6 @@ struct st_tree {
     int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
     int ladder_scalar = 0;    // tuning: 1 = distance batches of >= ladder_min_pairs pairs on records of 128 bytes and more go to k_canopy_ladder: the scalar kernel over the ladder image, meeting nodes from the sparse table (set when the tree is created: timed)
-    int ladder_refill = 0;    // tuning: K = 2 / 4 / 8: large distance batches of explicit pair arrays that would go to k_canopy_ladder go to k_canopy_refill<K> (lane-granular refill) when its result slots fit LDS behind the image
-    int ladder_lockstep = 0;  // tuning: K = 2 / 4: the same batches go to k_canopy_refill<K, lock step>: K climbs per lane and round, chains added between a's and b's climbs
-    int refill_threshold = 0; // tuning: lanes that must wait before k_canopy_refill hands out new climbs (0 = 16)
     int ladder_dynamic = 1;   // tuning: 0 = the scalar ladder kernel deals its pairs statically whatever the batch size
     unsigned long long *d_work = nullptr;          // kWorkSlots x 64 counters (eight used per launch, 64 bytes apart)
     mutable std::atomic<unsigned> work_next{0};

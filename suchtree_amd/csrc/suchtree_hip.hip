@@ -428,21 +428,6 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->ladder_dynamic = (int)value;
         return ST_OK;
     }
-    if (std::strcmp(name, "ladder_refill") == 0) {
-        if (value != 0 && value != 2 && value != 4 && value != 8) return fail(ST_ERR_ARG, "ladder_refill must be 0, 2, 4 or 8");
-        t->ladder_refill = (int)value;
-        return ST_OK;
-    }
-    if (std::strcmp(name, "ladder_lockstep") == 0) {
-        if (value != 0 && value != 2 && value != 4) return fail(ST_ERR_ARG, "ladder_lockstep must be 0, 2 or 4");
-        t->ladder_lockstep = (int)value;
-        return ST_OK;
-    }
-    if (std::strcmp(name, "refill_threshold") == 0) {
-        if (value < 0 || value > 64) return fail(ST_ERR_ARG, "refill_threshold must be in [0, 64]");
-        t->refill_threshold = (int)value;
-        return ST_OK;
-    }
     if (std::strcmp(name, "ladder_min_pairs") == 0) {
         if (value < 0) return fail(ST_ERR_ARG, "ladder_min_pairs must be >= 0");
         t->ladder_min_pairs = value;
