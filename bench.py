@@ -64,6 +64,11 @@ def parse(argv=None):
                     help="N > 1: fraction of the batch rank 0 computes itself: 'auto' (balance its kernels against the "
                          "peers' transfers, from rates measured before the timed region), 'even' (1/N) or a number")
     ap.add_argument("--weak", action="store_true", help="weak scaling: every rank its own batch, no gather")
+    ap.add_argument("--gather", default="root", choices=["root", "allgather", "none"],
+                    help="N > 1, strong scaling: where the result of a step ends up inside the timed region.  root (default): "
+                         "assembled on rank 0 by point-to-point transfers; allgather: assembled on every rank (even slices, "
+                         "grouped send/recv between all pairs of GPUs); none: every rank keeps its slice (nothing travels; the "
+                         "slices are gathered once, untimed, for the parity check)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="N > 1: CUs rank 0's kernels leave free for RCCL's receive kernels (handle option reserve_cus)")
     ap.add_argument("--wire-int32", action="store_true",
@@ -285,10 +290,10 @@ class HipBackend:
         return self.tree.info()
 
     def make_pairs(self, n, seed):
-        torch = self.torch
-        gen = torch.Generator(device=self.device)
-        gen.manual_seed(seed)
-        return torch.randint(0, self.n_leaves, (n, 2), generator=gen, device=self.device, dtype=torch.int64) * 2
+        """SURVEY 8d config 3's batch: default_rng(seed).integers(0, leaves, (n, 2)) * 2 (leaf ids), int64, drawn on the
+        host and uploaded once, before anything is timed (seed 3: the batch of the -m gpu suite's headline-launch test)."""
+        from suchtree_amd import synth
+        return self.torch.from_numpy(synth.random_leaf_pairs(self.n_leaves, n, seed=seed)).to(self.device)
 
     def bind(self, pairs):
         torch, tree, stream = self.torch, self.tree, self.stream
@@ -397,7 +402,7 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
     # strong scaling: every rank generates the SAME batch (same seed) and owns a slice of it
     pairs = be.make_pairs(n, 3 + (rank if args.weak else 0))
     root_share, calib = None, None
-    if strong and world > 1 and args.root_share != "even":
+    if strong and world > 1 and args.root_share != "even" and args.gather == "root":
         if args.root_share == "auto":
             # untimed: this GPU's kernel rate on a prefix of the batch and the rate at which rank 0
             # receives from all peers at once (the gather's pattern); rank 0 decides, everyone agrees
@@ -410,16 +415,28 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
             root_share = float(args.root_share)
     # the gather's wire format: float32 + 24-bit MRCA id (7 bytes per pair) on trees of fewer than 2^24 nodes, packed by
     # the peers' kernels, unpacked on the root piece by piece; else float32 + int32
+    mode = args.gather if (strong and world > 1) else "root"
     packed = strong and world > 1 and info["n_nodes"] <= 0xFFFFFF and not args.wire_int32
     wire_bytes = sharding.WIRE_BYTES_PACKED if packed else sharding.WIRE_BYTES_PLAIN
     plan = sharding.ShardPlan(n, world if strong else 1, rank if strong else 0,
-                              chunks=args.chunks if (strong and world > 1) else 1, root_share=root_share, align=4)
-    out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=be.device, packed_ids=packed)
+                              chunks=args.chunks if (strong and world > 1) else 1,
+                              root_share=root_share if mode == "root" else None, align=4)
+    out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=be.device, packed_ids=packed, all_ranks=mode == "allgather")
     compute = be.bind(pairs)
     unpack = getattr(be, "unpack_mrca24", None)
+    own_d = own_m = None
+    if mode == "none":      # every rank keeps its slice: float64 + int32 of the slice's length, written by the kernels directly
+        s_lo, s_hi = plan.bounds(plan.rank)
+        own_d = torch.empty(s_hi - s_lo, dtype=torch.float64, device=be.device)
+        own_m = torch.empty(s_hi - s_lo, dtype=torch.int32, device=be.device)
 
     def step():
-        sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m, unpack=unpack)
+        if mode == "allgather":
+            sharding.run_allgather(plan, compute, out_d, out_m, wire_d, wire_m, unpack=unpack)
+        elif mode == "none":
+            sharding.run_local(plan, compute, own_d, own_m)
+        else:
+            sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m, unpack=unpack)
 
     def barrier():
         if dg is not None:
@@ -450,6 +467,24 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
         be.fault_check()
     lo0, hi0 = plan.bounds(plan.rank)
     pairs_this_rank = hi0 - lo0
+    per_rank = None
+    if dg is not None:
+        # what every rank did, as seen on its own GPU: kernel milliseconds per step and pairs per step (the driver's first
+        # multi-GPU run should show whether the kernels scale even where the gather does not)
+        mine = torch.tensor([kernel_ms, float(pairs_this_rank)], dtype=torch.float64, device=be.device)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dg.all_gather(everyone, mine)
+        per_rank = {"kernel_ms": [float(t[0].item()) for t in everyone], "pairs": [int(t[1].item()) for t in everyone]}
+    if mode == "none":
+        # untimed: the slices are assembled on rank 0 once (the root gather with the same plan), so that the parity
+        # check and the path statistics below see the whole batch (kernel_ms was read above)
+        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, device=be.device, packed_ids=packed)
+        sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m, unpack=unpack)
+        be.synchronize()
+        if rank == 0:      # the timed slice of this rank must be what the assembled result holds
+            if not (torch.equal(own_d.view(torch.int64), out_d[lo0:hi0].view(torch.int64)) and torch.equal(own_m, out_m[lo0:hi0])):
+                raise SystemExit("bench.py: --gather none: rank 0's resident slice differs from the assembled result")
+        be.fault_check()
 
     line = None
     if rank != 0 and peers_wait is not None:
@@ -464,7 +499,12 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
         checksum = float(out_d.sum().item())
         traffic, traffic_file = latest_traffic()
         line = build_line(args, world, plan, info, len(parent), elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
-                          pairs_this_rank, calib, traffic, traffic_file, wire_bytes)
+                          pairs_this_rank, calib, traffic, traffic_file, wire_bytes, mode)
+        if dg is not None:
+            line["process_group"] = {"backend": str(dg.get_backend()), "world_size": int(dg.get_world_size()),
+                                     "what": "as torch.distributed reports them for the group the step ran on (nccl = RCCL on ROCm)"}
+        if per_rank:
+            line["per_rank"] = per_rank
         roof = line["roofline"]
         if hasattr(be, "extra_legs"):
             be.extra_legs(args, line, roof, pairs, out_d, out_m, traffic, traffic_file, pairs_this_rank, kernel_ms)
@@ -487,7 +527,7 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
 
 
 def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
-               pairs_this_rank, calib, traffic, traffic_file, wire_bytes=8):
+               pairs_this_rank, calib, traffic, traffic_file, wire_bytes=8, mode="root"):
     """The contract's JSON line from the measured quantities (no measurement happens here)."""
     n = args.pairs
     strong = not args.weak
@@ -569,13 +609,22 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
                                % (args.levels, n_nodes,
                                   ("%d uniform random leaf pairs per GPU per step" % n) if args.weak else
                                   ("one batch of %d uniform random leaf pairs per step, sharded over %d GPU(s)" % (n, world)),
-                                  "" if (args.weak or world == 1) else " assembled on rank 0 inside the timed region"),
+                                  "" if (args.weak or world == 1) else
+                                  {"root": " assembled on rank 0 inside the timed region",
+                                   "allgather": " assembled on every rank inside the timed region",
+                                   "none": "; every rank keeps its slice (nothing travels inside the timed region)"}[mode]),
                    "pairs_per_step": n_job, "pairs_per_gpu": pairs_this_rank if strong else n,
                    "tree_levels": args.levels, "kernel_family": info["strategy"],
                    "canopy_nodes": info["canopy_nodes"], "record_bytes": info["record_bytes"],
-                   "sharding": ("contiguous pair slices (rank 0: %.0f %% of the batch, the peers share the rest: its kernels "
-                                "end when their transfers do), tree replicated, no data-path collective; results to rank 0 "
-                                "by RCCL send/recv over xGMI (%s on the wire, %d pieces per slice)"
+                   "gather": mode if (strong and world > 1) else None,
+                   "sharding": ({"root": "contiguous pair slices (rank 0: %.0f %% of the batch, the peers share the rest: its kernels "
+                                         "end when their transfers do), tree replicated, no data-path collective; results to rank 0 "
+                                         "by RCCL send/recv over xGMI (%s on the wire, %d pieces per slice)",
+                                 "allgather": "even contiguous pair slices (rank 0: %.0f %%), tree replicated, no data-path collective; every "
+                                              "rank sends its result pieces to every other rank by grouped RCCL send/recv over xGMI (%s on "
+                                              "the wire, %d pieces per slice)",
+                                 "none": "even contiguous pair slices (rank 0: %.0f %%), tree replicated, nothing travels: float64 + int32 "
+                                         "results stay on the GPU that computed them (%s would be the wire format; %d launches per slice)"}[mode]
                                 % (100.0 * pairs_this_rank / max(n, 1),
                                    "float32 + 24-bit MRCA id = 7 bytes per pair" if wire_bytes == 7 else "float32 + int32 = 8 bytes per pair", plan.chunks))
                    if (strong and world > 1) else "none" if world == 1 else
@@ -587,9 +636,10 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     }
     if strong and world > 1:
         # what the gather costs on top of the slowest rank's kernels (exposed, after overlap)
+        line["gather"] = mode
         line["gather_ms"] = max(0.0, ms_per_step - kernel_ms_max)
         line["wire_bytes_per_pair"] = wire_bytes
-        line["gather_bytes_into_root"] = wire_bytes * (n - pairs_this_rank)
+        line["gather_bytes_into_root"] = 0 if mode == "none" else wire_bytes * (n - pairs_this_rank)
         line["root_share"] = pairs_this_rank / max(n, 1)
         if calib:
             line["root_share_calibration"] = calib

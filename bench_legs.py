@@ -214,44 +214,39 @@ def host_path_leg(be, pairs, out_d, out_m):
         tree.distances_host(host_pairs, True, False, out_dist=h_d)
         t_d = min(t_d, time.perf_counter() - t)
     d_ok = bool(np.array_equal(h_d.view(np.int64), ref_d.view(np.int64)))
-    # measurement switches of the pipeline (results are not produced): the CPU passes alone (nothing launched) and the
+    # measurement switches of the pipeline (handle option "measure"; results are not produced and the call says so): the CPU passes alone (nothing launched) and the
     # GPU / link side alone (no pack, no unpack).  The first bounds what ONE process can feed: a multi-device handle
     # (SuchTree(..., devices=[0..7])) runs one such pipeline per GPU against the same host memory system, so
     # cpu_passes / pairs_per_s is the most it can scale to on this host.
-    def switched(var):
-        os.environ[var] = "1"
+    def switched(bits):
+        from suchtree_amd._capi import MeasureOnly
+        tree.set_option("measure", bits)
         try:
-            tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
             best = 1e30
-            for _ in range(2):
+            for _ in range(3):
                 t0 = time.perf_counter()
-                tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+                try:
+                    tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)
+                except MeasureOnly:      # (what such a call returns: its results are not valid)
+                    pass
+                else:
+                    raise RuntimeError("a call under the measure option must not return ST_OK")
                 best = min(best, time.perf_counter() - t0)
             return best
         finally:
-            del os.environ[var]
-    t_cpu = switched("SUCHTREE_AMD_PIPE_SKIP_GPU")
-    t_link = switched("SUCHTREE_AMD_PIPE_SKIP_CPU")
+            tree.set_option("measure", 0)
+    t_cpu = switched(4)
+    t_link = switched(2)
     tree.distances_host(host_pairs, True, True, out_dist=h_d, out_mrca=h_m)      # (the arrays hold results again)
-    # opt-in: result arrays from the recycled pinned pool, written by the kernel directly
-    tree.pinned_results = True
-    p_d, p_m = tree.distances_host(host_pairs, True, True)
-    pooled_ok = bool(np.array_equal(p_d.view(np.int64), ref_d.view(np.int64)) and np.array_equal(p_m, ref_m))
-    del p_d, p_m
-    t_p = time.perf_counter()
-    p_d, p_m = tree.distances_host(host_pairs, True, True)
-    t_p = time.perf_counter() - t_p
-    del p_d, p_m
-    tree.pinned_results = False
     return {
         "pairs_per_s": k2 / t_h, "pairs_per_s_fresh_arrays": k2 / t_f,
         "pairs_per_s_call_and_drop_loop": k2 / t_l,
         "pairs_per_s_int32_ids": k2 / t_32,
         "pairs_per_s_distances_only": k2 / t_d,
-        "pairs_per_s_pinned_result_pool": k2 / t_p, "pairs": k2,
+        "pairs": k2,
         "cpu_passes_pairs_per_s": k2 / t_cpu, "link_side_pairs_per_s": k2 / t_link,
         "one_process_many_gpus_ceiling": {"x_one_gpu": (k2 / t_cpu) / (k2 / t_h),
-                                          "why": "the pack / unpack passes alone (SUCHTREE_AMD_PIPE_SKIP_GPU=1) sustain cpu_passes_pairs_per_s on "
+                                          "why": "the pack / unpack passes alone (handle option measure = 4) sustain cpu_passes_pairs_per_s on "
                                                  "this host; a multi-device handle feeds one pipeline per GPU from the same host memory system"},
         "link_bytes_per_pair": {"in": wire_in, "out": wire_out},
         "link_GBps_out": float(wire_out) * k2 / t_h / 1e9,
@@ -260,12 +255,11 @@ def host_path_leg(be, pairs, out_d, out_m):
                 "result arrays allocated by the call, first use of their memory (what a single "
                 "SuchTree.distances_bulk call returns) / the same call in a loop that drops each result "
                 "(blocks recycled by the library, release included) / int32 ids handed over as they are / distances alone, as "
-                "the reference's distances() returns them (reused array) / opt-in "
-                "pinned result pool (float64 + int32 written by the kernel straight into the returned arrays)",
+                "the reference's distances() returns them (reused array)",
         "matches_device_results": bool(np.array_equal(f_d.view(np.int64), ref_d.view(np.int64))
                                        and np.array_equal(f_m, ref_m)
                                        and np.array_equal(h_d.view(np.int64), ref_d.view(np.int64))
-                                       and np.array_equal(h_m, ref_m) and pooled_ok and loop_ok and i32_ok and d_ok)}
+                                       and np.array_equal(h_m, ref_m) and loop_ok and i32_ok and d_ok)}
 
 
 # --------------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ extern "C" {
 #define ST_ERR_BOUNDS  3   /* a node id in `pairs` is outside [0, n_nodes) */
 #define ST_ERR_NOMEM   4   /* host allocation failed */
 #define ST_ERR_TREE    5   /* parent array is not a single rooted binary tree */
+#define ST_ERR_MEASURE_ONLY 6   /* the handle's "measure" option made this host-path call skip work: timing only, results invalid */
 
 /* kernel families (st_tree_create `strategy`, st_tree_info.strategy) */
 #define ST_STRATEGY_AUTO    0  /* canopy when the tree admits it, else walk */
@@ -91,8 +92,7 @@ typedef struct st_tree_options {
 
 /* st_tree_info.big_batch_kernel */
 #define ST_KERNEL_WALK            0   /* k_walk / k_walk_sorted: trees the canopy family does not serve */
-#define ST_KERNEL_CANOPY          1   /* predicated canopy kernel (one pair per lane, chain in registers) */
-#define ST_KERNEL_CANOPY_SCALAR   2   /* branchy canopy kernel */
+#define ST_KERNEL_CANOPY          1   /* predicated canopy kernel (one pair per lane, chain in registers); 2: unused since round 5 */
 #define ST_KERNEL_CANOPY_SORTED   3   /* tile-sorted canopy kernel (ladder form of the canopy in LDS) */
 #define ST_KERNEL_WALK_SORTED     4   /* tile-sorted walk kernel on a tree that also has canopy tables */
 #define ST_KERNEL_CANOPY_LADDER   5   /* scalar canopy kernel over the ladder form (long records in registers, read once) */
@@ -291,9 +291,7 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
  * ST_ERR_ARG if the tree was built without that family's tables. */
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
-/* Tuning knobs (benchmarking / tests).  "pairs_per_lane": pairs each lane of the canopy
- * kernel keeps in flight: 1 (default) or 2 (explicit pair arrays only, chains of up to 15 slots); 0 = scalar,
- * branchy form (chains read through a pointer).
+/* Tuning knobs (benchmarking / tests).
  * "tile_sort": 1 = every workgroup sorts its tile of pairs by expected climb length so that a wave's lanes
  * finish together (deep canopies: the default where it measured fastest when the tree was created, see
  * "prefer_walk_sorted" below); 0 = pairs in input order.
@@ -320,7 +318,7 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * tables run the tile-sorted walk kernel (a wave's 64 pairs have streams of similar length); 0 = k_walk.
  * "prefer_walk_sorted": 1 = distance batches of >= 524288 pairs on a canopy-strategy tree that also has the walk
  * family's tables (deep trees) go to the tile-sorted walk kernel; 0 = they stay with the canopy kernels.  Like
- * "tile_sort" and "pairs_per_lane" its default is set when the tree is created, on deep trees by timing the candidate
+ * "tile_sort" its default is set when the tree is created, on deep trees by timing the candidate
  * kernels on a sample of random leaf pairs (st_tree_info.tuned; SUCHTREE_AMD_AUTOTUNE=0: by a fixed rule).
  * "ladder_scalar": 1 = distance batches of at least "ladder_min_pairs" pairs (0 = 131072) on records of 128 bytes and
  * more are served by the scalar kernel over the ladder form of the canopy (records read once, no sort: large batches);
@@ -329,7 +327,7 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * paths -- does better with "ladder_scalar" 0 and "prefer_walk_sorted" 1: the walk family's cost follows the path
  * length; nj.tree, leaves within 8 of each other: 1.4e10 -> 1.9e10 pairs/s, ml.tree 1.7e10 -> 2.0e10).
  * "ladder_dynamic": 1 (default) = on records of 512 bytes and more, batches of 2^22 pairs and more (2^21 on 1 KB
- * records) of that kernel draw their work from per-XCD counters instead of a static deal; 0 = never; 2 = always.
+ * records) of that kernel draw their work from per-XCD counters instead of a static deal; 0 = never.
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.
  * "sort_tile": tile of both tile-sorted kernels in units of 1024 pairs: 1, 2 or 4 (taken when it fits LDS and the
  * kernel's form has that tile), 0 (default) = the largest tile LDS admits, cut finer for batches that would
@@ -346,7 +344,10 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * kernels a few CUs of their own.
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
- * staged pipe. */
+ * staged pipe.
+ * "measure" (default 0; MEASUREMENT ONLY): bits 1 = one line per host-path call on stderr with the host thread's time by
+ * phase, 2 = the host path skips its pack / unpack passes, 4 = it launches nothing.  A call made with bit 2 or 4 set
+ * returns ST_ERR_MEASURE_ONLY, never ST_OK: its result arrays are not valid. */
 int st_tree_set_option(st_tree *tree, const char *name, int64_t value);
 
 /*
@@ -390,18 +391,6 @@ int st_newick_fill(const st_newick *h, int32_t *parent, int32_t *left, int32_t *
                    float *support, float *distance, int32_t *leaf_ids, char *names,
                    int64_t *name_offsets);
 void st_newick_close(st_newick *h);
-
-/*
- * Pinned, GPU-addressable host memory for result arrays.  The "_host" entry points recognise
- * result arrays that live in such memory (these blocks, hipHostRegister-ed memory, pinned torch
- * tensors) and let the kernels write the float64 distances / int32 MRCA ids straight into them:
- * no staging slot, no unpack pass on the CPU, no page faults on first touch and no page
- * teardown when the array is released.  suchtree_amd hands its numpy results out of a
- * recycled pool of these blocks (the reference allocates a fresh numpy array per call,
- * SuchTree/MuchTree.pyx:906-907).
- */
-int st_host_alloc(int64_t bytes, void **out);
-int st_host_free(void *ptr);
 
 /* Thin device-memory helpers so callers without torch can stage buffers. */
 int st_device_malloc(int device, int64_t bytes, void **out);

@@ -2,7 +2,6 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash scripts/gpu_session.sh <step> ...'): named measurement steps, each writing
 # gpurun_out/<step>.log.  One parameterised script instead of one file per experiment.
 #   tests [pytest args]     the -m gpu suite (or the files / -k expression given), log kept
-#   hostpath [pairs]        scripts/host_path_trace.py
 #   choice <tree> ...       scripts/kernel_choice_probe.py for every tree named (ml nj s70 s80 s85 <leaves>:<skew>)
 #   bench [args]            python bench.py [args]
 #   py <script> [args]      any script under scripts/
@@ -11,7 +10,6 @@ mkdir -p gpurun_out
 STEP=$1; shift
 case $STEP in
   tests)    timeout 3000 python -m pytest tests -m gpu -x -q "$@" 2>&1 | tee gpurun_out/tests.log | tail -15 ;;
-  hostpath) timeout 900 python scripts/host_path_trace.py "$@" 2>&1 | tee gpurun_out/hostpath.log ;;
   choice)   for T in "$@"; do timeout 900 python scripts/kernel_choice_probe.py $T 2>&1 | grep -v Warning; done | tee gpurun_out/choice.log ;;
   bench)    timeout 1500 python bench.py "$@" 2> gpurun_out/bench.err | tee gpurun_out/bench.json | cut -c1-1500 ;;
   py)       S=$1; shift; timeout 1500 python scripts/$S "$@" 2>&1 | tee gpurun_out/$(basename $S .py).log ;;

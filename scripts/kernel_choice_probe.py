@@ -33,8 +33,7 @@ def t(label):
 t("default")
 tree.set_option("prefer_walk_sorted", 0)
 tree.set_option("ladder_scalar", 0); tree.set_option("tile_sort", 1); t("tile-sorted canopy kernel")
-tree.set_option("tile_sort", 0); tree.set_option("pairs_per_lane", 1); tree.set_option("ladder_scalar", 0); t("predicated kernel (ilp)")
+tree.set_option("tile_sort", 0); tree.set_option("ladder_scalar", 0); t("predicated kernel (ilp)")
 tree.set_option("ladder_scalar", 1); tree.set_option("ladder_min_pairs", 0); t("scalar ladder kernel"); tree.set_option("ladder_dynamic", 0); t("scalar ladder kernel, static deal"); tree.set_option("ladder_dynamic", 1); tree.set_option("ladder_scalar", 0)
-tree.set_option("tile_sort", 0); tree.set_option("pairs_per_lane", 0); t("scalar canopy kernel")
 tree.set_strategy("walk"); t("walk family")
 tree.close()

@@ -4,7 +4,7 @@
 # and profiles/traffic_*_<round>.json (copied back through gpurun_out/round_profiles/).
 # usage: scripts/profile_round.sh r04
 R=${1:-r04}
-LADDER="--opt tile_sort=0 --opt pairs_per_lane=1 --opt ladder_scalar=1 --opt ladder_min_pairs=0"
+LADDER="--opt tile_sort=0 --opt ladder_scalar=1 --opt ladder_min_pairs=0"
 bash scripts/profile_gpu.sh $R 2>&1 | tail -3
 bash scripts/profile_kernel.sh ml_$R k_canopy_ladder 10000000 --tree ml $LADDER 2>&1 | tail -2
 bash scripts/profile_kernel.sh nj_$R k_canopy_ladder 10000000 --tree nj $LADDER 2>&1 | tail -2

@@ -60,7 +60,6 @@ def main():
                 want_d = True
             try:
                 if rng.random() < 0.3:
-                    dev.set_option("pairs_per_lane", int(rng.choice([0, 1, 2])))
                     dev.set_option("small_batch_path", int(rng.integers(0, 2)))
                     if k == 0:
                         dev.set_option("tile_sort", int(rng.integers(0, 2)))
@@ -73,7 +72,7 @@ def main():
                     if k in (0, 2):
                         dev.set_option("ladder_scalar", int(rng.integers(0, 2)))
                         dev.set_option("ladder_min_pairs", int(rng.choice([0, 0, 300000])))
-                        dev.set_option("ladder_dynamic", int(rng.choice([0, 1, 2])))
+                        dev.set_option("ladder_dynamic", int(rng.choice([0, 1])))
                     if k in (0, 4):
                         for name in ("walk_sort", "walk_ladder", "walk_crown", "lineage_lens"):
                             dev.set_option(name, int(rng.random() < 0.8))

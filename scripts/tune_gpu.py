@@ -1,7 +1,7 @@
 """A/B timing of kernel variants in ONE process on the GPU box (interleaved,
 several rounds), e.g.
 
-    python scripts/tune_gpu.py --levels 20 --pairs 100000000 --opt pairs_per_lane=0,1,2
+    python scripts/tune_gpu.py --levels 20 --pairs 100000000 --opt rec_a4=0,1
 
 Prints median kernel ms and pairs/s per setting and checks that every setting
 produces identical outputs.

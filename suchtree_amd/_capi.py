@@ -14,10 +14,10 @@ from .exceptions import HipBackendError, InvalidNodeError, TreeStructureError
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsuchtree_hip.so")
 
-ST_OK, ST_ERR_ARG, ST_ERR_HIP, ST_ERR_BOUNDS, ST_ERR_NOMEM, ST_ERR_TREE = 0, 1, 2, 3, 4, 5
+ST_OK, ST_ERR_ARG, ST_ERR_HIP, ST_ERR_BOUNDS, ST_ERR_NOMEM, ST_ERR_TREE, ST_ERR_MEASURE_ONLY = 0, 1, 2, 3, 4, 5, 6
 STRATEGY = {"auto": 0, "walk": 1, "canopy": 2}
 STRATEGY_NAME = {v: k for k, v in STRATEGY.items()}
-BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 2: "canopy_scalar", 3: "canopy_sorted", 4: "walk_sorted", 5: "canopy_ladder"}      # ST_KERNEL_*
+BIG_BATCH_KERNEL = {0: "walk", 1: "canopy", 3: "canopy_sorted", 4: "walk_sorted", 5: "canopy_ladder"}      # ST_KERNEL_*
 
 # ST_TABLE_* bits of st_tree_info.dropped_tables, in the order a table budget drops them
 DROPPED_TABLES = ((1, "lineage_len"), (2, "lineage_sum"), (4, "tree_rmq"), (8, "rec_i"), (16, "rec_a4"), (32, "ranks"), (64, "canopy"))
@@ -39,7 +39,7 @@ SYMBOLS = (
     "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_distances_device_wire", "st_unpack_mrca24_device", "st_fault_check", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
-    "st_host_depths", "st_link_sample_pairs", "st_bucket_moments", "st_host_alloc", "st_host_free", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
+    "st_host_depths", "st_link_sample_pairs", "st_bucket_moments", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
     "st_device_synchronize",
 )
 
@@ -197,8 +197,6 @@ def load():
         L.st_host_depths.argtypes = [vp, i64, vp, ctypes.POINTER(ctypes.c_int32)]
         L.st_link_sample_pairs.argtypes = [ctypes.POINTER(ctypes.c_uint64), vp, i64, i64, vp, vp]
         L.st_bucket_moments.argtypes = [vp, i64, i64, vp, vp]
-        L.st_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
-        L.st_host_free.argtypes = [vp]
         L.st_device_malloc.argtypes = [i32, i64, ctypes.POINTER(vp)]
         L.st_device_free.argtypes = [i32, vp]
         L.st_memcpy_h2d.argtypes = [i32, vp, vp, i64]
@@ -209,6 +207,11 @@ def load():
                 getattr(L, name).restype = i32
         _lib = L
     return _lib
+
+
+class MeasureOnly(HipBackendError):
+    """A host-path call made under the handle option ``measure`` (2 / 4) skipped part of the pipeline: its time counts,
+    its results do not (bench_legs.host_path_leg)."""
 
 
 def last_error():
@@ -228,6 +231,8 @@ def check(rc, tree_size=None, bad_id=None):
         raise ValueError(msg)
     if rc == ST_ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == ST_ERR_MEASURE_ONLY:
+        raise MeasureOnly(msg)
     raise HipBackendError(msg)
 
 
@@ -313,91 +318,6 @@ def host_chunk_map(n, n_devices):
     return out
 
 
-class _Lent:
-    """A pinned block on loan to one numpy array (its ``base``); goes back to the pool when the
-    array and every view of it are gone."""
-
-    def __init__(self, pool, ptr, capacity, n, dtype):
-        self._pool, self._ptr, self._capacity = pool, ptr, capacity
-        self.__array_interface__ = {"data": (ptr, False), "shape": (n,), "typestr": np.dtype(dtype).str, "version": 3}
-
-    def __del__(self):
-        try:
-            self._pool._give_back(self._ptr, self._capacity)
-        except Exception:     # interpreter shutdown
-            pass
-
-
-class ResultPool:
-    """Recycled pinned, GPU-addressable blocks (``st_host_alloc``) for result arrays.
-
-    A result array that lives in such a block is written by the kernels directly over PCIe:
-    no staging slot, no unpack pass on the CPU, no page faults on first touch and no page
-    teardown when it is released -- for batches of 1e6-1e8 pairs those cost as much as the
-    computation (``scripts/thp_probe.py``).  OPT-IN (``SuchTree(..., pinned_results=True)`` or
-    ``SUCHTREE_AMD_PINNED_RESULTS=1``) because of one behavioural difference: pinned memory is
-    not inherited by ``fork()`` children (the driver marks it DONTFORK), so a result array
-    handed to a fork-pool worker is unreadable there; ordinary numpy arrays are.
-    ``budget_bytes`` caps what the pool keeps pinned; beyond it callers get ordinary arrays.
-    """
-
-    MIN_BYTES = 1 << 20
-
-    def __init__(self, budget_bytes=None):
-        if budget_bytes is None:
-            budget_bytes = int(os.environ.get("SUCHTREE_AMD_RESULT_POOL_MB", "4096")) << 20
-        self.budget = int(budget_bytes)
-        self.total = 0
-        self._free = {}
-        # re-entrant: the garbage collector may run a lent block's __del__ (-> _give_back) on this
-        # very thread while it is inside array() / _give_back()
-        self._lock = threading.RLock()
-        self._pid = os.getpid()
-
-    @staticmethod
-    def _size_class(nbytes):
-        cap = 1 << 21
-        while cap < nbytes and cap < (1 << 26):
-            cap <<= 1
-        if cap < nbytes:                                   # beyond 64 MiB: multiples of 64 MiB
-            cap = (nbytes + (1 << 26) - 1) >> 26 << 26
-        return cap
-
-    def array(self, n, dtype):
-        """A 1-D array of ``n`` items in a pinned block, or None (too small, over budget, no GPU)."""
-        nbytes = int(n) * np.dtype(dtype).itemsize
-        if nbytes < self.MIN_BYTES or self._pid != os.getpid():
-            return None
-        cap = self._size_class(nbytes)
-        with self._lock:
-            stack = self._free.get(cap)
-            ptr = stack.pop() if stack else None
-            if ptr is None:
-                if self.total + cap > self.budget:
-                    return None
-                p = ctypes.c_void_p()
-                if load().st_host_alloc(cap, ctypes.byref(p)) != ST_OK or not p.value:
-                    return None
-                ptr = p.value
-                self.total += cap
-        return np.asarray(_Lent(self, ptr, cap, int(n), dtype))
-
-    def _give_back(self, ptr, cap):
-        if self._pid != os.getpid():       # a forked child must not touch the parent's HIP state
-            return
-        with self._lock:
-            self._free.setdefault(cap, []).append(ptr)
-
-    def trim(self):
-        """Unpin every block that is not on loan."""
-        with self._lock:
-            free, self._free = self._free, {}
-        for cap, ptrs in free.items():
-            for ptr in ptrs:
-                load().st_host_free(ctypes.c_void_p(ptr))
-                self.total -= cap
-
-
 class _LentBlock:
     """An ordinary (pageable) block on loan to one numpy array; see RecyclePool."""
 
@@ -413,13 +333,12 @@ class _LentBlock:
 
 
 class RecyclePool:
-    """Recycled ordinary memory for LARGE result arrays (the default; the pinned ResultPool is the
-    opt-in alternative).
+    """Recycled ordinary memory for LARGE result arrays.
 
     What a fresh numpy array costs beyond 32 MiB -- where glibc stops recycling freed blocks and
     maps / unmaps every one -- is the kernel zeroing its pages on first touch and tearing them
     down on release: for 5e7 pairs (600 MB of float64 + int32) three times as long as the
-    computation (``scripts/thp_probe.py``, ``profiles/host_path_r02.jsonl``: 1.2e9 pairs/s for
+    computation (``profiles/host_path_r02.jsonl``: 1.2e9 pairs/s for
     "call, drop the result" against 4.8e9 into arrays that are reused).  Result arrays of that
     size are therefore handed out as views of blocks that come back here when the array and all
     its views are gone, and go out again, resident, with the next call.  The memory is ordinary:
@@ -440,12 +359,21 @@ class RecyclePool:
         # very thread while it is inside array() / _give_back()
         self._lock = threading.RLock()
 
+    @staticmethod
+    def _size_class(nbytes):
+        cap = 1 << 21
+        while cap < nbytes and cap < (1 << 26):
+            cap <<= 1
+        if cap < nbytes:                                   # beyond 64 MiB: multiples of 64 MiB
+            cap = (nbytes + (1 << 26) - 1) >> 26 << 26
+        return cap
+
     def array(self, n, dtype):
         """A 1-D array of ``n`` items in a recycled block, or None (too small, over budget)."""
         nbytes = int(n) * np.dtype(dtype).itemsize
         if nbytes < self.MIN_BYTES or self.budget <= 0:
             return None
-        cap = ResultPool._size_class(nbytes)
+        cap = self._size_class(nbytes)
         with self._lock:
             stack = self._free.get(cap)
             block = stack.pop() if stack else None
@@ -479,16 +407,6 @@ def recycle_pool():
     return _recycle_pool
 
 
-_result_pool = None
-
-
-def result_pool():
-    global _result_pool
-    if _result_pool is None or _result_pool._pid != os.getpid():
-        _result_pool = ResultPool()
-    return _result_pool
-
-
 def device_count():
     c = ctypes.c_int(0)
     rc = load().st_device_count(ctypes.byref(c))
@@ -518,14 +436,11 @@ class DeviceTree:
     ``devices=[...]`` -- replicated on several GPUs of the node (``st_tree_create_multi``),
     the host-buffer entry points then dealing their chunks over all of them."""
 
-    def __init__(self, parent, distance, device=0, strategy="auto", devices=None, pinned_results=None, table_mb=None):
+    def __init__(self, parent, distance, device=0, strategy="auto", devices=None, table_mb=None):
         """``table_mb``: budget (MiB) for the tree's device tables (st_tree_options.table_budget_bytes; default: the
         environment's SUCHTREE_AMD_TABLE_MB, else none): accelerator tables are left out, in a stated order, until the
         rest fits -- ``info()["dropped_tables"]`` names them; results are the same bits."""
         global _gpu_pid
-        if pinned_results is None:
-            pinned_results = os.environ.get("SUCHTREE_AMD_PINNED_RESULTS", "0") == "1"
-        self.pinned_results = bool(pinned_results)
         _check_fork()
         L = load()
         self._lib = L
@@ -596,7 +511,7 @@ class DeviceTree:
         if not want:
             return None
         if buf is None:
-            arr = (result_pool() if self.pinned_results else recycle_pool()).array(n, dtype)
+            arr = recycle_pool().array(n, dtype)
             if arr is not None:
                 return arr
             return np.empty(n, dtype=dtype)
@@ -693,7 +608,7 @@ class DeviceTree:
     def quartets_host(self, quartets):
         """quartets: int64 (n,4) ndarray (any non-negative strides); returns int64 (n,4)."""
         n = int(quartets.shape[0])
-        flat = None if self.pinned_results else recycle_pool().array(4 * n, np.int64)      # (large results: recycled blocks)
+        flat = recycle_pool().array(4 * n, np.int64)      # (large results: recycled blocks)
         out = flat.reshape(n, 4) if flat is not None else np.empty((n, 4), dtype=np.int64)
         if n == 0:
             return out

@@ -230,8 +230,6 @@ inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, 
         std::memcpy(out + 6 * k, &w, 6);
     }
     const bool wide = cpu_has_avx2() && s0 == 2 && s1 == 1 && n_nodes >= 1 && n_nodes <= 0xFFFFFF;
-    // SUCHTREE_AMD_PACK_CACHED=1 (experiment): ordinary stores instead of streaming stores for the packed ids
-    static const bool cached = std::getenv("SUCHTREE_AMD_PACK_CACHED") != nullptr;
     for (; k + 4 <= m; k += 4) {
         long long *q = reinterpret_cast<long long *>(out + 6 * k);      // 8-byte aligned: dst is 16-byte aligned, 6 (first + k) is a multiple of 24
         uint64_t w[3];
@@ -246,13 +244,9 @@ inline void pack_pairs48(uint8_t *dst, int64_t first, const Id *src, int64_t m, 
             w[1] = (p1 >> 16) | (p2 << 32);
             w[2] = (p2 >> 32) | (p3 << 16);
         }
-        if (cached) {
-            q[0] = (long long)w[0]; q[1] = (long long)w[1]; q[2] = (long long)w[2];
-        } else {
-            _mm_stream_si64(q + 0, (long long)w[0]);
-            _mm_stream_si64(q + 1, (long long)w[1]);
-            _mm_stream_si64(q + 2, (long long)w[2]);
-        }
+        _mm_stream_si64(q + 0, (long long)w[0]);
+        _mm_stream_si64(q + 1, (long long)w[1]);
+        _mm_stream_si64(q + 2, (long long)w[2]);
     }
     for (; k < m; k++) {
         const uint64_t w = one(k);
@@ -297,14 +291,7 @@ inline void populate_for_write(void *p, int64_t bytes)
     // page faults -- and the next call tries again.  Called from all copy threads: atomic.
     static std::atomic<int> have_populate{1};
     static std::atomic<int> probed{0};
-    // SUCHTREE_AMD_POPULATE=madv|touch|none: measurement override of the choice below
-    static const int forced = [] {
-        const char *env = std::getenv("SUCHTREE_AMD_POPULATE");
-        if (!env) return 0;
-        return !std::strcmp(env, "madv") ? 1 : !std::strcmp(env, "touch") ? 2 : !std::strcmp(env, "none") ? 3 : 0;
-    }();
-    if (forced == 3) return;
-    if ((forced == 1 || (forced == 0 && !thp_available())) && have_populate.load(std::memory_order_relaxed)) {
+    if (!thp_available() && have_populate.load(std::memory_order_relaxed)) {
         const int rc = madvise(reinterpret_cast<void *>(b), e - b, MADV_POPULATE_WRITE);
         const int err = rc == 0 ? 0 : errno;
         const bool first = probed.exchange(1, std::memory_order_relaxed) == 0;

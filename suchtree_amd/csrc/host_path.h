@@ -27,11 +27,6 @@ constexpr int64_t kMailboxPairs = 8192;   // largest batch served through the ma
 // several devices the chunk shrinks (down to kHostChunkMin) so that every device gets work.
 static int64_t host_chunk_pairs(int64_t n, int n_dev)
 {
-    static const int64_t forced = [] {     // tuning experiments
-        const char *env = std::getenv("SUCHTREE_AMD_HOST_CHUNK");
-        return env ? std::max<int64_t>(1024, std::atoll(env)) / 1024 * 1024 : (int64_t)0;
-    }();
-    if (forced) return n <= forced ? std::max<int64_t>(n, 1) : forced;
     if (n <= kHostChunkMin) return std::max<int64_t>(n, 1);
     // at least eight chunks per device, so that packing, the link and unpacking overlap even
     // on batches of a few million pairs; never below kHostChunkMin, never above kHostChunk
@@ -153,13 +148,6 @@ static hipError_t enqueue_words_copy(const void *src, void *dst, int64_t n_words
     return hipGetLastError();
 }
 
-// float32 (device) -> float64 (pinned host), coalesced: the staged form of a direct result write
-__global__ __launch_bounds__(1024) void k_widen_copy(const float *__restrict__ src, double *__restrict__ dst, long long n)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = (double)src[i];
-}
-
 // int32 MRCA ids (device) -> the 24-bit wire format (pinned host), coalesced: the staged form of a direct result write
 __global__ __launch_bounds__(1024) void k_pack24_copy(const int *__restrict__ src, unsigned char *__restrict__ dst, long long n)
 {
@@ -171,45 +159,27 @@ __global__ __launch_bounds__(1024) void k_pack24_copy(const int *__restrict__ sr
     }
 }
 
-// Is [p, p + bytes) pinned host memory the GPU can address (hipHostMalloc / hipHostRegister)?
-// Result arrays like that -- st_host_alloc blocks, pinned torch tensors -- are written by the
-// kernels directly: no staging slot, no unpack pass, no page faults.
-static bool device_visible_host(const void *p, int64_t bytes)
-{
-    if (!p || bytes <= 0) return false;
-    for (const char *q : {static_cast<const char *>(p), static_cast<const char *>(p) + bytes - 1}) {
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, q) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (attr.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-}
-
-// Where the results of a host-path call go: the caller's arrays, and whether the kernels can
-// write each of them directly.
+// Where the results of a host-path call go: the caller's arrays (any host memory; results always come back through the
+// pinned slots as float32 + 24-bit / int32 ids and are widened into them by the unpack pass.  Round 4 let the kernels
+// write float64 + int32 straight into result arrays that were themselves pinned -- 12 bytes per pair over the link
+// instead of 7: 2.65e9 pairs/s where the staged form does 4.98e9, profiles/bench_r04_selfrun.json -- removed).
 struct HostOut {
     double *dist = nullptr;
     int32_t *mrca = nullptr;
-    bool direct_d = false, direct_m = false;
-    bool wire24 = false;      // staged MRCA ids cross the link as 24 bits each (device_common.h::MrcaSink)
+    bool wire24 = false;      // MRCA ids cross the link as 24 bits each (device_common.h::MrcaSink)
 };
 
-// MRCA ids come back as 24 bits each on trees of fewer than 2^24 nodes (option wire24; direct result arrays take int32)
+// MRCA ids come back as 24 bits each on trees of fewer than 2^24 nodes (option wire24)
 static bool wire24_of(const st_tree *t, const HostOut &out)
 {
-    return out.mrca && !out.direct_m && t->wire24 && t->n_nodes <= 0xFFFFFF;
+    return out.mrca && t->wire24 && t->n_nodes <= 0xFFFFFF;
 }
 
-static HostOut make_host_out(double *out_dist, int32_t *out_mrca, int64_t n)
+static HostOut make_host_out(double *out_dist, int32_t *out_mrca)
 {
     HostOut o;
     o.dist = out_dist;
     o.mrca = out_mrca;
-    o.direct_d = device_visible_host(out_dist, n * 8);
-    o.direct_m = device_visible_host(out_mrca, n * 4);
     return o;
 }
 
@@ -225,24 +195,19 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
 {
     if (!wants_device_stage(r, m) || (!out.dist && mrca_ranks_ready(r))) {
         DistSink sink{nullptr, nullptr};
-        if (out.dist) {
-            if (out.direct_d) sink.d64 = out.dist + off;
-            else sink.f32 = static_cast<float *>(s.h_d);
-        }
+        if (out.dist) sink.f32 = static_cast<float *>(s.h_d);
         MrcaSink mrca{nullptr, nullptr};
         if (out.mrca) {
-            if (out.direct_m) mrca.m32 = out.mrca + off;
-            else if (out.wire24) mrca.m24 = static_cast<unsigned char *>(s.h_m);
+            if (out.wire24) mrca.m24 = static_cast<unsigned char *>(s.h_m);
             else mrca.m32 = static_cast<int32_t *>(s.h_m);
         }
         // The chunk's packed pairs come in through the copy engine into a device copy of the slot (the kernel reads them
         // there; its results still go straight to the pinned slot): the way in then runs at the engine's rate beside the
         // kernels of the other slots instead of at what 16 waves per CU keep in flight over the link -- link side alone
         // 5.87 -> 6.50e9 pairs/s (both outputs), whole calls: distances alone +8 % (6.1-6.4 -> 6.6-7.1e9), both outputs
-        // even (the CPU passes bind there).  SUCHTREE_AMD_H2D_ENGINE=0: the kernel reads the pinned slot itself.
-        static const bool h2d_engine = !(std::getenv("SUCHTREE_AMD_H2D_ENGINE") && std::getenv("SUCHTREE_AMD_H2D_ENGINE")[0] == '0');
+        // even (the CPU passes bind there).
         const void *in = s.h_in;
-        if (h2d_engine && in_bytes_per_pair) {
+        if (in_bytes_per_pair) {
             hipError_t e = r->dp->pipe.ensure_device_in();
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_in, s.h_in, (size_t)m * in_bytes_per_pair, hipMemcpyHostToDevice, s.stream);
             if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
@@ -261,19 +226,13 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
     const int rc = enqueue_src(r, make_src(s.d_in), m, DistSink{nullptr, out.dist ? static_cast<float *>(s.d_d) : nullptr},
                                MrcaSink{out.mrca ? static_cast<int32_t *>(s.d_m) : nullptr, nullptr}, r->d_fault_host, s.stream);
     if (rc != ST_OK) return rc;
-    if (out.dist && out.direct_d) {
-        hipLaunchKernelGGL(k_widen_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, kCopyKernelBlocks))),
-                           dim3(1024), 0, s.stream, static_cast<const float *>(s.d_d), out.dist + off, (long long)m);
-        e = hipGetLastError();
-    } else if (out.dist) {
-        e = enqueue_words_copy(s.d_d, s.h_d, m, s.stream);
-    }
-    if (e == hipSuccess && out.mrca && out.wire24 && !out.direct_m) {
+    if (out.dist) e = enqueue_words_copy(s.d_d, s.h_d, m, s.stream);
+    if (e == hipSuccess && out.mrca && out.wire24) {
         hipLaunchKernelGGL(k_pack24_copy, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((m + 1023) / 1024, kCopyKernelBlocks))),
                            dim3(1024), 0, s.stream, static_cast<const int *>(s.d_m), static_cast<unsigned char *>(s.h_m), (long long)m);
         e = hipGetLastError();
     } else if (e == hipSuccess && out.mrca) {
-        e = enqueue_words_copy(s.d_m, out.direct_m ? static_cast<void *>(out.mrca + off) : s.h_m, m, s.stream);
+        e = enqueue_words_copy(s.d_m, s.h_m, m, s.stream);
     }
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("device staging: ") + hipGetErrorString(e));
     return ST_OK;
@@ -282,23 +241,20 @@ static int launch_chunk(st_tree *r, PipeSlot &s, int64_t off, int64_t m, int in_
 // Push this device's chunks of a batch through the slots of the pipe (host_pipe.h).
 // pack(slot, off, m) fills slot.h_in for chunk [off, off+m); launch(slot, off, m) enqueues
 // the kernel on slot.stream, reading slot.h_in and writing slot.h_d / slot.h_m -- pinned
-// host memory, accessed by the kernel over PCIe (see host_pipe.h) -- or, where the caller's
-// own result array is pinned (HostOut::direct_*), that array itself.  Caller holds the
-// device pipe's mutex.
+// host memory, accessed by the kernel over PCIe (see host_pipe.h).  Caller holds the device pipe's mutex.
 template <typename Pack, typename Launch>
 static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, const HostOut &out, Fault &fault)
 {
     fault = kFaultInit;
-    // SUCHTREE_AMD_TRACE_PIPE=1: one line per call on stderr with the host thread's time by phase
-    static const bool trace = std::getenv("SUCHTREE_AMD_TRACE_PIPE") != nullptr;
-    // SUCHTREE_AMD_PIPE_SKIP_CPU=1 (measurement only, results are garbage): no pack and no unpack passes --
-    // what the GPU / link side of the pipeline takes when the host's memory system is otherwise idle
-    // SUCHTREE_AMD_PIPE_SKIP_GPU=1 (measurement only, results are garbage): the pack / pre-fault / unpack passes alone,
-    // nothing launched -- what the host side of the pipeline sustains when it never waits for a GPU: the most a
-    // multi-device handle (one pipeline per GPU, all fed by this host's memory system) can scale to
-    // (both read per call, so that a benchmark can switch them on for one call)
-    const bool skip_cpu = std::getenv("SUCHTREE_AMD_PIPE_SKIP_CPU") != nullptr;
-    const bool skip_gpu = std::getenv("SUCHTREE_AMD_PIPE_SKIP_GPU") != nullptr;
+    // Handle option "measure" (st_tree_set_option; MEASUREMENT ONLY -- a call made with a skip bit set returns
+    // ST_ERR_MEASURE_ONLY instead of ST_OK, because its result arrays hold garbage): 1 = trace, one line per call on
+    // stderr with the host thread's time by phase; 2 = no pack and no unpack passes (what the GPU / link side of the
+    // pipeline takes when the host's memory system is otherwise idle); 4 = the pack / pre-fault / unpack passes alone,
+    // nothing launched (what the host side sustains when it never waits for a GPU: the most a multi-device handle,
+    // one pipeline per GPU all fed by this host's memory system, can scale to).  Nothing in the environment reaches here.
+    const bool trace = (t->measure & 1) != 0;
+    const bool skip_cpu = (t->measure & 2) != 0;
+    const bool skip_gpu = (t->measure & 4) != 0;
     using Clock = std::chrono::steady_clock;
     double t_wait = 0, t_unpack = 0, t_pack = 0, t_launch = 0, t_prefault = 0;
     const Clock::time_point t_begin = Clock::now();
@@ -309,8 +265,8 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         since = now;
     };
     // results the kernels write directly need neither unpacking nor pre-faulting
-    double *const out_dist = out.direct_d ? nullptr : out.dist;
-    int32_t *const out_mrca = out.direct_m ? nullptr : out.mrca;
+    double *const out_dist = out.dist;
+    int32_t *const out_mrca = out.mrca;
     HostPipe &P = t->dp->pipe;
     {
         const hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
@@ -360,16 +316,8 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
         // Only with the page-touch form of populate_for_write (transparent huge pages): MADV_POPULATE_WRITE from
         // threads of its own beside the faulting unpack passes measured 3x SLOWER than doing nothing (5e7 pairs, fresh
         // arrays: 1.1-1.6e9 pairs/s; the touch form 4.5-4.9e9; populating between the passes, either form, 3.7-3.9e9;
-        // profiles/fresh_array_r04.log).  SUCHTREE_AMD_ASYNC_PREFAULT=0 / 1 overrides.  Multi-device handles: the
-        // replica that owns the first chunk populates for all.
-        static const int async_env = [] {
-            const char *env = std::getenv("SUCHTREE_AMD_ASYNC_PREFAULT");
-            return !env ? -1 : env[0] == '0' ? 0 : 1;
-        }();
-        const char *mode = std::getenv("SUCHTREE_AMD_POPULATE");
-        const bool touch_form = mode ? !std::strcmp(mode, "touch") : thp_available();
-        const bool async_on = async_env >= 0 ? async_env == 1 : touch_form;
-        async_populates = async_on && !skip_cpu && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8;
+        // profiles/fresh_array_r04.log).  Multi-device handles: the replica that owns the first chunk populates for all.
+        async_populates = thp_available() && !skip_cpu && (pd ? seq.n * 8 : 0) + (pm ? seq.n * 4 : 0) >= kAsyncMinBytes && hw >= 8;
         if (async_populates && seq.first == 0) async_prefault.start(pd, pm, seq.n, (int)std::min<unsigned>(16, hw / 4));
     }
     auto prefault = [&](int64_t off, int64_t m) {
@@ -470,6 +418,7 @@ static int run_pipe(st_tree *t, const ChunkSeq &seq, Pack pack, Launch launch, c
                      (long long)seq.n, (long long)seq.chunk, (long long)k,      // (pieces: the first and last chunk are cut)
                      std::chrono::duration<double, std::micro>(Clock::now() - t_begin).count(), t_pack, t_launch, t_prefault,
                      t_wait, t_unpack);
+    if (skip_cpu || skip_gpu) return fail(ST_ERR_MEASURE_ONLY, "handle option 'measure' is set: this call skipped part of the pipeline, its results are not valid");
     return ST_OK;
 }
 

@@ -196,13 +196,8 @@ struct HostPipe {
         cap = pairs;
         // copy threads: a quarter of the hardware threads, at most 16 (the three memory passes
         // of the host path saturate the host's memory system well before they run out of cores);
-        // SUCHTREE_AMD_COPY_THREADS overrides
         const unsigned hw = std::thread::hardware_concurrency();
         int n_threads = (int)std::min<unsigned>(16, std::max<unsigned>(1, hw / 4));
-        if (const char *env = std::getenv("SUCHTREE_AMD_COPY_THREADS")) {
-            const int v = std::atoi(env);
-            if (v >= 1 && v <= 256) n_threads = v;
-        }
         pool.start(n_threads);
         return hipSuccess;
     }

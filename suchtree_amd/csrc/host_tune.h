@@ -5,7 +5,7 @@
 // the tile-sorted canopy kernel, the predicated canopy kernel and the tile-sorted walk kernel.  Which one is fastest
 // depends on the shape of the tree in ways no single statistic captured (launch_policy.h has the numbers), and the
 // spread is 2-4x, so the handle times them once on a sample of 2^23 random leaf pairs drawn on the device -- ~15 ms on ml.tree next to the 0.07-2 s
-// the tables of such a tree take to build -- and sets its defaults (tile_sort, pairs_per_lane, prefer_walk_sorted)
+// the tables of such a tree take to build -- and sets its defaults (tile_sort, prefer_walk_sorted, ladder_scalar)
 // to the fastest -- if it beats the rule's own choice by more than 5 % (kTuneMargin), else the rule stands.  The decision
 // is recorded per (tree digest, device, library build) and read back by later handles and processes, so a handle's
 // kernel is stable across runs (info.tuned: 1 = timed now, 2 = read from the record); multi-device handles time on
@@ -26,15 +26,14 @@ static int big_batch_kernel_of(const st_tree *t)
     if (ladder_scalar_ready(t)) return ST_KERNEL_CANOPY_LADDER;      // (launch_canopy.hip: the first choice of large batches)
     if (prefers_walk_sorted(t, (int64_t)1 << 40, true)) return ST_KERNEL_WALK_SORTED;
     if (t->tile_sort && sorted_q(t) > 0) return ST_KERNEL_CANOPY_SORTED;
-    return t->pairs_per_lane == 0 ? ST_KERNEL_CANOPY_SCALAR : ST_KERNEL_CANOPY;
+    return ST_KERNEL_CANOPY;
 }
 
 static void rule_for_deep_tree(st_tree *t)
 {
-    t->pairs_per_lane = 0;
     t->tile_sort = 1;
     // 63-slot chains: the tile-sorted canopy kernel reads them through a pointer and never won a measurement
-    if (t->rec_cap > 31 || sorted_q(t) <= 0) { t->pairs_per_lane = 1; t->tile_sort = 0; }
+    if (t->rec_cap > 31 || sorted_q(t) <= 0) t->tile_sort = 0;
     t->prefer_walk_sorted = walk_sorted_by_rule(t) ? 1 : 0;
     t->ladder_scalar = t->rec_bytes > kMaxRecordBytes ? 1 : 0;      // (1 KB records: no other canopy kernel reads them well)
 }
@@ -71,21 +70,21 @@ static std::string tune_cache_path(const st_tree *t, const TreeTables &T, const 
     return dir + name;
 }
 
-static bool tune_cache_read(const std::string &path, int &tile_sort, int &ppl, int &walk, int &ladder, long long &ladder_min)
+static bool tune_cache_read(const std::string &path, int &tile_sort, int &walk, int &ladder, long long &ladder_min)
 {
     if (path.empty()) return false;
     FILE *f = std::fopen(path.c_str(), "r");
     if (!f) return false;
-    int a = -1, b = -1, c = -1, d = -1;
+    int a = -1, c = -1, d = -1;
     long long e = -1;
-    const int got = std::fscanf(f, "%d %d %d %d %lld", &a, &b, &c, &d, &e);
+    const int got = std::fscanf(f, "%d %d %d %lld", &a, &c, &d, &e);
     std::fclose(f);
-    if (got != 5 || (a != 0 && a != 1) || b < 0 || b > 2 || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0) return false;
-    tile_sort = a; ppl = b; walk = c; ladder = d; ladder_min = e;
+    if (got != 4 || (a != 0 && a != 1) || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0) return false;
+    tile_sort = a; walk = c; ladder = d; ladder_min = e;
     return true;
 }
 
-static void tune_cache_write(const std::string &path, int tile_sort, int ppl, int walk, int ladder, long long ladder_min)
+static void tune_cache_write(const std::string &path, int tile_sort, int walk, int ladder, long long ladder_min)
 {
     if (path.empty()) return;
     const size_t slash = path.rfind('/');
@@ -95,7 +94,7 @@ static void tune_cache_write(const std::string &path, int tile_sort, int ppl, in
     const std::string tmp = path + ".tmp." + std::to_string((long long)::getpid());
     FILE *f = std::fopen(tmp.c_str(), "w");
     if (!f) return;
-    std::fprintf(f, "%d %d %d %d %lld\n", tile_sort, ppl, walk, ladder, ladder_min);
+    std::fprintf(f, "%d %d %d %lld\n", tile_sort, walk, ladder, ladder_min);
     std::fclose(f);
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
@@ -107,7 +106,6 @@ constexpr float kTuneMargin = 0.95f;
 static void copy_tuned_settings(st_tree *to, const st_tree *from)
 {
     to->tile_sort = from->tile_sort;
-    to->pairs_per_lane = from->pairs_per_lane;
     to->prefer_walk_sorted = from->prefer_walk_sorted;
     to->ladder_scalar = from->ladder_scalar;
     to->ladder_min_pairs = from->ladder_min_pairs;
@@ -121,15 +119,15 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         if (env[0] == '0') return;
     const std::string cache = tune_cache_path(t, T, device_name);
     {
-        int a, b, c, d;
+        int a, c, d;
         long long e;
-        if (tune_cache_read(cache, a, b, c, d, e)) {
+        if (tune_cache_read(cache, a, c, d, e)) {
             // (a recorded choice the handle cannot serve -- other table budget, other options -- is ignored)
-            const int keep_sort = t->tile_sort, keep_ppl = t->pairs_per_lane, keep_walk = t->prefer_walk_sorted, keep_ladder = t->ladder_scalar;
-            t->tile_sort = a; t->pairs_per_lane = b; t->prefer_walk_sorted = c; t->ladder_scalar = 0;
+            const int keep_sort = t->tile_sort, keep_walk = t->prefer_walk_sorted, keep_ladder = t->ladder_scalar;
+            t->tile_sort = a; t->prefer_walk_sorted = c; t->ladder_scalar = 0;
             const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_tables_ready(t));
             if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->info.tuned = 2; return; }
-            t->tile_sort = keep_sort; t->pairs_per_lane = keep_ppl; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = keep_ladder;
+            t->tile_sort = keep_sort; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = keep_ladder;
         }
     }
     // sample: uniform random leaf pairs (the reference's typical query, and the bench's)
@@ -168,9 +166,8 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     }
     // milliseconds of the fastest of three launches of m pairs after one warm-up, or a negative number
-    auto time_settings = [&](int tile_sort, int ppl, int walk, int ladder, int64_t m) -> float {
+    auto time_settings = [&](int tile_sort, int walk, int ladder, int64_t m) -> float {
         t->tile_sort = tile_sort;
-        t->pairs_per_lane = ppl;
         t->prefer_walk_sorted = walk;
         t->ladder_scalar = ladder;
         t->ladder_min_pairs = 0;
@@ -186,22 +183,22 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         return best;
     };
     if (ok) {
-        const int rule_sort = t->tile_sort, rule_ppl = t->pairs_per_lane, rule_walk = t->prefer_walk_sorted, rule_ladder = t->ladder_scalar;
+        const int rule_sort = t->tile_sort, rule_walk = t->prefer_walk_sorted, rule_ladder = t->ladder_scalar;
         // Two batch sizes: the whole sample (what bulk callers send) and a quarter of it.  The scalar ladder kernel sorts
         // nothing, so its waves finish unevenly and few tiles per wave leave a long tail: it can win at 2^23 pairs and
         // lose at 2^21 (launch_policy.h) -- then it only takes the batches beyond the size in between.
-        struct Cand { int sort, ppl, walk, ladder; float ms, ms_small; };
+        struct Cand { int sort, walk, ladder; float ms, ms_small; };
         const int64_t n_small = n / 4;
         std::vector<Cand> cands;
         t->ladder_scalar = 0;
-        if (sorted_q(t) > 0) cands.push_back({1, 0, 0, 0, -1.0f, -1.0f});
-        cands.push_back({0, 1, 0, 0, -1.0f, -1.0f});
-        if (ladder_tables_ready(t)) cands.push_back({0, 1, 0, 1, -1.0f, -1.0f});
+        if (sorted_q(t) > 0) cands.push_back({1, 0, 0, -1.0f, -1.0f});
+        cands.push_back({0, 0, 0, -1.0f, -1.0f});
+        if (ladder_tables_ready(t)) cands.push_back({0, 0, 1, -1.0f, -1.0f});
         t->prefer_walk_sorted = 1;
-        if (prefers_walk_sorted(t, n_small, true)) cands.push_back({rule_sort, rule_ppl, 1, 0, -1.0f, -1.0f});
+        if (prefers_walk_sorted(t, n_small, true)) cands.push_back({rule_sort, 1, 0, -1.0f, -1.0f});
         for (Cand &c : cands) {
-            c.ms = time_settings(c.sort, c.ppl, c.walk, c.ladder, n);
-            c.ms_small = time_settings(c.sort, c.ppl, c.walk, c.ladder, n_small);
+            c.ms = time_settings(c.sort, c.walk, c.ladder, n);
+            c.ms_small = time_settings(c.sort, c.walk, c.ladder, n_small);
         }
         const Cand *best = nullptr, *rule = nullptr, *base = nullptr, *base_small = nullptr;
         for (const Cand &c : cands) {
@@ -210,7 +207,7 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
             if (!c.ladder && (!base || c.ms < base->ms)) base = &c;                            // fastest without the ladder kernel, whole sample ...
             if (!c.ladder && (!base_small || c.ms_small < base_small->ms_small)) base_small = &c;   // ... and at the smaller size
             // the rule's choice among the candidates (with the walk kernel chosen, the canopy settings behind it do not matter)
-            if (c.walk == rule_walk && (c.walk || (c.ladder == rule_ladder && c.sort == rule_sort && c.ppl == rule_ppl))) rule = &c;
+            if (c.walk == rule_walk && (c.walk || (c.ladder == rule_ladder && c.sort == rule_sort))) rule = &c;
         }
         if (best && rule && best != rule && best->ms > kTuneMargin * rule->ms) best = rule;      // too close to call: the rule stands
         if (best) {
@@ -222,7 +219,6 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
                 for (const Cand &c : cands)
                     if (!c.walk && !c.ladder && c.ms_small > 0.0f && (!canopy || c.ms_small < canopy->ms_small)) canopy = &c;
             t->tile_sort = canopy ? canopy->sort : rule_sort;
-            t->pairs_per_lane = canopy ? canopy->ppl : rule_ppl;
             t->prefer_walk_sorted = other && other->walk ? 1 : 0;
             t->ladder_scalar = best->ladder;
             t->ladder_min_pairs = 0;
@@ -232,20 +228,18 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
                 // ahead at a quarter of the sample too: one more size, a sixteenth (ml.tree: the tile-sorted kernel is
                 // 10-20 % ahead from 2^17 to 2^19 pairs, even at 2^20, behind from 2^21 -- profiles/ladder_midsize_r04.log)
                 const Cand ladder = *best, other_small = *base_small;      // (time_settings overwrites the handle's settings)
-                const float ms_ladder = time_settings(ladder.sort, ladder.ppl, ladder.walk, ladder.ladder, n / 16);
-                const float ms_other = time_settings(other_small.sort, other_small.ppl, other_small.walk, other_small.ladder, n / 16);
+                const float ms_ladder = time_settings(ladder.sort, ladder.walk, ladder.ladder, n / 16);
+                const float ms_other = time_settings(other_small.sort, other_small.walk, other_small.ladder, n / 16);
                 t->tile_sort = canopy ? canopy->sort : rule_sort;
-                t->pairs_per_lane = canopy ? canopy->ppl : rule_ppl;
-                t->prefer_walk_sorted = other && other->walk ? 1 : 0;
+                    t->prefer_walk_sorted = other && other->walk ? 1 : 0;
                 t->ladder_scalar = best->ladder;
                 t->ladder_min_pairs = (ms_ladder > 0.0f && ms_other > 0.0f && ms_ladder > kTuneMargin * ms_other) ? n / 8 : 0;
             }
             if (t->rec_bytes > kMaxRecordBytes) t->ladder_scalar = 1;      // (1 KB records: the family's other kernels read them through a pointer, far slower)
             t->info.tuned = 1;
-            tune_cache_write(cache, t->tile_sort, t->pairs_per_lane, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs);
+            tune_cache_write(cache, t->tile_sort, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs);
         } else {
             t->tile_sort = rule_sort;
-            t->pairs_per_lane = rule_ppl;
             t->prefer_walk_sorted = rule_walk;
             t->ladder_scalar = rule_ladder;
             t->ladder_min_pairs = 0;

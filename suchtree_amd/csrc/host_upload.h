@@ -40,12 +40,10 @@ static int64_t walk_table_budget()
 }
 
 // Lineage-length bytes the crown's (shared) blocks may occupy: small enough to live in an XCD's
-// 4 MiB L2 next to the streams.  SUCHTREE_AMD_CROWN_KB: tuning experiments.
+// 4 MiB L2 next to the streams.
 static int64_t crown_hot_budget()
 {
-    int64_t kb = 1024;
-    if (const char *env = std::getenv("SUCHTREE_AMD_CROWN_KB")) kb = std::atoll(env);
-    return std::max<int64_t>(1, kb) << 10;
+    return (int64_t)1024 << 10;
 }
 
 // Largest crown (nodes) the tile-sorted walk kernel keeps in LDS as a ladder, 16 bytes per node beside
@@ -54,12 +52,9 @@ static int64_t crown_hot_budget()
 // depth-338 tree: 7.37e9 pairs/s with 8192 or 6144, 7.04e9 with 4096, 6.67e9 with 2048).  Deep-canopy trees
 // (the walk family is their second family): 5120 nodes, so that 4096-pair tiles fit (ml.tree 1.71e10, nj.tree
 // 1.74e10; with 8192: 1.53e10 / 1.40e10).  profiles/walk_ladder_sweep_r03.log.
-// SUCHTREE_AMD_CROWN_LADDER_NODES: tuning experiments (0 = never).
 static int crown_ladder_nodes(bool has_canopy)
 {
-    int nodes = has_canopy ? 5120 : 8192;
-    if (const char *env = std::getenv("SUCHTREE_AMD_CROWN_LADDER_NODES")) nodes = std::atoi(env);
-    return std::max(0, std::min(nodes, 8704));
+    return has_canopy ? 5120 : 8192;
 }
 
 // The walk family's tables with offsets by node id: the whole-tree sparse table beyond prepare_basic's 64 MB -- the
@@ -153,8 +148,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
 {
     std::string err;
     if (!prepare_basic(parent, distance, n_nodes, B.T, err)) return fail(ST_ERR_TREE, err);
-    int max_canopy = 0;
-    if (const char *env = std::getenv("SUCHTREE_AMD_CANOPY_NODES")) max_canopy = std::atoi(env);   // tuning experiments
+    const int max_canopy = 0;      // (prepare_canopy: the LDS limit)
     if (B.budget > 0) {
         // (tables beyond the floor: the whole-tree sparse table prepare_basic may have built is the first thing to go
         // when the records would not fit beside it)
@@ -163,9 +157,8 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
     // Records: up to 512 bytes (63-slot chains) with every kernel of the family; trees that need more -- up to 127
     // levels below the canopy: 1e6 leaves at depth 340 -- get 1 KB records without id chains, read through a pointer by
     // the scalar ladder kernel alone (k_canopy_ladder<0>): 9.4e9 pairs/s on that tree where the walk family's tables
-    // give 7.5e9 (profiles/kernel_choice_r04.log).  SUCHTREE_AMD_MAX_RECORD_BYTES=512 keeps such trees with the walk family.
-    int max_record = kLongRecordBytes;
-    if (const char *env = std::getenv("SUCHTREE_AMD_MAX_RECORD_BYTES")) max_record = std::atoi(env);
+    // give 7.5e9 (profiles/kernel_choice_r04.log).
+    const int max_record = kLongRecordBytes;
     if (strategy != ST_STRATEGY_WALK) {
         B.T.max_record_bytes = std::min<int>(max_record, kMaxRecordBytes);
         B.canopy_ok = prepare_canopy(parent, distance, B.T, max_canopy);
@@ -183,8 +176,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
             for (const CanopyEntry &e : B.T.canopy) cdepth = std::max<int>(cdepth, (int)(e.link >> 16));
             if (cdepth > kDeepCanopyDepth) {
                 B.deep = true;
-                int deep_nodes = kDeepCanopyNodes;
-                if (const char *env = std::getenv("SUCHTREE_AMD_DEEP_NODES")) deep_nodes = std::atoi(env);   // tuning experiments
+                const int deep_nodes = kDeepCanopyNodes;      // (other sizes: profiles/deep_nodes_r05.log)
                 if (B.T.canopy_nodes > deep_nodes) {
                     TreeTables T2 = B.T;
                     if (prepare_canopy(parent, distance, T2, deep_nodes)) B.T = std::move(T2);
@@ -388,6 +380,12 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
             t->d_work = nullptr;
         } else {
             bytes += (int64_t)kWorkSlots * 64 * 8;
+            for (unsigned k = 0; k < kWorkSlots; k++) {      // (an event that cannot be created leaves the static deal: launch_canopy.hip)
+                if (hipEventCreateWithFlags(&t->work_done[k], hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    t->work_done[k] = nullptr;
+                }
+            }
         }
     }
     if (rc != ST_OK) return rc;      // (owner destroys t and keeps the message)
@@ -405,8 +403,7 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
     t->info.dropped_tables = B.dropped;
     t->info.table_budget_bytes = B.budget;
     t->info.lineage_entries = t->d_lineage ? (int64_t)T.lineage_sum.size() : 0;
-    if (t->rec_bytes > kMaxRecordBytes) {      // 1 KB records: the scalar ladder kernel (the scalar kernel over the plain image otherwise)
-        t->pairs_per_lane = 1;
+    if (t->rec_bytes > kMaxRecordBytes) {      // 1 KB records: the scalar ladder kernel
         t->tile_sort = 0;
         t->ladder_scalar = 1;
     }

@@ -1,4 +1,4 @@
-// kernels_canopy.h -- canopy family: CanopyParams, the per-pair device helpers, k_canopy, k_canopy_ilp,
+// kernels_canopy.h -- canopy family: CanopyParams, the per-pair device helpers, k_canopy_ladder, k_canopy_ilp,
 // k_mrca_ranks (launch_canopy.hip); k_canopy_sorted lives in kernels_canopy_sorted.h
 // (launch_canopy_sorted.hip).  Include after device_common.h and pair_math.h.
 #pragma once
@@ -166,43 +166,6 @@ __device__ __forceinline__ void stage_ladder(const CanopyParams &P, unsigned cha
     __syncthreads();
 }
 
-// Scalar, branchy kernel (one pair per lane, input order): records longer than 128 bytes and
-// the pairs_per_lane = 0 setting.  (Over the ladder image it measured no faster than the
-// predicated kernel on 2^17-leaf trees -- those are bound by record fetches too -- so the
-// ladder is only used by the tile-sorted kernel.)
-template <int CAP, typename Src>
-__global__ __launch_bounds__(kCanopyBlock) void k_canopy(CanopyParams P, Src src, long long n,
-                                                         DistSink out_d,
-                                                         MrcaSink out_m, Fault *fault)
-{
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    stage_canopy(P, lds_raw);
-
-    const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    // (the trip count is uniform over the workgroup and results leave from one converged place: store_mrca_wave)
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < n; base += stride) {
-        const long long i = base + threadIdx.x;
-        const bool live = i < n;
-        PairResult r;
-        r.dist = __builtin_nanf("");
-        r.mrca = -1;
-        if (live) {
-            long long a, b;
-            src.load(i, a, b);
-            if ((unsigned long long)a >= (unsigned long long)P.n_nodes ||
-                (unsigned long long)b >= (unsigned long long)P.n_nodes) {
-                record_fault(fault, a, b, P.n_nodes);
-            } else {
-                const long long sa = record_slot(a, P.parity != 0, P.n_leaves);
-                const long long sb = record_slot(b, P.parity != 0, P.n_leaves);
-                r = canopy_pair_scalar<CAP, false>(P, lds_raw, sa, sb, rec_bytes);
-            }
-        }
-        store_result_wave(out_d, out_m, i, r.dist, r.mrca, live);
-    }
-}
-
 // b's record (L.rb set) for long chains: the first 128-byte line at once, of a 63-slot chain's second line only the
 // 16-byte chunks that hold slots in use, once the length is there (k_canopy_ilp reads its records the same way).
 template <int CAP>
@@ -331,11 +294,10 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
     }
 }
 
-// Same computation with PPL pairs in flight per lane.  Every lane carries PPL independent
-// pairs: their pair and record loads are issued together and their canopy climbs advance in
-// the same loop iteration as independent ds_read_b64 (low word = dist bits, high word =
-// parent index).  All updates are predicated selects (a finished climb keeps re-reading its
-// meeting node), so the PPL chains never serialise behind a branch.
+// The predicated kernel (shallow canopies; the headline): one pair per lane, ds_read_b64 per canopy entry (low word = dist
+// bits, high word = parent index).  All updates are predicated selects (a finished climb keeps re-reading its meeting
+// node), so nothing serialises behind a branch.  (PPL: pairs per lane, 1 -- two measured equal and were dropped in round 5,
+// as was the branchy scalar kernel k_canopy, last on every tree of profiles/kernel_choice_r0{4,5}.log.)
 // A4: the four-byte form of the a side (tree_prep.h): pbot from rec_a4 (4 bytes, a table half the size
 // of rec_a), the portal from the block table of leaf slots, staged into LDS behind the canopy image;
 // leaves of straddling blocks and internal nodes take the 8-byte entry (a wave-uniform rare branch).

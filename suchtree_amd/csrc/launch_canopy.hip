@@ -1,4 +1,4 @@
-// launch_canopy.hip -- translation unit of the canopy family's plain kernels (k_canopy, k_canopy_ilp, k_mrca_ranks)
+// launch_canopy.hip -- translation unit of the canopy family's plain kernels (k_canopy_ilp, k_canopy_ladder, k_mrca_ranks)
 // and of launch_canopy<Src>, the family's one entry point (the tile-sorted kernel sits behind it in
 // launch_canopy_sorted.hip).  Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <hip/hip_runtime.h>
@@ -61,15 +61,23 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
     int64_t blocks = std::min<int64_t>((n + kCanopyBlock - 1) / kCanopyBlock, (int64_t)t->n_cu * wg_per_cu);
     blocks = std::max<int64_t>(blocks, 1);
     unsigned long long *work = nullptr;
-    if (t->d_work && (t->ladder_dynamic == 2 ||      // (2: whatever the records and the batch -- measurements)
-                      (t->ladder_dynamic == 1 && t->rec_bytes >= 512 && n >= (t->rec_bytes > 512 ? kLadderDynamicMin / 2 : kLadderDynamicMin)))) {
+    hipEvent_t done = nullptr;
+    if (t->d_work && t->ladder_dynamic && t->rec_bytes >= 512 && n >= (t->rec_bytes > 512 ? kLadderDynamicMin / 2 : kLadderDynamicMin)) {
         const unsigned slot = t->work_next.fetch_add(1, std::memory_order_relaxed) % kWorkSlots;
-        work = t->d_work + (size_t)slot * 64;      // eight counters, 64 bytes apart
-        const hipError_t e = hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), stream);
-        if (e != hipSuccess) return e;
+        done = t->work_done[slot];
+        if (done) {      // (no event: the static deal)
+            work = t->d_work + (size_t)slot * 64;      // eight counters, 64 bytes apart
+            // the launch that drew from this slot 64 launches ago may still be queued on ANOTHER stream: zeroing its counters
+            // under it would deal chunks twice or not at all -- this stream waits for it first (an event never recorded is complete)
+            hipError_t e = hipStreamWaitEvent(stream, done, 0);
+            if (e == hipSuccess) e = hipMemsetAsync(work, 0, 64 * sizeof(unsigned long long), stream);
+            if (e != hipSuccess) return e;
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, work);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && work) e = hipEventRecord(done, stream);
+    return e;
 }
 
 template <int CAP, typename Src>
@@ -86,20 +94,13 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
     if (t->tile_sort && sorted_q(t) > 0)
         return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
     if constexpr (CAP == 0) {
-        return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+        // 1 KB records exist for the scalar ladder kernel alone (host_upload.h builds them with a canopy that fits its image)
+        return ladder_tables_ready(t) ? launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream) : hipErrorInvalidValue;
     } else if constexpr (CAP == 31 || CAP == 63) {
         // 256- and 512-byte records (large trees of random shape: 2^22 leaves, depth 57, understories of up to 31
-        // nodes; 1e6 leaves with some skew: up to 63): the predicated kernel with the chain in 31 / 63 registers,
-        // one pair per lane; pairs_per_lane = 0: the scalar kernel that reads the chain through a pointer
-        if (t->pairs_per_lane == 0) return launch_canopy_k(k_canopy<0, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
+        // nodes; 1e6 leaves with some skew: up to 63): the predicated kernel with the chain in 31 / 63 registers
         return launch_canopy_k(k_canopy_ilp<CAP, 1, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
     } else {
-        if (t->pairs_per_lane == 0) return launch_canopy_k(k_canopy<CAP, Src>, 1, t, P, src, n, out_d, out_m, fault, stream);
-        // two pairs per lane: a measured-equal variant kept selectable for explicit pair arrays only
-        if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
-            if (t->pairs_per_lane == 2)
-                return launch_canopy_k(k_canopy_ilp<CAP, 2, Src>, 2, t, P, src, n, out_d, out_m, fault, stream);
-        }
         // explicit pair arrays on trees with the four-byte a side: 4-byte gathers from a table half the size
         if constexpr (std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value) {
             if (P.rec_a4 && P.leaf_blocks)

@@ -113,7 +113,7 @@ static inline bool mrca_ranks_ready(const st_tree *t)
 
 // Which kernel large distance batches of a deep tree get is decided when the tree is created (host_tune.h): the
 // candidates -- tile-sorted canopy kernel, predicated canopy kernel, tile-sorted walk kernel -- are timed on a
-// sample of random leaf pairs and the handle's defaults (tile_sort, pairs_per_lane, prefer_walk_sorted) follow the
+// sample of random leaf pairs and the handle's defaults (tile_sort, prefer_walk_sorted, ladder_scalar) follow the
 // fastest; nothing else separates them reliably (ml.tree: 2.2e10 / 5.7e9 / 1.7e10 pairs/s in that order, a 1e6-leaf
 // tree of depth 252: 5.2e9 / 1.1e10 / 6.8e9, a 1e5-leaf tree of depth 423: 3.8e9 / 5.7e9 / 1.1e10;
 // profiles/kernel_choice_r03.log).  Batches of 524288 pairs and more (below, the canopy kernels' finer tiles are the
@@ -139,12 +139,7 @@ static inline bool walk_sorted_by_rule(const st_tree *t)
 
 // In lineage-sum mode the tile-sorted canopy kernel reads every pair once (key phase; shared-portal pairs, rare,
 // a second time) and all its stores are coalesced: it may work on the host path's pinned slots directly.
-// SUCHTREE_AMD_SORTED_ZERO_COPY=0 puts the device staging back (measurement).
-static inline bool sorted_zero_copy(const st_tree *t)
-{
-    static const bool on = !(std::getenv("SUCHTREE_AMD_SORTED_ZERO_COPY") && std::getenv("SUCHTREE_AMD_SORTED_ZERO_COPY")[0] == '0');
-    return on && sorted_shape(t).sums;
-}
+static inline bool sorted_zero_copy(const st_tree *t) { return sorted_shape(t).sums; }
 
 static inline bool wants_device_stage(const st_tree *t, int64_t m)
 {

@@ -20,7 +20,7 @@ using st::LadderEntry;
 using st::Node8;
 using st::Stride3;
 
-constexpr unsigned kWorkSlots = 64;      // work-counter slots of a handle (k_canopy_ladder): launches in flight at once never come near
+constexpr unsigned kWorkSlots = 64;      // work-counter slots of a handle (k_canopy_ladder); a slot's reuse waits for the launch that drew from it last (work_done)
 
 struct st_tree {
     int device = 0;
@@ -60,12 +60,12 @@ struct st_tree {
     // canopy geometry
     int32_t canopy_nodes = 0, rec_bytes = 0, rec_cap = 0, parity = 0;
     int64_t n_nodes = 0, n_leaves = 0;
-    int pairs_per_lane = 1;   // tuning: 0 = scalar (branchy) kernel, 1/2 = predicated ILP kernel with that many pairs per lane
     int tile_sort = 0;        // tuning: 1 = tile-sorted kernel over the ladder form of the canopy (default for deep canopies)
     int ladder_scalar = 0;    // tuning: 1 = distance batches of >= ladder_min_pairs pairs on records of 128 bytes and more go to k_canopy_ladder: the scalar kernel over the ladder image, meeting nodes from the sparse table (set when the tree is created: timed)
     int ladder_dynamic = 1;   // tuning: 0 = the scalar ladder kernel deals its pairs statically whatever the batch size
     unsigned long long *d_work = nullptr;          // kWorkSlots x 64 counters (eight used per launch, 64 bytes apart)
     mutable std::atomic<unsigned> work_next{0};
+    hipEvent_t work_done[kWorkSlots] = {};         // recorded behind the launch that used slot k: the next user's memset waits for it, whatever its stream
     int64_t ladder_min_pairs = 0;   // smallest batch of that kernel; 0 = kLadderMinPairs (set when the tree is created: timed at two batch sizes)
     int prefer_walk_sorted = 0;   // large distance batches of a canopy-strategy tree go to k_walk_sorted (set when the tree is created: timed, or by rule)
     int wire48 = 1;           // tuning: 0 = host-path ids always cross the link as int32 (8 bytes per pair), also on trees of fewer than 2^24 nodes
@@ -84,6 +84,7 @@ struct st_tree {
     uint32_t *d_rmq = nullptr;
     int canopy_depth = 0;     // deepest canopy node (edges)
     int small_batch_path = 1; // tuning: batches <= kMailboxPairs go through the pinned mailbox
+    int measure = 0;          // measurement switches of the host path (host_path.h::run_pipe): 1 trace, 2 skip the CPU passes, 4 skip the GPU side; calls with 2 / 4 return ST_ERR_MEASURE_ONLY
     // staging of the host entry points: the device's shared pipe
     DevicePipe *dp = nullptr;
     void *q_tmp = nullptr;        // MRCA ids of the quartet path (6 int32 per quartet)

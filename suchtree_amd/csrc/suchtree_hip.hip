@@ -10,14 +10,13 @@
 //           folded into one fixed-stride understory record per node (split into an
 //           8-byte a-side table and a b-side table), so a pair costs two record reads
 //           plus an LDS climb instead of ~h dependent global gathers.
-//           k_canopy_ilp     1-2 pairs per lane, predicated (shallow canopies: the default)
+//           k_canopy_ilp     one pair per lane, predicated (shallow canopies: the default)
 //           k_canopy_ladder  deep canopies, large batches, long records: records read once, chain in
 //                            registers, meeting node from a sparse table, both sides climbed on the
 //                            ladder form of the canopy (three edges per 16-byte LDS entry)
 //           k_canopy_sorted  deep canopies: pairs sorted by climb length within a workgroup tile; with
 //                            in-order ids the meeting node comes from a sparse table and a's side from
 //                            per-node lineage sums
-//           k_canopy         scalar, branchy (pairs_per_lane = 0; records through a pointer)
 //
 // Every kernel is templated on a pair source (SrcContig / SrcContig32 / SrcStrided /
 // SrcTriangle / SrcGrid / SrcQuartet): an explicit (n,2) array, or pairs derived from their
@@ -354,6 +353,8 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_crown_ladder);
         (void)hipFree(t->d_fault);
         (void)hipFree(t->d_work);
+        for (hipEvent_t ev : t->work_done)
+            if (ev) (void)hipEventDestroy(ev);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
         (void)hipFree(t->d_fault_mb);
@@ -400,12 +401,6 @@ try {
 
 static int set_option_one(st_tree *t, const char *name, int64_t value)
 {
-    if (std::strcmp(name, "pairs_per_lane") == 0) {
-        if (value != 0 && value != 1 && value != 2)
-            return fail(ST_ERR_ARG, "pairs_per_lane must be 0, 1 or 2");
-        t->pairs_per_lane = (int)value;
-        return ST_OK;
-    }
     if (std::strcmp(name, "tile_sort") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "tile_sort must be 0 or 1");
         t->tile_sort = (int)value;
@@ -424,8 +419,14 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         return ST_OK;
     }
     if (std::strcmp(name, "ladder_dynamic") == 0) {
-        if (value != 0 && value != 1 && value != 2) return fail(ST_ERR_ARG, "ladder_dynamic must be 0, 1 or 2");
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_dynamic must be 0 or 1");
         t->ladder_dynamic = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "measure") == 0) {      // (host_path.h::run_pipe; peers of a multi-device handle follow)
+        if (value < 0 || value > 7) return fail(ST_ERR_ARG, "measure must be a combination of 1 (trace), 2 (skip CPU passes), 4 (skip GPU side)");
+        t->measure = (int)value;
+        for (st_tree *p : t->peers) p->measure = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "ladder_min_pairs") == 0) {
@@ -592,11 +593,11 @@ static int distances_host_impl(st_tree *t, const Id *pairs, int64_t n, int64_t s
         ST_DEVICE(t->device);
         return small_batch(t, pairs, n, stride0, stride1, out_dist, out_mrca, bad_id);
     }
-    HostOut out = make_host_out(out_dist, out_mrca, n);
+    HostOut out = make_host_out(out_dist, out_mrca);
     out.wire24 = wire24_of(t, out);
     // fresh result arrays: ask for huge pages before the first touch (a no-op on resident memory)
-    if (out_dist && !out.direct_d && !looks_resident(out_dist, n * 8)) advise_huge(out_dist, n * 8);
-    if (out_mrca && !out.direct_m && !looks_resident(out_mrca, n * 4)) advise_huge(out_mrca, n * 4);
+    if (out_dist && !looks_resident(out_dist, n * 8)) advise_huge(out_dist, n * 8);
+    if (out_mrca && !looks_resident(out_mrca, n * 4)) advise_huge(out_mrca, n * 4);
 
     // Ids cross PCIe as int32 (half the H2D bytes).  Values that do not fit are clamped to
     // INT32_MAX / INT32_MIN -- still out of range for the kernel -- and their exact extremes
@@ -721,10 +722,10 @@ try {
     int rc = triangle_args(t, ids, m, k_begin, k_count, out_dist, out_mrca);
     if (rc != ST_OK) return rc;
     if (k_count == 0) return ST_OK;
-    HostOut out = make_host_out(out_dist, out_mrca, k_count);
+    HostOut out = make_host_out(out_dist, out_mrca);
     out.wire24 = wire24_of(t, out);
-    if (out_dist && !out.direct_d && !looks_resident(out_dist, k_count * 8)) advise_huge(out_dist, k_count * 8);
-    if (out_mrca && !out.direct_m && !looks_resident(out_mrca, k_count * 4)) advise_huge(out_mrca, k_count * 4);
+    if (out_dist && !looks_resident(out_dist, k_count * 8)) advise_huge(out_dist, k_count * 8);
+    if (out_mrca && !looks_resident(out_mrca, k_count * 4)) advise_huge(out_mrca, k_count * 4);
     // the id list goes up once per device (packed); results stream back through the pipe
     std::vector<int64_t> packed;
     const int64_t *src_ids = ids;
@@ -774,10 +775,10 @@ try {
     if (rc != ST_OK) return rc;
     if (symmetric && (n_rows != n_cols)) return fail(ST_ERR_ARG, "symmetric grid needs n_rows == n_cols");
     if (e_count == 0) return ST_OK;
-    HostOut out = make_host_out(out_dist, out_mrca, e_count);
+    HostOut out = make_host_out(out_dist, out_mrca);
     out.wire24 = wire24_of(t, out);
-    if (out_dist && !out.direct_d && !looks_resident(out_dist, e_count * 8)) advise_huge(out_dist, e_count * 8);
-    if (out_mrca && !out.direct_m && !looks_resident(out_mrca, e_count * 4)) advise_huge(out_mrca, e_count * 4);
+    if (out_dist && !looks_resident(out_dist, e_count * 8)) advise_huge(out_dist, e_count * 8);
+    if (out_mrca && !looks_resident(out_mrca, e_count * 4)) advise_huge(out_mrca, e_count * 4);
     auto work = [&](st_tree *r, const ChunkSeq &seq, Fault &fault) -> int {
         HostPipe &P = r->dp->pipe;
         hipError_t e = P.ensure(std::max<int64_t>(seq.chunk, 1024));
@@ -1019,21 +1020,6 @@ try {
         W->cap = 0;
     }
     if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("graph matrices: ") + hipGetErrorString(e));
-    return ST_OK;
-} ST_CATCH_ALL
-
-int st_host_alloc(int64_t bytes, void **out)
-try {
-    if (!out || bytes < 0) return fail(ST_ERR_ARG, "bad arguments");
-    *out = nullptr;
-    // portable: addressable by every GPU of the process (multi-device handles write into it too)
-    ST_HIP(hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocPortable));
-    return ST_OK;
-} ST_CATCH_ALL
-
-int st_host_free(void *ptr)
-try {
-    if (ptr) ST_HIP(hipHostFree(ptr));
     return ST_OK;
 } ST_CATCH_ALL
 

@@ -232,6 +232,81 @@ def run_sharded(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d=N
     return pending
 
 
+def run_allgather(plan: ShardPlan, compute: Callable, result_d, result_m, wire_d, wire_m, group=None,
+                  unpack: Optional[Callable] = None):
+    """The same pass with the result assembled on EVERY rank (``result_d`` float64[n], ``result_m`` int32[n],
+    ``wire_d`` float32[n] and ``wire_m`` -- uint8 of ``packed_bytes(n)`` + slack for the packed format, or None --
+    on every rank: ``sharded_buffers(plan, all_ranks=True)``).  Every rank computes piece c of its own slice in the
+    wire format at the piece's global offset, sends it to every other rank and receives theirs (grouped
+    point-to-point: every pair of GPUs its own xGMI link, both directions), while piece c + 1 is computed; then
+    widens what it holds.  Each link carries 1/world of the result in each direction -- the per-link load of the
+    gather to one root, on all links at once.  The plan must be an even split (``root_share`` None)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = plan.world, plan.rank
+    if plan.root_pairs is not None:
+        raise ValueError("run_allgather needs an even plan (root_share None)")
+    lo, hi = plan.bounds(rank)
+    if world == 1:
+        if hi > lo:
+            compute(lo, hi, result_d[lo:hi], result_m[lo:hi])
+        return []
+    packed = wire_m is not None and wire_m.dtype == torch.uint8
+    if packed and plan.align % 4 != 0:
+        raise ValueError("the packed wire format needs a plan with align = 4")
+    if unpack is None:
+        unpack = unpack_mrca24
+
+    def ids_view(g, plo, phi, whole_dwords=False):
+        """Where the ids of [plo, phi) of rank g's slice live: int32 straight in result_m, or -- packed -- 3 bytes per pair
+        in g's region of wire_m, which starts on a dword of its own (the kernels store whole dwords; pieces start at
+        multiples of four pairs from their slice's start: plan.align)."""
+        if not packed:
+            return result_m[plo:phi]
+        g_lo = plan.bounds(g)[0]
+        at = packed_bytes(g_lo) + 8 * g + 3 * (plo - g_lo)
+        return wire_m[at:at + (packed_bytes(phi - plo) if whole_dwords else 3 * (phi - plo))]
+
+    pending = []
+    for c in range(plan.chunks):
+        plo, phi = plan.piece(rank, c)
+        ops = []
+        if phi > plo:
+            compute(plo, phi, wire_d[plo:phi], ids_view(rank, plo, phi, True))
+        for g in range(world):
+            if g == rank:
+                continue
+            glo, ghi = plan.piece(g, c)
+            if ghi > glo:
+                ops.append(dist.P2POp(dist.irecv, wire_d[glo:ghi], g, group))
+                ops.append(dist.P2POp(dist.irecv, ids_view(g, glo, ghi), g, group))
+            if phi > plo:
+                ops.append(dist.P2POp(dist.isend, wire_d[plo:phi], g, group))
+                ops.append(dist.P2POp(dist.isend, ids_view(rank, plo, phi), g, group))
+        pending.append(dist.batch_isend_irecv(ops) if ops else [])
+    for c in range(plan.chunks):
+        for w in pending[c]:
+            w.wait()
+        for g in range(world):
+            glo, ghi = plan.piece(g, c)
+            if ghi > glo:
+                result_d[glo:ghi].copy_(wire_d[glo:ghi])     # float32 -> float64, exact
+                if packed:
+                    unpack(ids_view(g, glo, ghi), result_m[glo:ghi])
+    return pending
+
+
+def run_local(plan: ShardPlan, compute: Callable, own_d, own_m):
+    """No gather: every rank computes its slice into buffers of its own (``own_d`` float64, ``own_m`` int32, both of
+    the slice's length) in ``plan.chunks`` launches; the result stays sharded over the GPUs that computed it."""
+    lo, _ = plan.bounds(plan.rank)
+    for plo, phi in plan.pieces(plan.rank):
+        if phi > plo:
+            compute(plo, phi, own_d[plo - lo:phi - lo], own_m[plo - lo:phi - lo])
+    return []
+
+
 def measure_root_share(world: int, rank: int, kernel_pairs_per_s: float, device=None, group=None,
                        nbytes: int = 64 << 20, root: int = 0, wire_bytes_per_pair: float = 8.0):
     """The rate at which ``root`` receives from ALL peers at once (the gather's pattern: every
@@ -271,22 +346,23 @@ def measure_root_share(world: int, rank: int, kernel_pairs_per_s: float, device=
     return float(t[0].item()), float(t[1].item()), float(t[2].item())
 
 
-def sharded_buffers(plan: ShardPlan, device=None, packed_ids: bool = False):
+def sharded_buffers(plan: ShardPlan, device=None, packed_ids: bool = False, all_ranks: bool = False):
     """(result_d, result_m, wire_d, wire_m) torch tensors of the sizes ``run_sharded`` needs on
     this rank: results only on the root, wire buffers only where something travels.
     ``packed_ids``: MRCA ids travel as 24 bits each (``wire_m`` is uint8: on the peers 3 bytes per
-    pair of the slice, on the root 3 bytes per pair of the batch, each with a few bytes of slack)."""
+    pair of the slice, on the root 3 bytes per pair of the batch, each with a few bytes of slack).
+    ``all_ranks``: every rank gets the root's buffers (``run_allgather``)."""
     import torch
 
     lo, hi = plan.bounds(plan.rank)
-    root = plan.rank == plan.root
+    root = all_ranks or plan.rank == plan.root
     result_d = torch.empty(plan.n if root else 0, dtype=torch.float64, device=device)
     result_m = torch.empty(plan.n if root else 0, dtype=torch.int32, device=device)
     if plan.world == 1:
         return result_d, result_m, None, None
     wire_d = torch.empty(plan.n if root else hi - lo, dtype=torch.float32, device=device)
     if packed_ids:
-        wire_m = torch.empty(packed_bytes(plan.n if root else hi - lo) + 16, dtype=torch.uint8, device=device)
+        wire_m = torch.empty(packed_bytes(plan.n if root else hi - lo) + 16 + 8 * plan.world, dtype=torch.uint8, device=device)
     else:
         wire_m = None if root else torch.empty(hi - lo, dtype=torch.int32, device=device)
     return result_d, result_m, wire_d, wire_m

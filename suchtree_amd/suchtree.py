@@ -67,13 +67,9 @@ class SuchTree(TreeNavigation):
     the bulk methods taking host arrays (``distances_bulk``, ``pairwise_distances``, ...) deal
     their work over every listed GPU from this one process.
     ``strategy``: ``'auto'`` | ``'canopy'`` | ``'walk'`` kernel family.
-    ``pinned_results``: hand bulk results out of a recycled pool of pinned, GPU-addressable
-    memory that the kernels write directly (no unpack pass, no page faults, no page teardown;
-    see ``_capi.ResultPool``).  Off by default: such arrays cannot be read by ``fork()`` children.
     """
 
-    def __init__(self, tree_input, device: int = 0, strategy: str = "auto", devices=None,
-                 pinned_results=None, table_mb=None):
+    def __init__(self, tree_input, device: int = 0, strategy: str = "auto", devices=None, table_mb=None):
         self._epsilon = EPSILON
         if isinstance(tree_input, FlatTree):
             flat = tree_input
@@ -103,7 +99,6 @@ class SuchTree(TreeNavigation):
         if strategy not in _capi.STRATEGY:
             raise ValueError("strategy must be one of %s" % sorted(_capi.STRATEGY))
         self._strategy = strategy
-        self._pinned_results = pinned_results
         self._table_mb = table_mb      # budget (MiB) of the device tables: _capi.DeviceTree
         self._dev_tree = None
 
@@ -118,8 +113,7 @@ class SuchTree(TreeNavigation):
         if self._dev_tree is None:
             self._dev_tree = _capi.DeviceTree(self._flat.parent, self._flat.distance,
                                               device=self._device, strategy=self._strategy,
-                                              devices=self._devices, pinned_results=self._pinned_results,
-                                              table_mb=self._table_mb)
+                                              devices=self._devices, table_mb=self._table_mb)
         return self._dev_tree
 
     def to_device(self) -> "SuchTree":

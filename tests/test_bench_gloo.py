@@ -152,6 +152,37 @@ def test_bench_job_line_on_gloo(world, share, chunks, n, wire):
     assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
 
 
+@pytest.mark.parametrize("world,mode,chunks,n,wire", [(2, "allgather", 3, 30011, 7), (3, "allgather", 4, 30013, 8), (4, "allgather", 1, 1003, 7),
+                                                     (2, "none", 2, 30011, 7), (3, "none", 1, 30013, 7), (4, "none", 4, 1003, 8)])
+def test_bench_gather_modes_on_gloo(world, mode, chunks, n, wire):
+    """--gather allgather (the result assembled on every rank by grouped send/recv between all pairs of ranks) and
+    --gather none (every rank keeps its slice; assembled once, untimed, for the parity check): even slices, the same line."""
+    from suchtree_amd import sharding
+    argv = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--pairs", str(n), "--levels", "9", "--gather", mode,
+            "--chunks", str(chunks), "--cpu-seconds", "0.2", "--deadline", "120"] + (["--wire-int32"] if wire == 8 else [])
+    procs, q, timeout = _run(world, argv)
+    res = sorted(q.get(timeout=timeout) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    d = json.loads(res[0][1])
+    assert d["gather"] == mode and d["config"]["gather"] == mode and d["n_gpus"] == world and d["scaling"] == "strong"
+    assert d["parity"]["distances_bit_exact"] and d["parity"]["mrca_bit_exact"]
+    assert d["parity_across_slices"]["distances_bit_exact"] and d["parity_across_slices"]["mrca_bit_exact"]
+    assert d["process_group"] == {"backend": "gloo", "world_size": world, "what": d["process_group"]["what"]}
+    assert len(d["per_rank"]["kernel_ms"]) == world and sum(d["per_rank"]["pairs"]) == n
+    assert abs(d["root_share"] - (sharding.shard_bounds(n, world, 0)[1]) / n) < 1e-12 and "root_share_calibration" not in d
+    assert d["gather_bytes_into_root"] == (0 if mode == "none" else wire * (n - sharding.shard_bounds(n, world, 0)[1]))
+    covered = []
+    for rank, _, calls in res:
+        plan = sharding.ShardPlan(n, world, rank, chunks=chunks, root_share=None, align=4)
+        want = [pc for pc in plan.pieces(rank) if pc[1] > pc[0]] * 2
+        assert [tuple(c) for c in calls][: len(want)] == want      # (--gather none: one more, untimed, pass for the parity check)
+        assert len(calls) == len(want) * (3 if mode == "none" else 2) // 2
+        covered += want[: len(want) // 2]
+    covered.sort()
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
 def test_a_hung_rank_ends_the_job_at_the_deadline():
     """Rank 1 never finishes its first piece: every rank must leave with code 3 when its deadline
     expires instead of waiting for the backend's own collective timeout."""

@@ -457,7 +457,7 @@ def test_wire_format_of_the_gather_on_one_gpu(ml_arrays):
     parent, dist_arr, leaf_ids = ml_arrays
     rng = np.random.default_rng(77)
     trees = [("ml.tree", parent, dist_arr, {}), ("ml.tree, walk family", parent, dist_arr, {"strategy": "walk"}),
-             ("2^16 leaves", *synth.balanced_tree(16), {}), ("2^16 leaves, scalar kernel", *synth.balanced_tree(16), {"pairs_per_lane": 0})]
+             ("2^16 leaves", *synth.balanced_tree(16), {})]
     for what, par, dst, opts in trees:
         dev = _capi.DeviceTree(par, dst)
         for name, v in opts.items():

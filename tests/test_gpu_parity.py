@@ -127,7 +127,8 @@ def test_config3_balanced_2_20_sample_and_full_size_properties():
     for name, (d, m) in _both(dev, sample).items():
         assert_bits_equal(d, want_d, name)
         assert np.array_equal(m, want_m), name
-    # full batch size of the bench step: size-independent properties
+    # a fifth of the bench step's batch through the host path, both families: size-independent properties
+    # (the whole 1e8-pair batch, device resident, exactly as bench.py launches it: test_config3_headline_launch_1e8_device_resident)
     big = synth.random_leaf_pairs(n_leaves, 20_000_000, seed=11)
     res = _both(dev, big)
     (dw, mw), (dc, mc) = res["walk"], res["canopy"]
@@ -150,6 +151,44 @@ def test_config3_balanced_2_20_sample_and_full_size_properties():
     expect = np.where(same, big[:, 0], (((la >> k) << 1 | 1) << k) - 1)
     assert np.array_equal(mc.astype(np.int64), expect)
     assert np.all(dc[same] == 0.0)
+    dev.close()
+
+
+def test_config3_headline_launch_1e8_device_resident():
+    """bench.py's timed call itself (bench.py::HipBackend.bind -> st_distances_device): SURVEY 8d config 3's batch --
+    default_rng(3).integers(0, 2^20, (1e8, 2)) * 2, int64 ids resident in HBM -- in ONE launch into float64 + int32
+    device buffers, i.e. k_canopy_ilp<7, 1, SrcContig, true> with the plain sinks.  MRCA ids: the closed form of a complete
+    tree on all 1e8 pairs; distances and ids: the oracle's bits on every 100th pair and on the first and last 1e5."""
+    import torch
+    levels, n_leaves, n = 20, 1 << 20, 100_000_000
+    parent, dist = synth.balanced_tree(levels)
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert (info["strategy"], info["record_bytes"], info["a_side_bytes"]) == ("canopy", 64, 4)      # the headline kernel's tables
+    host = synth.random_leaf_pairs(n_leaves, n, seed=3)
+    pairs = torch.from_numpy(host).cuda()
+    out_d = torch.full((n,), -1.0, dtype=torch.float64, device="cuda")
+    out_m = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    dev.distances_device(pairs.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    dev.fault_check(stream)
+    # closed form, all pairs: two leaves of a complete tree differ first at bit k of the leaf index
+    la, lb = pairs[:, 0] >> 1, pairs[:, 1] >> 1
+    x = la ^ lb
+    k = torch.where(x > 0, torch.floor(torch.log2(x.clamp(min=1).double())).long() + 1, torch.zeros_like(x))
+    expect = torch.where(x == 0, pairs[:, 0], (((la >> k) << 1 | 1) << k) - 1)
+    assert torch.equal(out_m.long(), expect)
+    assert bool((out_d[x == 0] == 0.0).all()) and bool((out_d[x != 0] > 0.0).all())
+    del la, lb, x, k, expect
+    # oracle bits: a strided sample of 1e6 pairs and both ends of the batch
+    O = OracleTree(parent, dist)
+    cores = len(os.sched_getaffinity(0))
+    idx = np.unique(np.concatenate([np.arange(0, n, 100), np.arange(0, 100_000), np.arange(n - 100_000, n)]))
+    it = torch.from_numpy(idx).cuda()
+    got_d, got_m = out_d[it].cpu().numpy(), out_m[it].cpu().numpy()
+    assert_bits_equal(got_d, O.distances_mt(host[idx], cores), "headline launch, sampled distances")
+    assert np.array_equal(got_m, O.mrca_bulk(host[idx]))
     dev.close()
 
 
@@ -610,9 +649,8 @@ def test_every_candidate_kernel_on_nj_tree(nj_arrays):
     dev = _capi.DeviceTree(parent, dist)
     assert dev.info()["record_bytes"] == 256
     seen = set()
-    for sort, ppl, walk, ladder in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 1, 0), (0, 1, 0, 1)):
+    for sort, walk, ladder in ((1, 0, 0), (0, 0, 0), (1, 1, 0), (0, 0, 1)):
         dev.set_option("tile_sort", sort)
-        dev.set_option("pairs_per_lane", ppl)
         dev.set_option("prefer_walk_sorted", walk)
         dev.set_option("ladder_scalar", ladder)
         kernel = dev.info()["big_batch_kernel"]
@@ -626,7 +664,7 @@ def test_every_candidate_kernel_on_nj_tree(nj_arrays):
         d, m = dev.distances_host(allp, True, True)      # (packed ids on the way back)
         assert_bits_equal(d, want_d, "host path, " + kernel)
         assert np.array_equal(m, want_m), kernel
-    assert seen == {"canopy_sorted", "canopy", "canopy_scalar", "walk_sorted", "canopy_ladder"}, seen
+    assert seen == {"canopy_sorted", "canopy", "walk_sorted", "canopy_ladder"}, seen
     out_m.fill_(-1)
     dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())      # k_mrca_ranks<31>
     dev.fault_check()
@@ -678,9 +716,8 @@ def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
     monkeypatch.delenv("SUCHTREE_AMD_TUNE_CACHE")
     run(dev, "default (%s)" % info["big_batch_kernel"])
     seen = set()
-    for sort, ppl, walk, ladder in ((1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 0, 0), (1, 0, 1, 0), (0, 1, 0, 1)):
+    for sort, walk, ladder in ((1, 0, 0), (0, 0, 0), (1, 1, 0), (0, 0, 1)):
         dev.set_option("tile_sort", sort)
-        dev.set_option("pairs_per_lane", ppl)
         dev.set_option("prefer_walk_sorted", walk)
         dev.set_option("ladder_scalar", ladder)
         kernel = dev.info()["big_batch_kernel"]
@@ -689,7 +726,7 @@ def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
         d, m = dev.distances_host(allp[:300_000], True, True)
         assert_bits_equal(d, want_d[:300_000], "host path, " + kernel)
         assert np.array_equal(m, want_m[:300_000])
-    assert seen == {"canopy_sorted", "canopy", "canopy_scalar", "walk_sorted", "canopy_ladder"}, seen
+    assert seen == {"canopy_sorted", "canopy", "walk_sorted", "canopy_ladder"}, seen
     dev.close()
     monkeypatch.setenv("SUCHTREE_AMD_AUTOTUNE", "0")
     dev = _capi.DeviceTree(parent, dist)
@@ -721,9 +758,8 @@ def test_deep_canopy_tree_with_walk_form_lineage_tables(ml_arrays, monkeypatch):
     out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
     out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
     seen = set()
-    for sort, ppl, walk in ((1, 0, 0), (0, 1, 0), (1, 0, 1)):
+    for sort, walk in ((1, 0), (0, 0), (1, 1)):
         dev.set_option("tile_sort", sort)
-        dev.set_option("pairs_per_lane", ppl)
         dev.set_option("prefer_walk_sorted", walk)
         dev.set_option("ladder_scalar", 0)      # (the handle may have chosen it; its own test: ..._is_timed_at_creation)
         kernel = dev.info()["big_batch_kernel"]
@@ -791,12 +827,10 @@ def test_table_budget_on_the_device(ml_arrays):
     dev = _capi.DeviceTree(par, dst, table_mb=20)
     info = dev.info()
     assert "rec_i" in info["dropped_tables"] and info["strategy"] == "canopy" and info["device_bytes"] <= 20 * 2**20, info
-    for ppl in (1, 2, 0):
-        dev.set_option("pairs_per_lane", ppl)
-        d, m = dev.distances_host(near, True, True)
-        assert_bits_equal(d, O.distances(near), "2^17 leaves without id chains, pairs_per_lane=%d" % ppl)
-        assert np.array_equal(m, O.mrca_bulk(near))
-        assert np.array_equal(dev.distances_host(near, False, True)[1], O.mrca_bulk(near))
+    d, m = dev.distances_host(near, True, True)
+    assert_bits_equal(d, O.distances(near), "2^17 leaves without id chains")
+    assert np.array_equal(m, O.mrca_bulk(near))
+    assert np.array_equal(dev.distances_host(near, False, True)[1], O.mrca_bulk(near))
     dev.close()
     # 2^24 leaves of random shape under 2 GiB: the floor (940 MB) and whatever else fits; the walk kernel climbs
     par, dst = synth.random_binary_tree_levels(1 << 24, seed=24)
@@ -893,10 +927,9 @@ def test_deep_tree_with_ids_that_are_not_in_order_positions(ml_arrays):
     dev = _capi.DeviceTree(p2, d2, strategy="canopy")
     assert dev.info()["record_bytes"] >= 128
     for opts in ({"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "ladder_dynamic": 0},
-                 {"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "ladder_dynamic": 2},
+                 {"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "ladder_dynamic": 1},
                  {"tile_sort": 1, "ladder_scalar": 0},
-                 {"tile_sort": 0, "ladder_scalar": 0, "pairs_per_lane": 1},
-                 {"tile_sort": 0, "ladder_scalar": 0, "pairs_per_lane": 0}):
+                 {"tile_sort": 0, "ladder_scalar": 0}):
         for k, v in opts.items():
             dev.set_option(k, v)
         d, m = dev.distances_host(pairs, True, True)
@@ -931,9 +964,9 @@ def test_batch_sizes_around_kernel_tile_boundaries(ml_arrays):
         dev.close()
 
 
-def test_non_default_canopy_variants(ml_arrays):
-    """The selectable forms of the canopy kernel -- scalar (pairs_per_lane 0), one and two
-    pairs per lane -- on a shallow and a deep tree, explicit pairs and the generated triangle."""
+def test_predicated_kernel_on_a_shallow_and_a_deep_tree(ml_arrays):
+    """The predicated canopy kernel forced (no tile sort, no ladder) on a shallow and a deep tree, explicit pairs and the
+    generated triangle."""
     rng = np.random.default_rng(21)
     trees = [synth.balanced_tree(16), (ml_arrays[0], ml_arrays[1])]
     for parent, dist in trees:
@@ -943,20 +976,19 @@ def test_non_default_canopy_variants(ml_arrays):
         ids = rng.choice(len(parent), size=500, replace=False).astype(np.int64)
         i, j = np.tril_indices(len(ids), -1)
         tri = np.stack([ids[j], ids[i]], 1)
-        want = (O.distances(pairs), O.mrca_bulk(pairs), O.distances(tri), O.mrca_bulk(tri))
-        for ppl in (0, 1, 2):
-            dev.set_option("pairs_per_lane", ppl)
-            d, m = dev.distances_host(pairs, want_dist=True, want_mrca=True)
-            td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
-            assert_bits_equal(d, want[0], "ppl%d" % ppl)
-            assert_bits_equal(td, want[2], "ppl%d triangle" % ppl)
-            assert np.array_equal(m, want[1]) and np.array_equal(tm, want[3])
+        for k, v in (("tile_sort", 0), ("ladder_scalar", 0), ("prefer_walk_sorted", 0)):
+            dev.set_option(k, v)
+        d, m = dev.distances_host(pairs, want_dist=True, want_mrca=True)
+        td, tm = dev.triangle_host(ids, want_dist=True, want_mrca=True)
+        assert_bits_equal(d, O.distances(pairs))
+        assert_bits_equal(td, O.distances(tri), "triangle")
+        assert np.array_equal(m, O.mrca_bulk(pairs)) and np.array_equal(tm, O.mrca_bulk(tri))
         dev.close()
 
 
 def test_argument_errors_on_a_live_handle(gopher_flat):
     dev = _capi.DeviceTree(gopher_flat.parent, gopher_flat.distance)
-    for name, value in (("pairs_per_lane", 3), ("lockstep", 1), ("flow", 1), ("nope", 1)):
+    for name, value in (("pairs_per_lane", 1), ("tile_sort", 3), ("ladder_dynamic", 2), ("measure", 8), ("nope", 1)):
         with pytest.raises(ValueError):
             dev.set_option(name, value)
     with pytest.raises(ValueError):

@@ -68,31 +68,13 @@ def test_lazy_upload_keeps_the_fork_pool_recipe_usable():
     assert T._dev_tree is None and _capi._gpu_pid == before
 
 
-def test_result_pool_lends_recycles_and_respects_its_budget(monkeypatch):
-    """_capi.ResultPool with a stand-in allocator (no GPU): a block is on loan while the array or
-    any view of it lives, comes back afterwards, is handed out again, and the budget holds."""
-    import ctypes
+def test_recycle_pool_lends_recycles_and_respects_its_budget():
+    """_capi.RecyclePool (no GPU): a block is on loan while the array or any view of it lives, comes back
+    afterwards, is handed out again, and the budget holds."""
     import gc
-
-    class FakeLib:
-        def __init__(self):
-            self.bufs, self.freed = {}, []
-
-        def st_host_alloc(self, cap, p):
-            b = ctypes.create_string_buffer(cap)
-            self.bufs[ctypes.addressof(b)] = b
-            ctypes.cast(p, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.addressof(b)
-            return 0
-
-        def st_host_free(self, p):
-            self.freed.append(p.value)
-            return 0
-
-    fake = FakeLib()
-    monkeypatch.setattr(_capi, "load", lambda: fake)
-    pool = _capi.ResultPool(budget_bytes=64 << 20)
-    a = pool.array(1_000_000, np.float64)
-    assert a.shape == (1_000_000,) and a.dtype == np.float64 and pool.total == 8 << 20
+    pool = _capi.RecyclePool(budget_bytes=192 << 20)
+    a = pool.array(5_000_000, np.float64)               # 40 MB -> 64 MiB class
+    assert a.shape == (5_000_000,) and a.dtype == np.float64 and pool.total == 64 << 20
     a[:] = 3.0
     view, ptr = a[10:20], a.ctypes.data
     del a
@@ -100,20 +82,17 @@ def test_result_pool_lends_recycles_and_respects_its_budget(monkeypatch):
     assert not pool._free                              # the view keeps the block on loan
     del view
     gc.collect()
-    assert pool._free == {8 << 20: [ptr]}
-    b = pool.array(900_000, np.float64)                # same size class: recycled, nothing new pinned
-    assert b.ctypes.data == ptr and pool.total == 8 << 20
-    assert pool.array(10, np.float64) is None          # too small to be worth a pinned block
-    c = pool.array(13_000_000, np.int32)               # 52 MB -> 64 MB class: would exceed the budget
-    assert c is None and pool.total == 8 << 20
-    assert _capi.ResultPool._size_class(3 << 20) == 4 << 20 and _capi.ResultPool._size_class(100 << 20) == 128 << 20
+    assert list(pool._free) == [64 << 20] and len(pool._free[64 << 20]) == 1
+    b = pool.array(4_500_000, np.float64)              # same size class: recycled, nothing new
+    assert b.ctypes.data == ptr and pool.total == 64 << 20
+    assert pool.array(10, np.float64) is None          # below 32 MiB: glibc recycles those itself
+    c = pool.array(40_000_000, np.int32)               # 160 MB -> 192 MiB class: would exceed the budget
+    assert c is None and pool.total == 64 << 20
+    assert _capi.RecyclePool._size_class(3 << 20) == 4 << 20 and _capi.RecyclePool._size_class(100 << 20) == 128 << 20
     del b
     gc.collect()
     pool.trim()
-    assert fake.freed == [ptr] and pool.total == 0
-    monkeypatch.setattr(pool, "_pid", -1)              # as seen from a forked child: hands out nothing
-    assert pool.array(1_000_000, np.float64) is None
-
+    assert pool.total == 0 and not pool._free
 
 def test_recycle_pool_of_ordinary_memory():
     """_capi.RecyclePool (the default home of result arrays of 32 MiB and more): on loan while the

@@ -109,6 +109,62 @@ def _worker_run_sharded(rank, world, port, n_pairs, chunks, root, q, root_share=
         dist.destroy_process_group()
 
 
+def _worker_run_allgather(rank, world, port, n_pairs, chunks, packed, q):
+    """sharding.run_allgather on gloo/CPU tensors, the oracle as the compute step: every rank ends with the whole result."""
+    import torch
+    import torch.distributed as dist
+    from oracle.oracle import OracleTree
+    from suchtree_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        parent, dist_ = synth.balanced_tree(9)
+        O = OracleTree(parent, dist_)
+        pairs = np.random.default_rng(6).integers(0, len(parent), (n_pairs, 2))
+        pairs[::5, 0] = pairs[::5, 1]
+        plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, align=4)
+        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, packed_ids=packed, all_ranks=True)
+        calls = []
+
+        def compute(lo, hi, dst_d, dst_m):
+            calls.append((lo, hi))
+            assert dst_d.dtype == torch.float32
+            dst_d.copy_(torch.from_numpy(O.distances(pairs[lo:hi])).to(torch.float32))
+            ids = torch.from_numpy(O.mrca_bulk(pairs[lo:hi]))
+            if packed:
+                assert dst_m.dtype == torch.uint8 and dst_m.numel() == sharding.packed_bytes(hi - lo) and dst_m.data_ptr() % 4 == 0
+                dst_m.fill_(0)
+                sharding.pack_mrca24(ids, dst_m)
+            else:
+                dst_m.copy_(ids)
+
+        for _ in range(2):
+            sharding.run_allgather(plan, compute, out_d, out_m, wire_d, wire_m)
+        lo, hi = plan.bounds(rank)
+        ok = sum(b - a for a, b in calls) == 2 * (hi - lo)
+        ok = ok and np.array_equal(out_d.numpy().view(np.int64), O.distances(pairs).view(np.int64))
+        ok = ok and np.array_equal(out_m.numpy(), O.mrca_bulk(pairs))
+        q.put((rank, bool(ok), len(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_pairs,chunks,packed", [(2, 1001, 3, True), (2, 4, 4, True), (3, 1001, 4, False), (3, 1000, 1, True),
+                                                         (4, 1003, 4, True), (4, 3, 2, False), (4, 1001, 3, False)])
+def test_run_allgather_on_gloo(world, n_pairs, chunks, packed):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_run_allgather, args=(r, world, port, n_pairs, chunks, packed, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert [r[1] for r in res] == [True] * world, res
+
+
 _CASES = [
     (2, 1001, 3, 0, None), (2, 4, 4, 0, None), (2, 777, 1, 1, None), (2, 1001, 4, 0, 0.8), (2, 1001, 2, 1, 0.37), (2, 50, 3, 0, 1.0),
     # more than one peer: the root posts receives from several ranks per piece, peers are indexed around the root
