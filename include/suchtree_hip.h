@@ -345,6 +345,10 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "small_batch_path": 1 (default) = host batches of <= 8192 pairs go through a pinned,
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe.
+ * "batch_probe": 1 (default) = on deep trees whose handle sends large distance batches to the scalar ladder kernel and
+ * whose tile-sorted walk kernel is ready as well, every device-resident batch of >= 524288 explicit pairs is sampled on
+ * the device (4096 pairs: do both nodes share their portal?) and goes to the walk kernel when a quarter of the sample
+ * does -- batches of close relatives -- else to the ladder kernel; no host round trip; 0 = always the handle's choice.
  * "measure" (default 0; MEASUREMENT ONLY): bits 1 = one line per host-path call on stderr with the host thread's time by
  * phase, 2 = the host path skips its pack / unpack passes, 4 = it launches nothing.  A call made with bit 2 or 4 set
  * returns ST_ERR_MEASURE_ONLY, never ST_OK: its result arrays are not valid. */

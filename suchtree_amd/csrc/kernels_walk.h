@@ -66,8 +66,11 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
 // read; only the nodes below the portal are streamed from global memory.
 template <int Q, bool LADDER, typename Src>
 __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Src src, long long n, DistSink out_d,
-                                                                 MrcaSink out_m, Fault *fault, int key_shift)
+                                                                 MrcaSink out_m, Fault *fault, int key_shift, const int *choice)
 {
+    // `choice` (or NULL): a word the batch probe wrote on this stream (kernels_canopy.h: k_probe_shared_portal); this
+    // kernel is the batch's kernel when it is 1, the scalar ladder kernel, launched beside it, when it is 0
+    if (choice && *choice == 0) return;
     extern __shared__ __align__(16) unsigned char walk_lds_all[];
     const LdsLadder LAD(walk_lds_all);
     unsigned char *walk_lds = walk_lds_all + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);

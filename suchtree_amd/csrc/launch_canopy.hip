@@ -48,7 +48,7 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
 constexpr int64_t kLadderDynamicMin = (int64_t)1 << 22;      // (records of 512 bytes and more; 1 KB records: half of it)
 template <int CAP, typename Src>
 static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
+                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice = nullptr)
 {
     const size_t lds = ladder_kernel_lds_bytes(t->canopy_nodes);      // (image + the kernel's eight "counter ran dry" flags)
     if (lds > kLdsBytesPerCu) return hipErrorInvalidValue;            // (launch_policy.h::ladder_tables_ready keeps such trees away)
@@ -74,7 +74,7 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
             if (e != hipSuccess) return e;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, work);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kCanopyBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, work, choice);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && work) e = hipEventRecord(done, stream);
     return e;
@@ -82,14 +82,15 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
 
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                  DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream)
+                                  DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
 {
     // the scalar ladder kernel: large distance batches of handles that chose it (launch_policy.h: ladder_applies;
     // records of more than 512 bytes: every batch the family takes -- nothing else reads them well)
     if constexpr (CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63) {
         if ((out_d.any() && ladder_applies(t, n)) || (t->rec_bytes > 512 && t->ladder_scalar && ladder_tables_ready(t)))
-            return launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream);
+            return launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream, choice);
     }
+    if (choice) return hipErrorInvalidValue;      // (a probed batch is one the scalar ladder kernel takes: host_launch.h)
     // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
     if (t->tile_sort && sorted_q(t) > 0)
         return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
@@ -112,8 +113,16 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
 }
 
 template <typename Src>
+hipError_t launch_probe(const st_tree *t, const Src &src, int64_t n, int *choice, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_probe_shared_portal<Src>, dim3(1), dim3(1024), 0, stream, t->d_rec_r, src, (long long)n, (long long)t->n_nodes,
+                       (long long)t->n_leaves, t->parity, choice);
+    return hipGetLastError();
+}
+
+template <typename Src>
 hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                                MrcaSink out_m, Fault *fault, hipStream_t stream)
+                                MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
 {
     CanopyParams P;
     P.canopy = t->d_canopy;
@@ -159,19 +168,20 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
         ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq, sorted_shape(t).sums) > 80 * 1024)
         return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
     switch (t->rec_cap) {
-        case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream);
-        case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream);
-        case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, fault, stream);
-        case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, fault, stream);
-        case 31: return launch_canopy_t<31>(t, P, src, n, out_d, out_m, fault, stream);
-        case 63: return launch_canopy_t<63>(t, P, src, n, out_d, out_m, fault, stream);
-        default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, fault, stream);
+        case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        case 7: return launch_canopy_t<7>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        case 15: return launch_canopy_t<15>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        case 31: return launch_canopy_t<31>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        case 63: return launch_canopy_t<63>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        default: return launch_canopy_t<0>(t, P, src, n, out_d, out_m, fault, stream, choice);
     }
 }
 
 
 #define ST_INSTANTIATE_CANOPY(S) \
-    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
+    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *); \
+    template hipError_t launch_probe<S>(const st_tree *, const S &, int64_t, int *, hipStream_t);
 ST_FOR_EACH_SRC(ST_INSTANTIATE_CANOPY)
 
 }  // namespace st

@@ -43,7 +43,7 @@ static WalkParams walk_params(const st_tree *t)
 
 template <int Q, bool LADDER, typename Src>
 static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, const Src &src, int64_t n, DistSink out_d,
-                                     MrcaSink out_m, Fault *fault, hipStream_t stream)
+                                     MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
 {
     constexpr int64_t tile = (int64_t)Q * kWalkSortBlock;
     const size_t lds = walk_sort_scratch_bytes(Q) + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
@@ -56,13 +56,13 @@ static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, cons
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWalkSortBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, key_shift);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWalkSortBlock), lds, stream, P, src, (long long)n, out_d, out_m, fault, key_shift, choice);
     return hipGetLastError();
 }
 
 template <typename Src>
 hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                              MrcaSink out_m, Fault *fault, hipStream_t stream)
+                              MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
 {
     const WalkParams P = walk_params(t);
     if (out_d.any() && n >= walk_sorted_min_pairs(t) && walk_sorted_ready(t)) {
@@ -73,16 +73,17 @@ hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out
             const int q_max = image + walk_sort_scratch_bytes(4) <= 160 * 1024 ? 4 : image + walk_sort_scratch_bytes(2) <= 160 * 1024 ? 2 : 1;
             if (image + walk_sort_scratch_bytes(q_max) <= 160 * 1024) {
                 const int q = batch_tile_q(q_max, 1, t->sort_tile, n, t->n_cu);
-                if (q == 4) return launch_walk_sorted<4, true>(t, P, src, n, out_d, out_m, fault, stream);
-                if (q == 2) return launch_walk_sorted<2, true>(t, P, src, n, out_d, out_m, fault, stream);
-                return launch_walk_sorted<1, true>(t, P, src, n, out_d, out_m, fault, stream);
+                if (q == 4) return launch_walk_sorted<4, true>(t, P, src, n, out_d, out_m, fault, stream, choice);
+                if (q == 2) return launch_walk_sorted<2, true>(t, P, src, n, out_d, out_m, fault, stream, choice);
+                return launch_walk_sorted<1, true>(t, P, src, n, out_d, out_m, fault, stream, choice);
             }
         }
         const int q = batch_tile_q(t->has_canopy ? 4 : 2, 1, t->sort_tile, n, t->n_cu);
-        if (q == 4) return launch_walk_sorted<4, false>(t, P, src, n, out_d, out_m, fault, stream);
-        if (q == 2) return launch_walk_sorted<2, false>(t, P, src, n, out_d, out_m, fault, stream);
-        return launch_walk_sorted<1, false>(t, P, src, n, out_d, out_m, fault, stream);
+        if (q == 4) return launch_walk_sorted<4, false>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        if (q == 2) return launch_walk_sorted<2, false>(t, P, src, n, out_d, out_m, fault, stream, choice);
+        return launch_walk_sorted<1, false>(t, P, src, n, out_d, out_m, fault, stream, choice);
     }
+    if (choice) return hipErrorInvalidValue;      // (a probed batch is one the tile-sorted kernel takes: host_launch.h)
     int64_t blocks = (n + 255) / 256;
     blocks = std::min<int64_t>(blocks, (int64_t)t->n_cu * 16);
     blocks = std::max<int64_t>(blocks, 1);
@@ -93,7 +94,7 @@ hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out
 
 
 #define ST_INSTANTIATE_WALK(S) \
-    template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
+    template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *);
 ST_FOR_EACH_SRC(ST_INSTANTIATE_WALK)
 
 hipError_t launch_walk_mailbox(const st_tree *t, const long long *d_pairs, int n, double *d_dist, int *d_mrca,

@@ -355,6 +355,9 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_work);
         for (hipEvent_t ev : t->work_done)
             if (ev) (void)hipEventDestroy(ev);
+        (void)hipFree(t->d_choice);
+        for (hipEvent_t ev : t->choice_done)
+            if (ev) (void)hipEventDestroy(ev);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
         (void)hipFree(t->d_fault_mb);
@@ -421,6 +424,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "ladder_dynamic") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_dynamic must be 0 or 1");
         t->ladder_dynamic = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "batch_probe") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "batch_probe must be 0 or 1");
+        t->batch_probe = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "measure") == 0) {      // (host_path.h::run_pipe; peers of a multi-device handle follow)

@@ -964,6 +964,48 @@ def test_batch_sizes_around_kernel_tile_boundaries(ml_arrays):
         dev.close()
 
 
+@pytest.mark.parametrize("which", ["ml", "nj"])
+def test_batch_probe_keeps_the_bits(which, ml_arrays, nj_arrays):
+    """Large explicit batches on a deep tree are dealt by the batch probe (k_probe_shared_portal): pairs of nearby leaves
+    go to the tile-sorted walk kernel, uniform pairs to the scalar ladder kernel, a half-and-half batch to whichever the
+    sample says -- the results are the oracle's bits every time, and the same with the probe switched off."""
+    import torch
+    parent, dist, leaf_ids = ml_arrays if which == "ml" else nj_arrays
+    rng = np.random.default_rng(31)
+    n = 1_200_000
+    ia = rng.integers(0, len(leaf_ids), n)
+    near = np.stack([leaf_ids[ia], leaf_ids[np.clip(ia + rng.integers(-8, 9, n), 0, len(leaf_ids) - 1)]], 1).astype(np.int64)
+    uniform = rng.choice(leaf_ids, size=(n, 2)).astype(np.int64)
+    mixed = np.where((np.arange(n) % 2 == 0)[:, None], near, uniform)
+    dev = _capi.DeviceTree(parent, dist)
+    for k, v in (("tile_sort", 0), ("ladder_scalar", 1), ("ladder_min_pairs", 0), ("prefer_walk_sorted", 0)):
+        dev.set_option(k, v)      # (the ladder kernel as the handle's choice, whatever it timed)
+    out_d = torch.empty(n, dtype=torch.float64, device="cuda")
+    out_m = torch.empty(n, dtype=torch.int32, device="cuda")
+    cores = len(os.sched_getaffinity(0))
+    O = OracleTree(parent, dist)
+    for name, batch in (("near", near), ("uniform", uniform), ("mixed", mixed)):
+        want_d, want_m = O.distances_mt(batch, cores), O.mrca_bulk(batch[:200_000])
+        t = torch.from_numpy(batch).cuda()
+        for probe in (1, 0):
+            dev.set_option("batch_probe", probe)
+            out_d.fill_(-1.0)
+            out_m.fill_(-7)
+            for _ in range(3):      # (back to back: the probe's words are reused)
+                dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d.cpu().numpy(), want_d, "%s probe=%d" % (name, probe))
+            assert np.array_equal(out_m[:200_000].cpu().numpy(), want_m), name
+    bad = near.copy()
+    bad[::4096, 1] = len(parent) + 5      # exactly the probe's own sample positions hold an id out of range
+    t = torch.from_numpy(bad).cuda()
+    dev.set_option("batch_probe", 1)
+    dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
+    with pytest.raises(InvalidNodeError):
+        dev.fault_check()
+    dev.close()
+
+
 def test_predicated_kernel_on_a_shallow_and_a_deep_tree(ml_arrays):
     """The predicated canopy kernel forced (no tile sort, no ladder) on a shallow and a deep tree, explicit pairs and the
     generated triangle."""
