@@ -1006,6 +1006,43 @@ def test_batch_probe_keeps_the_bits(which, ml_arrays, nj_arrays):
     dev.close()
 
 
+def test_counter_and_probe_slots_survive_many_launches_on_several_streams():
+    """The scalar ladder kernel's work counters and the batch probe's words are rings of 64 slots on the handle; a slot's
+    reuse is ordered behind its last user by an event, whatever stream that was on.  200 launches of 2^22 pairs (the
+    size at which 512-byte records draw their work dynamically) dealt round-robin over three streams without any host
+    synchronisation in between: every launch must produce the whole, correct result."""
+    import torch
+    parent, dist = synth.skewed_tree(np.random.default_rng(5), 1_000_000, 0.8)
+    dev = _capi.DeviceTree(parent, dist)
+    info = dev.info()
+    assert info["record_bytes"] == 512 and info["big_batch_kernel"] == "canopy_ladder", info
+    n = 1 << 22
+    pairs = torch.from_numpy(synth.random_leaf_pairs(1_000_000, n, seed=8)).cuda()
+    ref_d = torch.empty(n, dtype=torch.float64, device="cuda")
+    ref_m = torch.empty(n, dtype=torch.int32, device="cuda")
+    dev.distances_device(pairs.data_ptr(), n, ref_d.data_ptr(), ref_m.data_ptr())
+    torch.cuda.synchronize()
+    dev.fault_check()
+    O = OracleTree(parent, dist)
+    k = 100_000
+    assert_bits_equal(ref_d[:k].cpu().numpy(), O.distances_mt(pairs[:k].cpu().numpy(), len(os.sched_getaffinity(0))))
+    assert np.array_equal(ref_m[:k].cpu().numpy(), O.mrca_bulk(pairs[:k].cpu().numpy()))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [(torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda")) for _ in streams]
+    torch.cuda.synchronize()
+    for launch in range(200):
+        s = streams[launch % 3]
+        d, m = outs[launch % 3]
+        with torch.cuda.stream(s):
+            d.fill_(-1.0)      # (on the launch's own stream: a pair a kernel skips keeps the sentinel)
+            m.fill_(-7)
+            dev.distances_device(pairs.data_ptr(), n, d.data_ptr(), m.data_ptr(), stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    for d, m in outs:
+        assert torch.equal(d.view(torch.int64), ref_d.view(torch.int64)) and torch.equal(m, ref_m)
+    dev.close()
+
+
 def test_predicated_kernel_on_a_shallow_and_a_deep_tree(ml_arrays):
     """The predicated canopy kernel forced (no tile sort, no ladder) on a shallow and a deep tree, explicit pairs and the
     generated triangle."""
