@@ -112,6 +112,16 @@ def three_ceilings(traffic, pairs_per_s, algorithmic_bytes_per_pair, ceiling=Non
                 out["request_rate"].update({"ceiling_Greads_per_s": ceiling["Greads_per_s"], "ceiling_table_MiB": ceiling["MiB"],
                                             "ceiling_shape": ceiling.get("best_shape"),
                                             "frac": rpp * pairs_per_s / 1e9 / ceiling["Greads_per_s"]})
+        l2 = traffic.get("counters_mean_per_launch", {}).get("TCP_TCC_READ_REQ_sum")
+        if l2:
+            # reads that miss the CU's L1 and go to L2: what the deep-tree kernels' time follows (profiles/ladder_ablation_r05.log),
+            # against the random-sector rate of an L2-resident table from the round's committed sweep
+            rpp = l2 / traffic["pairs_per_launch"]
+            out["l2_request_rate"] = {"l2_reads_per_pair": rpp, "Greads_per_s": rpp * pairs_per_s / 1e9}
+            c = committed_sector_ceiling(2 << 20)
+            if c and c.get("table_MiB", 0) <= 2:
+                out["l2_request_rate"].update({"ceiling_Greads_per_s": c["Greads_per_s"], "ceiling_source": "%s (%s)" % (c["source"], c["entry"]),
+                                               "frac": rpp * pairs_per_s / 1e9 / c["Greads_per_s"]})
     return out
 
 
