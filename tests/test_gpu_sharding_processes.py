@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_pairs, chunks, root, root_share, packed, q):
+def _worker(rank, world, port, n_pairs, chunks, root, root_share, packed, q, allgather=False):
     import torch
     import torch.distributed as dist
     from suchtree_amd import _capi, sharding, synth
@@ -34,7 +34,7 @@ def _worker(rank, world, port, n_pairs, chunks, root, root_share, packed, q):
         host[::7, 0] = host[::7, 1]
         pairs = torch.from_numpy(host).cuda()
         plan = sharding.ShardPlan(n_pairs, world, rank, chunks=chunks, root=root, root_share=root_share, align=4 if packed else 1)
-        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, packed_ids=packed)      # CPU tensors (gloo)
+        out_d, out_m, wire_d, wire_m = sharding.sharded_buffers(plan, packed_ids=packed, all_ranks=allgather)      # CPU tensors (gloo)
 
         def compute(lo, hi, dst_d, dst_m):
             n = hi - lo
@@ -52,9 +52,12 @@ def _worker(rank, world, port, n_pairs, chunks, root, root_share, packed, q):
             dst_m.copy_(dev_m.cpu())
 
         for _ in range(2):
-            sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
+            if allgather:
+                sharding.run_allgather(plan, compute, out_d, out_m, wire_d, wire_m)
+            else:
+                sharding.run_sharded(plan, compute, out_d, out_m, wire_d, wire_m)
         tree.fault_check()
-        if rank == root:
+        if rank == root or allgather:
             q.put((rank, out_d.numpy().copy(), out_m.numpy().copy()))
         else:
             q.put((rank, None, None))
@@ -84,3 +87,26 @@ def test_sharded_step_in_processes_on_one_gpu(world, n_pairs, chunks, root, root
     got_d, got_m = res[root][1], res[root][2]
     assert np.array_equal(got_d.view(np.int64), want_d.view(np.int64)) and np.array_equal(got_m, want_m)
     assert all(r[1] is None for r in res if r[0] != root)
+
+
+@pytest.mark.parametrize("world,n_pairs,chunks,packed", [(2, 300_001, 3, True), (3, 100_003, 4, False), (4, 70_001, 2, True)])
+def test_allgather_step_in_processes_on_one_gpu(world, n_pairs, chunks, packed):
+    """sharding.run_allgather (bench.py --gather allgather) with the product's kernels: every rank ends with the whole
+    result; the packed ids of every slice sit in a region of their own of the wire buffer, written there by the kernels."""
+    import torch.multiprocessing as mp
+    from conftest import oracle_both
+    from suchtree_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, chunks, 0, None, packed, q, True)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    parent, dist_ = synth.skewed_tree(np.random.default_rng(3), 40_000, 0.6)
+    host = np.random.default_rng(5).integers(0, len(parent), (n_pairs, 2))
+    host[::7, 0] = host[::7, 1]
+    want_d, want_m = oracle_both(parent, dist_, host)
+    for _, got_d, got_m in res:
+        assert np.array_equal(got_d.view(np.int64), want_d.view(np.int64)) and np.array_equal(got_m, want_m)
