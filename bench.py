@@ -69,6 +69,9 @@ def parse(argv=None):
                          "assembled on rank 0 by point-to-point transfers; allgather: assembled on every rank (even slices, "
                          "grouped send/recv between all pairs of GPUs); none: every rank keeps its slice (nothing travels; the "
                          "slices are gathered once, untimed, for the parity check)")
+    ap.add_argument("--no-gather-sweep", action="store_true",
+                    help="N > 1, strong scaling: skip the few steps of the two OTHER gather modes timed after the timed region "
+                         "(gather_modes in the line)")
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="N > 1: CUs rank 0's kernels leave free for RCCL's receive kernels (handle option reserve_cus)")
     ap.add_argument("--wire-int32", action="store_true",
@@ -486,6 +489,48 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
                 raise SystemExit("bench.py: --gather none: rank 0's resident slice differs from the assembled result")
         be.fault_check()
 
+    gather_modes = None
+    if strong and world > 1 and not args.no_gather_sweep:
+        # After the timed region, a few steps of each of the other two gather modes, timed the same way (barrier, sync, max
+        # over ranks), so that ONE run at N GPUs shows what the gather costs: kernels alone (none), every link at once
+        # (allgather), everything into rank 0 (root).  Not part of `value`.
+        gather_modes = {mode: {"ms_per_step": elapsed / args.steps * 1e3, "pairs_per_s": n * args.steps / elapsed, "steps": args.steps,
+                               "timed_region": True}}
+        k = max(1, min(args.steps, 5))
+        for other in ("root", "allgather", "none"):
+            if other == mode:
+                continue
+            with Deadline(args.deadline, "the %s gather mode's %d steps" % (other, k), rank):
+                o_plan = sharding.ShardPlan(n, world, rank, chunks=args.chunks, root_share=root_share if other == "root" else None, align=4)
+                o_d, o_m, o_wd, o_wm = sharding.sharded_buffers(o_plan, device=be.device, packed_ids=packed, all_ranks=other == "allgather")
+                o_lo, o_hi = o_plan.bounds(rank)
+                o_own = (torch.empty(o_hi - o_lo, dtype=torch.float64, device=be.device),
+                         torch.empty(o_hi - o_lo, dtype=torch.int32, device=be.device)) if other == "none" else None
+
+                def o_step():
+                    if other == "allgather":
+                        sharding.run_allgather(o_plan, compute, o_d, o_m, o_wd, o_wm, unpack=unpack)
+                    elif other == "none":
+                        sharding.run_local(o_plan, compute, o_own[0], o_own[1])
+                    else:
+                        sharding.run_sharded(o_plan, compute, o_d, o_m, o_wd, o_wm, unpack=unpack)
+
+                o_step()
+                be.synchronize()
+                barrier()
+                be.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    o_step()
+                be.synchronize()
+                barrier()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
+                dg.all_reduce(dt, op=dg.ReduceOp.MAX)
+                be.fault_check()
+                gather_modes[other] = {"ms_per_step": float(dt[0].item()) / k * 1e3, "pairs_per_s": n * k / float(dt[0].item()), "steps": k,
+                                       "timed_region": False}
+                del o_d, o_m, o_wd, o_wm, o_own
+
     line = None
     if rank != 0 and peers_wait is not None:
         peers_wait()
@@ -505,6 +550,8 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
                                      "what": "as torch.distributed reports them for the group the step ran on (nccl = RCCL on ROCm)"}
         if per_rank:
             line["per_rank"] = per_rank
+        if gather_modes:
+            line["gather_modes"] = gather_modes
         roof = line["roofline"]
         if hasattr(be, "extra_legs"):
             be.extra_legs(args, line, roof, pairs, out_d, out_m, traffic, traffic_file, pairs_this_rank, kernel_ms)
