@@ -355,7 +355,8 @@ class HipBackend:
             # the tables the kernel gathers from, for leaf pairs: rec_b (half a record per leaf) and rec_a4 (4 B) or
             # rec_a (8 B); walk family: node records + lineage blocks are not modelled (12 B per node as a floor)
             a_bytes = info.get("a_side_bytes") or 8
-            foot = self.n_leaves * (a_bytes + info["record_bytes"] // 2) if info["strategy"] == "canopy" else info["n_nodes"] * 12
+            b_bytes = info.get("b_table_bytes_per_leaf") or info["record_bytes"] // 2      # (cherry records: half of rec_b)
+            foot = self.n_leaves * (a_bytes + b_bytes) if info["strategy"] == "canopy" else info["n_nodes"] * 12
             hw = bench_legs.hardware_ceilings(self.local_rank, foot)
             if hw:
                 line["hardware_measured"] = hw

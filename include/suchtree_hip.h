@@ -69,6 +69,9 @@ typedef struct st_tree_info {
     int32_t a_side_bytes;     /* canopy family: bytes gathered for the first node of a pair, 4 (rec_a4 + block table) or 8 */
     int32_t dropped_tables;   /* ST_TABLE_* bits: what the table budget left out (slower forms of the kernels take over) */
     int64_t table_budget_bytes;   /* the budget this handle was built under (0 = none) */
+    int32_t b_table_bytes_per_leaf;   /* canopy family: bytes per leaf of the table the second node of a leaf pair gathers from:
+                                         record_bytes / 2, or record_bytes / 4 where sibling leaves share a cherry record */
+    int32_t reserved0;
 } st_tree_info;
 
 /* st_tree_info.dropped_tables, in the order in which a table budget (st_tree_options.table_budget_bytes, else
@@ -78,7 +81,7 @@ typedef struct st_tree_info {
 #define ST_TABLE_TREE_RMQ      4   /* whole-tree sparse table: the walk family finds meeting nodes by climbing */
 #define ST_TABLE_REC_I         8   /* id chains of the understory records (as large as the b-side records: judged when the
                                       records are sized): pairs under one portal are walked on the tree */
-#define ST_TABLE_REC_A4       16   /* four-byte a side of the predicated kernel: the 8-byte entries serve */
+#define ST_TABLE_REC_A4       16   /* four-byte a side of the predicated kernel and the cherry records of its b side: the 8-byte entries and rec_b serve */
 #define ST_TABLE_RANKS        32   /* rank table of MRCA-only requests: they go through the distance kernels */
 #define ST_TABLE_CANOPY       64   /* every canopy table: the walk family serves the tree */
 
@@ -335,6 +338,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * "rec_a4": 1 (default) = on trees whose leaves sit in portal-uniform aligned blocks of leaf slots (balanced
  * and near-balanced trees) the predicated canopy kernel gathers 4 bytes for the first node of a pair
  * (its understory sum; the portal comes from a block table in LDS) instead of the 8-byte entry; 0 = 8 bytes.
+ * "cherries": 1 (default) = on such trees the second node of a pair, when it is a leaf whose block of leaf slots consists
+ * of sibling pairs, is read from the pair's cherry record (one record of rec_b's size per two leaves: half the table);
+ * 0 = from rec_b.
  * "wire48": 1 (default) = on trees of fewer than 2^24 nodes the host entry points ship ids over the link as 24 bits
  * each (6 bytes per pair instead of 8; the packing step then checks the range and keeps the id to report); 0 = int32.
  * "wire24": 1 (default) = on such trees MRCA ids come back over the link as 24 bits each (7 bytes per pair with the

@@ -33,7 +33,7 @@ def main():
                     info = eval(line, {"__builtins__": {}}, {})      # (a dict literal printed by our own script)
                     break
         n_leaves = 1 << L
-        rec_half = (info.get("record_bytes") or 0) // 2
+        rec_half = info.get("b_table_bytes_per_leaf") or (info.get("record_bytes") or 0) // 2      # (bytes per leaf of the b-side table)
         a_bytes = info.get("a_side_bytes") or 8
         foot = n_leaves * (rec_half + a_bytes) if rec_half else None
         ns = k.get("avg_ns")
@@ -49,7 +49,7 @@ def main():
                "fabric_read_requests_per_pair": c.get("TCC_EA0_RDREQ_sum", 0) / pairs if c.get("TCC_EA0_RDREQ_sum") else None,
                "read_requests_dram_per_pair": c.get("TCC_EA0_RDREQ_DRAM_sum", 0) / pairs if c.get("TCC_EA0_RDREQ_DRAM_sum") else None,
                "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) if c.get("TCC_HIT_sum") and c.get("TCC_MISS_sum") else None,
-               "useful_bytes_per_pair": 28 + rec_half + (4 if a_bytes == 4 else 8) if rec_half else None,
+               "useful_bytes_per_pair": 28 + (info.get("record_bytes") or 0) // 2 + (4 if a_bytes == 4 else 8) if rec_half else None,
                "source": "profiles/traffic_fp%d_%s.json, profiles/kernel_stats_fp%d_%s.csv" % (L, tag, L, tag)}
         rows.append(row)
     out = {"what": "st_distances_device on balanced trees, 1e8 uniform random leaf pairs (int64 ids in HBM -> float64 + int32), "

@@ -9,6 +9,7 @@ TAG=${1:-r02}; shift || true
 ARGS=${@:-"--steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-microbench --no-other-configs"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT      # (raw outputs of an earlier call must not be averaged in)
 mkdir -p $OUT $REPO/scripts/micro/bin
 # the calibration program (known traffic) is built on demand; binaries are not kept in git
 [ -x $REPO/scripts/micro/bin/calib_requests ] || hipcc --offload-arch=gfx950 -O3 -o $REPO/scripts/micro/bin/calib_requests $REPO/scripts/micro/calib_requests.hip
@@ -26,3 +27,5 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC
 done
 cd $REPO
 python3 scripts/summarize_profile.py $OUT $TAG || true
+mkdir -p gpurun_out/round_profiles
+cp profiles/kernel_stats_$TAG.csv profiles/traffic_$TAG.json profiles/calibration_$TAG.json gpurun_out/round_profiles/ 2>/dev/null

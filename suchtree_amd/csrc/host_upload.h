@@ -107,7 +107,7 @@ static int64_t device_bytes_of(const BuiltTables &B)
     b += sz(T.canopy) + 8 + sz(T.canopy_id) + sz(T.ladder) + sz(T.canopy_depth) + 16 + (int64_t)kWorkSlots * 64 * 8;
     if (B.deep && T.inorder_ids && !T.canopy_rmq.empty()) b += sz(T.canopy_pos) + sz(T.canopy_rmq);
     b += sz(T.rec_a) + sz(T.rec_b) + sz(T.rec_i);
-    if (!T.rec_a4.empty()) b += sz(T.rec_a4) + sz(T.leaf_block_portal) + 16;
+    if (!T.rec_a4.empty()) b += sz(T.rec_a4) + sz(T.leaf_block_portal) + 16 + sz(T.rec_c);
     if (!T.rec_r.empty()) b += sz(T.rec_r) / 2 + sz(T.canopy_rmq64);      // (uploaded as 2-byte ranks)
     if (!T.lineage_sum.empty()) b += sz(T.lineage_sum) + sz(T.rec_p) + walk_lineage_bytes();
     return b;
@@ -131,11 +131,11 @@ static void apply_table_budget(BuiltTables &B)
     }
     if (over() && !T.tree_rmq.empty()) { clear(T.tree_rmq); T.tree_rmq_levels = 0; B.dropped |= ST_TABLE_TREE_RMQ; }
     if (over() && B.canopy_ok && !T.rec_i.empty()) { clear(T.rec_i); B.dropped |= ST_TABLE_REC_I; }
-    if (over() && !T.rec_a4.empty()) { clear(T.rec_a4); clear(T.leaf_block_portal); B.dropped |= ST_TABLE_REC_A4; }
+    if (over() && !T.rec_a4.empty()) { clear(T.rec_a4); clear(T.leaf_block_portal); clear(T.rec_c); B.dropped |= ST_TABLE_REC_A4; }
     if (over() && !T.rec_r.empty()) { clear(T.rec_r); clear(T.canopy_rmq64); B.dropped |= ST_TABLE_RANKS; }
     if (over() && B.canopy_ok) {
         clear(T.canopy); clear(T.canopy_id); clear(T.ladder); clear(T.canopy_depth); clear(T.canopy_pos); clear(T.canopy_rmq);
-        clear(T.rec_a); clear(T.rec_b); clear(T.rec_i); clear(T.rec_a4); clear(T.leaf_block_portal); clear(T.rec_r);
+        clear(T.rec_a); clear(T.rec_b); clear(T.rec_i); clear(T.rec_a4); clear(T.leaf_block_portal); clear(T.rec_c); clear(T.rec_r);
         clear(T.canopy_rmq64); clear(T.rec_p);
         T.has_canopy = false;
         B.canopy_ok = false;
@@ -205,7 +205,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
     }
     if (B.canopy_ok) (void)prepare_rank_table(B.T);      // MRCA-only queries of in-order trees
     // four-byte a side for the predicated kernel (shallow canopies): 32 KiB of LDS are left beside a full canopy image
-    if (B.canopy_ok && !B.deep && B.T.record_cap <= 15) (void)prepare_leaf_blocks(B.T, 8192);
+    if (B.canopy_ok && !B.deep && B.T.record_cap <= 15 && prepare_leaf_blocks(B.T, 8192)) (void)prepare_cherries(B.T);      // (+ one record per pair of sibling leaves)
     if (!B.canopy_ok) build_walk_only_tables(B, n_nodes, false);
     apply_table_budget(B);
     return ST_OK;
@@ -338,6 +338,12 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
                 if (upload_optional(&t->d_leaf_blocks, blocks, &bytes)) {
                     t->leaf_block_shift = T.leaf_block_shift;
                     t->leaf_block_count = (int32_t)T.leaf_block_portal.size();
+                    // cherry records: the block table carries their bits, so without the table on the device they must go too
+                    if (!T.rec_c.empty() && !upload_optional(&t->d_rec_c, T.rec_c, &bytes)) {
+                        for (uint16_t &e : blocks)
+                            if (e != kLeafBlockMixed) e &= (uint16_t)~kLeafBlockCherries;
+                        (void)hipMemcpy(t->d_leaf_blocks, blocks.data(), blocks.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+                    }
                 } else {
                     (void)hipFree(t->d_rec_a4);
                     t->d_rec_a4 = nullptr;

@@ -19,6 +19,7 @@ struct CanopyParams {
     const uint8_t *rec_a;          // [n_nodes * 8]            {word0, pbot}
     const float *rec_a4;           // [n_nodes]                pbot alone (tree_prep.h: four-byte form of the a side), or NULL
     const uint16_t *leaf_blocks;   // [leaf_block_count]       portal of every aligned block of leaf slots (staged to LDS), or NULL
+    const uint8_t *rec_c;          // [ceil(n_leaves / 2) * rec_bytes/2] cherry records (tree_prep.h), or NULL
     int32_t leaf_block_shift, leaf_block_count;
     const uint8_t *rec_b;          // [n_nodes * rec_bytes/2]  {word0, chain lengths}
     const uint8_t *rec_i;          // [n_nodes * rec_bytes/2]  {pbot, chain node ids}; NULL: left out under a table budget
@@ -356,10 +357,21 @@ __global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) voi
         for (int j = 0; j < PPL; j++) {
             const uint8_t *rb = P.rec_b + sb[j] * (rec_bytes / 2);
             uint32_t wa;
+            // b's record: its own, or -- a leaf of a block whose leaves all sit in sibling pairs -- the pair's cherry record
+            // (tree_prep.h: rec_c, a table half the size of rec_b): the portal then comes from the block table
+            uint32_t cherry_portal = 0xFFFFFFFFu;
             if (A4) {
                 s[j] = P.rec_a4[sa[j]];
-                wa = sa[j] < P.n_leaves ? (uint32_t)BLK[sa[j] >> P.leaf_block_shift] : 0xFFFFu;
-                if (wa == 0xFFFFu) wa = reinterpret_cast<const uint32_t *>(P.rec_a)[2 * sa[j]];      // rare
+                wa = sa[j] < P.n_leaves ? (uint32_t)BLK[sa[j] >> P.leaf_block_shift] : (uint32_t)kLeafBlockMixed;
+                if (wa == kLeafBlockMixed) wa = reinterpret_cast<const uint32_t *>(P.rec_a)[2 * sa[j]];      // rare
+                else wa &= kLeafBlockPortalMask;
+                if (P.rec_c) {
+                    const uint32_t eb = sb[j] < P.n_leaves ? (uint32_t)BLK[sb[j] >> P.leaf_block_shift] : (uint32_t)kLeafBlockMixed;
+                    if (eb != kLeafBlockMixed && (eb & kLeafBlockCherries)) {
+                        cherry_portal = eb & kLeafBlockPortalMask;
+                        rb = P.rec_c + (sb[j] >> 1) * (rec_bytes / 2);
+                    }
+                }
             } else {
                 const uint2 va = reinterpret_cast<const uint2 *>(P.rec_a)[sa[j]];
                 wa = va.x;
@@ -370,6 +382,10 @@ __global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) voi
                 const uint2 q = *reinterpret_cast<const uint2 *>(rb);
                 wb = q.x;
                 Db[j][0] = __uint_as_float(q.y);
+                if (A4 && cherry_portal != 0xFFFFFFFFu) {      // {first leaf's length, second leaf's}
+                    Db[j][0] = __uint_as_float((sb[j] & 1) ? q.y : q.x);
+                    wb = cherry_portal | (1u << 16);
+                }
             } else {
                 uint32_t w[CAP + 1];
                 // the first 128-byte line of the chain at once; of a 63-slot chain's second line only the 16-byte
@@ -390,6 +406,10 @@ __global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) voi
                 }
 #pragma unroll
                 for (int q = 0; q < CAP; q++) Db[j][q] = __uint_as_float(w[q + 1]);
+                if (A4 && cherry_portal != 0xFFFFFFFFu) {      // {first leaf's length, second leaf's, slots 1 .. CAP-1}
+                    Db[j][0] = __uint_as_float((sb[j] & 1) ? w[1] : w[0]);
+                    wb = cherry_portal | ((uint32_t)CAP << 16);
+                }
             }
             u[j] = wa & 0xFFFFu;
             v[j] = wb & 0xFFFFu;

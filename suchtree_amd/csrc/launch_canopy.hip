@@ -134,6 +134,7 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
     P.rec_a = t->d_rec_a;
     P.rec_a4 = t->rec_a4 ? t->d_rec_a4 : nullptr;
     P.leaf_blocks = t->rec_a4 ? t->d_leaf_blocks : nullptr;
+    P.rec_c = (t->rec_a4 && t->cherries) ? t->d_rec_c : nullptr;
     P.leaf_block_shift = t->leaf_block_shift;
     P.leaf_block_count = t->leaf_block_count;
     P.rec_b = t->d_rec_b;

@@ -39,6 +39,8 @@ struct st_tree {
     uint8_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_i = nullptr;
     float *d_rec_a4 = nullptr;            // four-byte form of the a side (balanced-like trees), else NULL
     uint16_t *d_leaf_blocks = nullptr;
+    uint8_t *d_rec_c = nullptr;           // cherry records (one per pair of sibling leaves; tree_prep.h), else NULL
+    int cherries = 1;         // tuning: 0 = the predicated kernel reads every b record from rec_b even where cherry records exist
     int32_t leaf_block_shift = 0, leaf_block_count = 0;
     int rec_a4 = 1;           // tuning: 0 = the predicated canopy kernel reads the 8-byte rec_a entries even when the four-byte form exists
     uint8_t *d_rec_p = nullptr;       // lineage sums (deep canopies with a sparse table), else NULL

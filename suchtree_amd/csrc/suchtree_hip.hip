@@ -341,6 +341,7 @@ void st_tree_destroy(st_tree *t)
         (void)hipFree(t->d_rec_a);
         (void)hipFree(t->d_rec_a4);
         (void)hipFree(t->d_leaf_blocks);
+        (void)hipFree(t->d_rec_c);
         (void)hipFree(t->d_rec_b);
         (void)hipFree(t->d_rec_i);
         (void)hipFree(t->d_rec_p);
@@ -374,6 +375,7 @@ try {
     info->strategy = t->strategy;
     info->big_batch_kernel = big_batch_kernel_of(t);      // (follows the handle's current options)
     info->a_side_bytes = t->has_canopy ? ((t->rec_a4 && t->d_rec_a4 && t->d_leaf_blocks) ? 4 : 8) : 0;
+    info->b_table_bytes_per_leaf = t->has_canopy ? ((t->rec_a4 && t->cherries && t->d_rec_c && t->d_leaf_blocks) ? t->rec_bytes / 4 : t->rec_bytes / 2) : 0;
     info->host_wire_bytes_in = t->wire48 && t->n_nodes <= 0xFFFFFF ? 6 : 8;
     info->host_wire_bytes_out = t->wire24 && t->n_nodes <= 0xFFFFFF ? 7 : 8;
     return ST_OK;
@@ -424,6 +426,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "ladder_dynamic") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_dynamic must be 0 or 1");
         t->ladder_dynamic = (int)value;
+        return ST_OK;
+    }
+    if (std::strcmp(name, "cherries") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "cherries must be 0 or 1");
+        t->cherries = (int)value;
         return ST_OK;
     }
     if (std::strcmp(name, "batch_probe") == 0) {

@@ -418,6 +418,46 @@ bool prepare_leaf_blocks(TreeTables &T, int max_blocks)
     return true;
 }
 
+bool prepare_cherries(TreeTables &T)
+{
+    T.rec_c.clear();
+    if (T.leaf_block_portal.empty() || T.leaf_block_shift < 1 || !T.parity_layout || T.canopy_nodes > (int32_t)kLeafBlockPortalMask + 1 ||
+        T.record_cap < 1 || T.rec_b.empty())
+        return false;
+    const size_t half = (size_t)T.record_bytes / 2;      // bytes of one rec_b entry: word0 + cap chain slots
+    const int64_t cherries = (T.n_leaves + 1) / 2;
+    std::vector<uint8_t> ok((size_t)cherries, 0);
+    std::vector<uint8_t> rec_c((size_t)cherries * half, 0);
+    for (int64_t c = 0; c < cherries; c++) {
+        const int64_t s0 = 2 * c, s1 = 2 * c + 1;
+        if (s1 >= T.n_leaves) continue;
+        const int64_t x0 = record_node(s0, true, T.n_leaves), x1 = record_node(s1, true, T.n_leaves);
+        if (T.nodes[(size_t)x0].parent < 0 || T.nodes[(size_t)x0].parent != T.nodes[(size_t)x1].parent) continue;
+        const uint8_t *r0 = T.rec_b.data() + (size_t)s0 * half, *r1 = T.rec_b.data() + (size_t)s1 * half;
+        // same portal, same chain length, the same slots above the leaves' own (they are the parent's lineage)
+        if (std::memcmp(r0, r1, 4) != 0 || std::memcmp(r0 + 8, r1 + 8, half - 8) != 0) continue;
+        uint8_t *q = rec_c.data() + (size_t)c * half;
+        std::memcpy(q, r0 + 4, 4);                  // the first leaf's own length
+        std::memcpy(q + 4, r1 + 4, 4);              // the second leaf's
+        std::memcpy(q + 8, r0 + 8, half - 8);       // slots 1 .. cap-1
+        ok[(size_t)c] = 1;
+    }
+    const int32_t shift = T.leaf_block_shift;
+    int64_t covered = 0;
+    std::vector<uint16_t> table = T.leaf_block_portal;
+    for (size_t b = 0; b < table.size(); b++) {
+        if (table[b] == kLeafBlockMixed) continue;
+        const int64_t lo = (int64_t)b << shift, hi = std::min<int64_t>(T.n_leaves, ((int64_t)b + 1) << shift);
+        bool all = (lo & 1) == 0 && (hi & 1) == 0;      // (whole cherries only)
+        for (int64_t c = lo / 2; all && c < hi / 2; c++) all = ok[(size_t)c] != 0;
+        if (all) { table[b] |= kLeafBlockCherries; covered += hi - lo; }
+    }
+    if (covered * 100 < T.n_leaves * 99) return false;
+    T.leaf_block_portal = std::move(table);
+    T.rec_c = std::move(rec_c);
+    return true;
+}
+
 static void build_rmq64(TreeTables &T)
 {
     T.canopy_rmq64.resize(T.canopy_rmq.size());

@@ -140,6 +140,14 @@ struct TreeTables {
     std::vector<float> rec_a4;                 // [n] slot order, or empty
     std::vector<uint16_t> leaf_block_portal;   // [ceil(n_leaves >> leaf_block_shift)] or empty
     int32_t leaf_block_shift = 0;
+    // Cherry records (prepare_cherries; needs the block table): two sibling leaves share every edge of their understory
+    // chains but their own, so ONE record of rec_b's size serves both -- {length of the first leaf, length of the
+    // second, chain slots 1 .. cap-1 of either} -- and the b side of a leaf pair gathers from a table HALF the size of
+    // rec_b (the fabric serves random sectors of a smaller table faster, and more of it stays in L2).  rec_c[c] is the
+    // record of leaf slots 2c and 2c + 1; a block of the table above whose leaves all sit in such pairs has bit 15
+    // (kLeafBlockCherries) set beside its portal; other leaves, internal nodes and the shared-portal case read rec_b.
+    // Built when at least 99 % of the leaves sit in marked blocks (balanced and near-balanced trees).
+    std::vector<uint8_t> rec_c;                // [ceil(n_leaves / 2) * record_bytes/2] or empty
     std::vector<uint8_t> rec_b;         // [n * record_bytes/2]
     std::vector<uint8_t> rec_i;         // [n * record_bytes/2], or empty: left out under a table budget (pairs that share a
                                         // portal are then walked on the tree itself: kernels_canopy.h::same_portal_by_walk)
@@ -225,6 +233,10 @@ bool prepare_basic(const int32_t *parent, const float *distance, int64_t n,
 // rec_a4 + leaf_block_portal (see TreeTables); false (tables left empty) when the tree has no canopy,
 // no leaves-first layout, or too few leaves in portal-uniform blocks of at most max_blocks blocks.
 bool prepare_leaf_blocks(TreeTables &T, int max_blocks = 8192);
+
+// rec_c and the cherry bits of leaf_block_portal (see TreeTables); false (rec_c left empty, no bit set) otherwise.
+constexpr uint16_t kLeafBlockCherries = 0x8000u, kLeafBlockPortalMask = 0x3FFFu, kLeafBlockMixed = 0xFFFFu;
+bool prepare_cherries(TreeTables &T);
 
 // rec_r and canopy_rmq64 (see TreeTables) for trees with a canopy and in-order ids; false otherwise.
 bool prepare_rank_table(TreeTables &T);

@@ -60,6 +60,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
         canopy = prepare_canopy(parent, distance, T);
         if (!canopy) { g_err = "canopy not admitted"; return 2; }
         leaf_blocks = prepare_leaf_blocks(T, 8192) || prepare_leaf_blocks(T, 1 << 30);   // (the second form: one leaf per block, always uniform)
+        if (leaf_blocks) (void)prepare_cherries(T);
         lineage = prepare_lineage_sums(T, (int64_t)1 << 27);   // (in-order ids only)
         ranks = prepare_rank_table(T);                         // (in-order ids only)
     }
@@ -142,7 +143,21 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                 if (std::memcmp(&T.rec_a4[(size_t)sa], &pbot_a, 4) != 0) { g_err = "rec_a4 disagrees with rec_a"; return 14; }
                 if (sa < T.n_leaves) {
                     const uint16_t e = T.leaf_block_portal[(size_t)(sa >> T.leaf_block_shift)];
-                    if (e != 0xFFFFu && e != (wa & 0xFFFFu)) { g_err = "leaf block table names another portal"; return 15; }
+                    if (e != kLeafBlockMixed && (uint32_t)(e & kLeafBlockPortalMask) != (wa & 0xFFFFu)) { g_err = "leaf block table names another portal"; return 15; }
+                }
+                // the cherry record of b (a leaf of a block of sibling pairs): the same chain as rec_b's, the portal from the block table
+                if (!T.rec_c.empty() && sb < T.n_leaves) {
+                    const uint16_t e = T.leaf_block_portal[(size_t)(sb >> T.leaf_block_shift)];
+                    if (e != kLeafBlockMixed && (e & kLeafBlockCherries)) {
+                        const size_t half = (size_t)T.record_bytes / 2;
+                        const uint8_t *q = T.rec_c.data() + (size_t)(sb >> 1) * half;
+                        std::vector<uint8_t> rebuilt(half);
+                        const uint32_t w0 = (uint32_t)(e & kLeafBlockPortalMask) | (B.nb << 16);
+                        std::memcpy(rebuilt.data(), &w0, 4);
+                        std::memcpy(rebuilt.data() + 4, q + ((sb & 1) ? 4 : 0), 4);
+                        if (half > 8) std::memcpy(rebuilt.data() + 8, q + 8, half - 8);
+                        if (std::memcmp(rebuilt.data(), T.rec_b.data() + (size_t)sb * half, half) != 0) { g_err = "cherry record disagrees with rec_b"; return 22; }
+                    }
                 }
             }
             if (ranks && A.portal != B.portal) {     // the MRCA-only kernel's form: two rank reads, two table entries

@@ -364,16 +364,22 @@ def test_four_byte_a_side_of_the_predicated_kernel():
         t = torch.from_numpy(pairs).cuda()
         out_d = torch.empty(len(pairs), dtype=torch.float64, device="cuda")
         out_m = torch.empty(len(pairs), dtype=torch.int32, device="cuda")
-        for on in (1, 0):
+        for on, cherries in ((1, 1), (1, 0), (0, 1)):      # (cherries: b's record shared by two sibling leaves, where they exist)
             dev.set_option("rec_a4", on)
+            dev.set_option("cherries", cherries)
             dev.distances_device(t.data_ptr(), len(pairs), out_d.data_ptr(), out_m.data_ptr())
             dev.fault_check()
-            assert_bits_equal(out_d.cpu().numpy(), want_d, "rec_a4=%d" % on)
+            assert_bits_equal(out_d.cpu().numpy(), want_d, "rec_a4=%d cherries=%d" % (on, cherries))
             assert np.array_equal(out_m.cpu().numpy(), want_m)
             d, m = dev.distances_host(pairs.astype(np.int32), True, True)
             assert_bits_equal(d, want_d, "rec_a4=%d host int32" % on)
             assert np.array_equal(m, want_m)
         dev.close()
+    # where the cherry records are built: the balanced tree (every leaf) and the complete tree (its two lowest levels mix)
+    for (parent, dist), expect in ((synth.balanced_tree(16), 8), (synth.complete_tree(50_000, seed=2), None), (synth.random_binary_tree(40_000, seed=9), 32)):
+        info = _capi.DeviceTree(parent, dist).info()
+        if expect is not None:
+            assert info["b_table_bytes_per_leaf"] == expect, info      # (record_bytes / 4 with cherries, / 2 without)
 
 
 def test_special_float_values():
