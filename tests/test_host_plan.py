@@ -161,3 +161,17 @@ def test_table_budget_plan_drops_tables_in_the_stated_order(ml_arrays):
     # the walk family asked for: nothing of the canopy family is "dropped", the optional walk tables are
     plan = _capi.host_table_plan(parent, dist, strategy="walk", table_mb=4)
     assert plan["family"] == "walk" and "canopy" not in plan["dropped_tables"] and plan["device_bytes"] <= 4 * 2**20
+
+
+def test_deepest_ladder_image_leaves_room_for_the_kernels_flags():
+    """The scalar ladder kernel's LDS is the image (16 bytes per canopy node) plus 32 bytes of flags; a deep canopy is rebuilt
+    with at most kDeepCanopyNodes nodes, and that many must fit the 160 KiB of a CU (round 4's advisor: 10240 nodes asked for
+    163872 bytes and the launch failed).  The library asserts it at compile time; this reads the constants back."""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "suchtree_amd", "csrc")
+    nodes = int(re.search(r"constexpr int kDeepCanopyNodes = (\d+);", open(os.path.join(csrc, "host_path.h")).read()).group(1))
+    geo = open(os.path.join(csrc, "launch_geometry.h")).read()
+    flags = int(re.search(r"constexpr size_t kLadderFlagBytes = (\d+);", geo).group(1))
+    assert "kLdsBytesPerCu = 160 * 1024" in geo and "static_assert(st::ladder_kernel_lds_bytes(kDeepCanopyNodes) <= st::kLdsBytesPerCu" in open(os.path.join(csrc, "host_path.h")).read()
+    assert nodes * 16 + flags <= 160 * 1024 < (nodes + 2) * 16 + flags
+    assert "ladder_kernel_lds_bytes(t->canopy_nodes) <= kLdsBytesPerCu" in open(os.path.join(csrc, "launch_policy.h")).read()
