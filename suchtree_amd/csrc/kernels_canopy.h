@@ -200,9 +200,13 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
 // reads and two table reads, all cache resident), so both sides climb towards a known node, three edges per
 // 16-byte LDS read (pair_math.h: ladder_climb_to -- read, compare, three adds): max k_a / 3 + max k_b / 3 dependent
 // LDS reads per wave where the predicated kernel's depth cut takes max(k_a, k_b) + max k_b rounds of two reads each.
-// Without the table: the lock-step search on the ladder.  What binds it: on ml.tree the LDS pipe (83 % busy); a wave
-// takes as long as the longest of its 64 climbs -- two pairs per lane, climbs dealt again among the workgroup's lanes
-// and a software pipeline over the passes were all measured slower or even (profiles/ladder_*_r04.log).
+// Without the table: the lock-step search on the ladder.  What binds it (round 5, profiles/ladder_ablation_r05.log): the
+// kernel is balanced -- on nj.tree its memory side alone (ids, records, ranks, two sparse-table entries: 5.7 reads that
+// miss L1 per pair) takes 0.41 of the 0.50 ms per 1e7 pairs, its climbs about as long, and a CU's 16 or 32 waves overlap
+// the two.  Forms that shrank one side only were bit-exact and no faster: two pairs per lane, climbs dealt again among
+// the workgroup's lanes, a software pipeline over the passes (profiles/ladder_*_r04.log); lane-granular refill, K climbs
+// per lane in lock step, fewer lookups, fewer dependent round trips, a block form of the meeting-node query
+// (profiles/ladder_refill_r05.log, ladder_ablation_r05.log).
 // (launch bounds: two 1024-lane workgroups per CU = 8 waves per SIMD need at most 64 VGPRs AND at most 80 SGPRs --
 // the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD -- so the short-record form, whose
 // ladder image can leave room for two workgroups (ml.tree: 74 KiB), is compiled for 8; at 92 SGPRs it ran one
