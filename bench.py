@@ -203,6 +203,8 @@ def cpu_baseline(parent, dist, pairs_host, gpu_dist, gpu_mrca, seconds):
     max_rel = float(np.max(np.abs(d - gpu_dist[:n]) / np.maximum(np.abs(d), 1e-300))) if n else 0.0
     return {
         "value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        # cores = the threads used = this process's affinity mask (a launcher may narrow it per rank); the host has host_cpus
+        "host_cpus": os.cpu_count(),
         "sample": "first %d pairs of the batch, oracle/suchtree_oracle.c (visited-list MRCA, 20-byte AoS), "
                   "%d pthreads on contiguous chunks" % (n, cores),
         "single_thread_value": rate_1,
@@ -354,9 +356,7 @@ class HipBackend:
         if not args.no_microbench:
             # the tables the kernel gathers from, for leaf pairs: rec_b (half a record per leaf) and rec_a4 (4 B) or
             # rec_a (8 B); walk family: node records + lineage blocks are not modelled (12 B per node as a floor)
-            a_bytes = info.get("a_side_bytes") or 8
-            b_bytes = info.get("b_table_bytes_per_leaf") or info["record_bytes"] // 2      # (cherry records: half of rec_b)
-            foot = self.n_leaves * (a_bytes + b_bytes) if info["strategy"] == "canopy" else info["n_nodes"] * 12
+            foot = gather_footprint_bytes(info, self.n_leaves)
             hw = bench_legs.hardware_ceilings(self.local_rank, foot)
             if hw:
                 line["hardware_measured"] = hw
@@ -406,7 +406,8 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
     # strong scaling: every rank generates the SAME batch (same seed) and owns a slice of it
     pairs = be.make_pairs(n, 3 + (rank if args.weak else 0))
     root_share, calib = None, None
-    if strong and world > 1 and args.root_share != "even" and args.gather == "root":
+    sweep = strong and world > 1 and not args.no_gather_sweep
+    if strong and world > 1 and args.root_share != "even" and (args.gather == "root" or sweep):
         if args.root_share == "auto":
             # untimed: this GPU's kernel rate on a prefix of the batch and the rate at which rank 0
             # receives from all peers at once (the gather's pattern); rank 0 decides, everyone agrees
@@ -414,7 +415,15 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
             root_share, link, k_rate = sharding.measure_root_share(
                 world, rank, k_rate, device=be.device, nbytes=getattr(be, "calibration_bytes", 64 << 20),
                 wire_bytes_per_pair=sharding.WIRE_BYTES_PLAIN if (args.wire_int32 or info["n_nodes"] > 0xFFFFFF) else sharding.WIRE_BYTES_PACKED)
-            calib = {"kernel_pairs_per_s": k_rate, "link_GBps_into_root_per_peer": link / 1e9}
+            wb = sharding.WIRE_BYTES_PLAIN if (args.wire_int32 or info["n_nodes"] > 0xFFFFFF) else sharding.WIRE_BYTES_PACKED
+            calib = {"kernel_pairs_per_s": k_rate, "link_GBps_into_root_per_peer": link / 1e9, "root_share": root_share,
+                     # DESIGN.md section 7's projection (60 GB/s per link into the root, this GPU's measured kernel rate) beside it
+                     "projected_root_share_at_60GBps_per_link": sharding.balanced_root_share(world, k_rate, 60e9, wb),
+                     "projected_speedup_at_60GBps_per_link": 1.0 / max(sharding.balanced_root_share(world, k_rate, 60e9, wb), 1e-9),
+                     "calibrated_speedup": 1.0 / max(root_share, 1e-9),
+                     "what": "untimed, before the timed region: this GPU's kernel rate on a 2e7-pair prefix and the rate at which rank 0 "
+                             "receives from all peers at once; root_share = the fraction of the batch for which rank 0's kernels end when "
+                             "the peers' transfers do; 1 / root_share bounds the root gather's speedup over one GPU"}
         else:
             root_share = float(args.root_share)
     # the gather's wire format: float32 + 24-bit MRCA id (7 bytes per pair) on trees of fewer than 2^24 nodes, packed by
@@ -491,12 +500,14 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
         be.fault_check()
 
     gather_modes = None
-    if strong and world > 1 and not args.no_gather_sweep:
+    if sweep:
         # After the timed region, a few steps of each of the other two gather modes, timed the same way (barrier, sync, max
         # over ranks), so that ONE run at N GPUs shows what the gather costs: kernels alone (none), every link at once
         # (allgather), everything into rank 0 (root).  Not part of `value`.
         gather_modes = {mode: {"ms_per_step": elapsed / args.steps * 1e3, "pairs_per_s": n * args.steps / elapsed, "steps": args.steps,
-                               "timed_region": True}}
+                               "timed_region": True, "kernel_ms_slowest_rank": kernel_ms_max,
+                               "gather_ms": max(0.0, elapsed / args.steps * 1e3 - kernel_ms_max),
+                               "root_share": (hi0 - lo0) / max(n, 1) if rank == 0 else None}}
         k = max(1, min(args.steps, 5))
         for other in ("root", "allgather", "none"):
             if other == mode:
@@ -518,6 +529,7 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
 
                 o_step()
                 be.synchronize()
+                be.kernel_clock_reset()
                 barrier()
                 be.synchronize()
                 t0 = time.perf_counter()
@@ -525,11 +537,16 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
                     o_step()
                 be.synchronize()
                 barrier()
-                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=be.device)
+                dt = torch.tensor([time.perf_counter() - t0, be.kernel_ms_total() / k], dtype=torch.float64, device=be.device)
                 dg.all_reduce(dt, op=dg.ReduceOp.MAX)
                 be.fault_check()
-                gather_modes[other] = {"ms_per_step": float(dt[0].item()) / k * 1e3, "pairs_per_s": n * k / float(dt[0].item()), "steps": k,
-                                       "timed_region": False}
+                o_ms = float(dt[0].item()) / k * 1e3
+                # kernel_ms_slowest_rank: kernels alone (HIP events on the launch stream, max over ranks); gather_ms: what the
+                # mode's transfers add on top after overlap -- one run per N separates kernel scaling from link limits
+                gather_modes[other] = {"ms_per_step": o_ms, "pairs_per_s": n * k / float(dt[0].item()), "steps": k,
+                                       "timed_region": False, "kernel_ms_slowest_rank": float(dt[1].item()),
+                                       "gather_ms": max(0.0, o_ms - float(dt[1].item())),
+                                       "root_share": (o_hi - o_lo) / max(n, 1) if rank == 0 else None}
                 del o_d, o_m, o_wd, o_wm, o_own
 
     line = None
@@ -544,8 +561,13 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
         del h
         checksum = float(out_d.sum().item())
         traffic, traffic_file = latest_traffic()
+        # the roofline block speaks for the SLOWEST rank's kernels (the rank that bounds the step), not for rank 0's own
+        slow = None
+        if per_rank and world > 1:
+            r = int(np.argmax(per_rank["kernel_ms"]))
+            slow = {"rank": r, "kernel_ms": per_rank["kernel_ms"][r], "pairs": per_rank["pairs"][r]}
         line = build_line(args, world, plan, info, len(parent), elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
-                          pairs_this_rank, calib, traffic, traffic_file, wire_bytes, mode)
+                          pairs_this_rank, calib, traffic, traffic_file, wire_bytes, mode, slow=slow)
         if dg is not None:
             line["process_group"] = {"backend": str(dg.get_backend()), "world_size": int(dg.get_world_size()),
                                      "what": "as torch.distributed reports them for the group the step ran on (nccl = RCCL on ROCm)"}
@@ -554,6 +576,8 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
         if gather_modes:
             line["gather_modes"] = gather_modes
         roof = line["roofline"]
+        if "traffic_not_used" in roof:      # (the side figures must not borrow another configuration's counters either)
+            traffic = None
         if hasattr(be, "extra_legs"):
             be.extra_legs(args, line, roof, pairs, out_d, out_m, traffic, traffic_file, pairs_this_rank, kernel_ms)
         if strong and world > 1:
@@ -574,18 +598,48 @@ def run_job(args, be, dg, world, rank, parent, dist, peers_wait=None):
     return line
 
 
+def gather_footprint_bytes(info, n_leaves):
+    """The tables the kernel gathers from, for leaf pairs: rec_b or the cherry records (half a record per leaf, or a quarter) and
+    rec_a4 (4 B) or rec_a (8 B); walk family: node records + lineage blocks are not modelled (12 B per node as a floor)."""
+    a_bytes = info.get("a_side_bytes") or 8
+    b_bytes = info.get("b_table_bytes_per_leaf") or info["record_bytes"] // 2
+    return n_leaves * (a_bytes + b_bytes) if info["strategy"] == "canopy" else info["n_nodes"] * 12
+
+
+def traffic_speaks_for(traffic, args, info, world):
+    """A committed PMC summary is used for `roofline.achieved` only when it was taken on THIS configuration: the same tree
+    (levels, canopy, record size) and the same kernel.  Summaries since round 6 carry `config` (scripts/profile_gpu.sh);
+    older ones are accepted for the default tree only."""
+    if not traffic or not traffic.get("hbm_bytes_per_launch") or not traffic.get("pairs_per_launch"):
+        return False, "no committed PMC summary"
+    if info["strategy"] != "canopy" or "k_canopy_ilp" not in str(traffic.get("kernel_full_name", "")):
+        return False, "the committed summary is of %s, this run's kernel family is %s" % (traffic.get("kernel_full_name"), info["strategy"])
+    c = traffic.get("config")
+    if c is None:
+        ok = args.levels == 20
+        return ok, None if ok else "the committed summary carries no config and this is not the default tree"
+    for key, mine in (("levels", args.levels), ("canopy_nodes", info["canopy_nodes"]), ("record_bytes", info["record_bytes"])):
+        if key in c and int(c[key]) != int(mine):
+            return False, "the committed summary was taken with %s = %s, this run has %s" % (key, c[key], mine)
+    return True, None
+
+
 def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_max, h_mean, checksum,
-               pairs_this_rank, calib, traffic, traffic_file, wire_bytes=8, mode="root"):
-    """The contract's JSON line from the measured quantities (no measurement happens here)."""
+               pairs_this_rank, calib, traffic, traffic_file, wire_bytes=8, mode="root", slow=None):
+    """The contract's JSON line from the measured quantities (no measurement happens here).  `slow`: at N > 1 the
+    slowest rank's {rank, kernel_ms, pairs}: the roofline block is computed from ITS kernel time."""
     n = args.pairs
+    roof_pairs, roof_ms, roof_rank = pairs_this_rank, kernel_ms, 0
+    if slow and slow.get("kernel_ms") and slow.get("pairs"):
+        roof_pairs, roof_ms, roof_rank = int(slow["pairs"]), float(slow["kernel_ms"]), int(slow["rank"])
     strong = not args.weak
     bytes_per_pair = 16 + 8 + 4 + 8 * h_mean
     n_job = n * (world if args.weak else 1)
     value = float(n_job) * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    achieved = bytes_per_pair * pairs_this_rank / (kernel_ms * 1e-3) / 1e9
+    achieved = bytes_per_pair * roof_pairs / (roof_ms * 1e-3) / 1e9
     kernel_name = {"canopy": "k_canopy_ilp", "walk": "k_walk"}.get(info["strategy"], info["strategy"])
-    rate = pairs_this_rank / (kernel_ms * 1e-3)      # this rank's pairs per second of kernel time (HIP events on the launch stream)
+    rate = roof_pairs / (roof_ms * 1e-3)      # the (slowest) rank's pairs per second of kernel time (HIP events on the launch stream)
     # bytes the kernel has to request from the fabric per pair when no record is cache resident: the coalesced
     # streams plus one 64-byte sector per record read
     required = 16 + 12 + 2 * 64
@@ -595,12 +649,18 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     # stay beside it in `algorithmic`: the canopy kernel climbs in LDS and reads pre-summed understories, so it does not
     # move them and that fraction exceeds 1 -- it is not a bandwidth claim.
     roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
-            "kernel": kernel_name, "kernel_ms": kernel_ms, "pairs_per_launch": pairs_this_rank // plan.chunks,
+            "kernel": kernel_name, "kernel_ms": roof_ms, "pairs_per_launch": roof_pairs // plan.chunks,
             "launches_per_step": plan.chunks}
+    if world > 1:
+        roof["rank"] = roof_rank
+        roof["rank_is"] = "the rank with the longest kernel time per step (it bounds the step); kernel_ms and pairs are its own"
     per_pair = None
-    if traffic and traffic.get("hbm_bytes_per_launch") and traffic.get("pairs_per_launch"):
+    speaks, why_not = traffic_speaks_for(traffic, args, info, world)
+    if not speaks:
+        roof["traffic_not_used"] = why_not
+    if speaks:
         per_pair = traffic["hbm_bytes_per_launch"] / traffic["pairs_per_launch"]
-        roof["traffic"] = per_pair * (pairs_this_rank / plan.chunks)
+        roof["traffic"] = per_pair * (roof_pairs / plan.chunks)
         roof["traffic_bytes_per_pair"] = per_pair
         roof["traffic_source"] = traffic_file
         c = traffic.get("counters_mean_per_launch", {})
@@ -620,7 +680,8 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     roof["frac"] = roof["achieved"] / HBM_PEAK_GBPS
     roof["achieved_is"] = ("fabric bytes per pair by counters (%s: read requests x calibrated bytes per request + WRITE_SIZE) x this "
                            "run's pairs per second of kernel time" % traffic_file) if per_pair is not None else \
-                          "no committed PMC pass: the bytes the kernel must request per pair (16 in + 12 out + two 64-byte record sectors)"
+                          ("no committed PMC pass of this configuration (%s): the bytes the kernel must request per pair (16 in + 12 out + "
+                           "two 64-byte record sectors)" % why_not)
     alg_frac = achieved / HBM_PEAK_GBPS
     roof["algorithmic"] = {"bytes_per_pair": bytes_per_pair, "mean_path_edges": h_mean, "GBps": achieved, "frac_of_hbm_peak": alg_frac,
                            "exceeds_peak": bool(alg_frac > 1.0),
@@ -636,10 +697,11 @@ def build_line(args, world, plan, info, n_nodes, elapsed, kernel_ms, kernel_ms_m
     if sweep:
         roof["hbm_regime"] = sweep
     roof["note"] = ("bound hbm: achieved / peak / frac = fabric bytes the kernel moves per second (counters) against the 8 TB/s HBM3E peak. "
-                    "At this tree's 36 MiB gather footprint most record sectors are served by the 256 MiB Infinity Cache, which the "
+                    "At this tree's %.0f MiB gather footprint most record sectors are served by the 256 MiB Infinity Cache, which the "
                     "TCC_EA counters include; hbm_regime shows the same kernel family on trees whose records exceed it. "
                     "secondary_ceiling (added when the in-process microbenchmark ran): fabric read requests per second against the "
-                    "random-64-byte-sector rate at the kernel's footprint -- what actually limits a gather kernel below the byte peak.")
+                    "random-64-byte-sector rate at the kernel's footprint -- what actually limits a gather kernel below the byte peak."
+                    % (gather_footprint_bytes(info, 1 << args.levels) / 2**20))
     if info["strategy"] == "canopy":
         # SURVEY 8d asks for the achieved occupancy next to the fraction: the canopy kernels run one 1024-lane
         # workgroup per CU when the LDS image exceeds 80 KiB (two below that)

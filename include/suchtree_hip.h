@@ -33,6 +33,17 @@
 extern "C" {
 #endif
 
+/*
+ * ABI version: bumped whenever an exported struct grows, or an export, option or constant goes away.  A caller built against
+ * an older header must not be handed a larger st_tree_info: compare ST_API_VERSION with st_api_version() at load (the ctypes
+ * binding does) and use st_tree_info_get_sized, which writes at most the bytes the caller says it has.
+ *   6 (round 6): st_api_version, st_tree_info_get_sized added.
+ *   5 (round 5): st_tree_info grew by 8 bytes (b_table_bytes_per_leaf, reserved0); st_host_alloc / st_host_free,
+ *                ST_KERNEL_CANOPY_SCALAR, the options pairs_per_lane and ladder_dynamic = 2 removed.
+ */
+#define ST_API_VERSION 6
+int st_api_version(void);
+
 #define ST_OK          0
 #define ST_ERR_ARG     1   /* bad argument (NULL, negative size, bad strategy) */
 #define ST_ERR_HIP     2   /* a HIP runtime call failed / no usable GPU */
@@ -160,7 +171,11 @@ int st_host_chunk_owner(int64_t n, int n_devices, int64_t chunk_index, int *devi
 /* Replaces SuchTree.__dealloc__ (MuchTree.pyx:230-232). */
 void st_tree_destroy(st_tree *tree);
 
+/* Fills *info (sizeof(st_tree_info) bytes of THIS header's struct: callers compiled against it only). */
 int st_tree_info_get(const st_tree *tree, st_tree_info *info);
+/* The same for a caller that states how large ITS st_tree_info is: at most info_bytes bytes are written (fields are only ever
+ * appended, so a shorter struct is a prefix); info_bytes < 8 or not a multiple of 4 is ST_ERR_ARG. */
+int st_tree_info_get_sized(const st_tree *tree, void *info, int64_t info_bytes);
 
 /*
  * Bulk distances (+ MRCA ids) for host-resident pairs.  Replaces
@@ -221,6 +236,13 @@ int st_unpack_mrca24_device(int device, const uint8_t *d_packed, int64_t n, int3
  * as for st_distances_host.
  */
 int st_fault_check(st_tree *tree, void *stream, int64_t *bad_id);
+
+/*
+ * Diagnostic: which kernel the batch probe gave the handle's most recent probed batch (large device-resident batches of
+ * explicit pairs on deep trees decide per batch, on the device: option batch_probe).  Synchronises `stream`.
+ * *choice = 0 scalar ladder kernel, 1 tile-sorted walk kernel, -1 no batch of this handle has been probed yet.
+ */
+int st_probe_last_choice(st_tree *tree, void *stream, int *choice);
 
 /*
  * All-pairs generator: for an id list ids[0..m) (element stride id_stride) computes

@@ -55,6 +55,8 @@ def main():
     out_dir, tag = sys.argv[1], sys.argv[2]
     kernel = sys.argv[3] if len(sys.argv) > 3 else "k_canopy"
     pairs_per_launch = float(sys.argv[4]) if len(sys.argv) > 4 else 1e8
+    # bytes of coalesced input stream per pair: 16 (int64 ids), 0 for pairs generated on the device (triangle)
+    stream_bytes_per_pair = float(os.environ.get("STREAM_BYTES_PER_PAIR", "16"))
     prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(prof, exist_ok=True)
     lines = []
@@ -65,7 +67,17 @@ def main():
         for r in stats:
             lines.append(",".join(str(r[c]) for c in cols))
     dur = per_kernel_durations(os.path.join(out_dir, "trace"))
-    summary = {"tag": tag, "kernel": kernel, "kernels": {}, "pairs_per_launch": pairs_per_launch}
+    summary = {"tag": tag, "kernel": kernel, "kernels": {}, "pairs_per_launch": pairs_per_launch,
+               "stream_bytes_per_pair": stream_bytes_per_pair}
+    try:      # bench.py's own line in the trace pass's log says what was launched
+        line = [l for l in open(os.path.join(out_dir, "trace.log")).read().splitlines() if l.lstrip().startswith('{"metric"')][-1]
+        cfg = json.loads(line)["config"]
+        summary["config"] = {"levels": cfg.get("tree_levels"), "canopy_nodes": cfg.get("canopy_nodes"), "record_bytes": cfg.get("record_bytes"),
+                             "pairs_per_step": cfg.get("pairs_per_step"), "kernel_family": cfg.get("kernel_family")}
+    except Exception:      # noqa: BLE001 -- not a bench.py run (scripts/tune_gpu.py legs)
+        pass
+    if os.environ.get("PROFILE_CONFIG"):      # what was launched (bench.py uses the counters only for a run of the same configuration)
+        summary["config"] = json.loads(os.environ["PROFILE_CONFIG"])
     for k, v in dur.items():
         v2 = sorted(v)
         summary["kernels"][k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "min_ns": v2[0], "max_ns": v2[-1]}
@@ -118,7 +130,7 @@ def main():
         # requests of the calibrated stream size (128 B on gfx950); every other read request is
         # a single 64-byte sector of a record table; writes are coalesced streams (WRITE_SIZE exact)
         stream_req_bytes = cal.get("stream_bytes_per_read_request", 128.0)
-        stream_requests = 16.0 * pairs / stream_req_bytes
+        stream_requests = stream_bytes_per_pair * pairs / stream_req_bytes
         record_requests = max(0.0, counters["TCC_EA0_RDREQ_sum"] - stream_requests)
         summary["hbm_bytes_per_launch"] = stream_requests * stream_req_bytes + record_requests * 64.0 + counters["WRITE_SIZE"] * 1024.0
         summary["traffic_model"] = {"stream_read_requests": stream_requests, "stream_bytes_per_request": stream_req_bytes,

@@ -24,11 +24,16 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--opt", action="append", default=[], help="name=v1,v2,...")
     ap.add_argument("--strategy", default="canopy")
+    ap.add_argument("--triangle", type=int, default=0,
+                    help="M: pairs generated on the device, a --pairs tile from the middle of the lower triangle of the complete M-leaf tree (seed 44)")
     args = ap.parse_args()
     import torch
     from suchtree_amd import _capi, synth
     dev = torch.device("cuda", 0)
-    if args.tree == "balanced":
+    if args.triangle:
+        parent, dist = synth.complete_tree(args.triangle, seed=44)
+        leaf_ids = np.arange(0, 2 * args.triangle, 2)
+    elif args.tree == "balanced":
         parent, dist = synth.balanced_tree(args.levels)
         leaf_ids = np.arange(0, len(parent), 2)
     elif args.tree == "caterpillar":       # deep, small canopy: 2^levels leaves on one ladder
@@ -57,7 +62,8 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     li = torch.from_numpy(np.ascontiguousarray(leaf_ids)).to(dev)
-    pairs = li[torch.randint(0, len(leaf_ids), (n, 2), generator=g, device=dev)]
+    pairs = li[torch.randint(0, len(leaf_ids), (n, 2), generator=g, device=dev)] if not args.triangle else None
+    k_mid = (args.triangle * (args.triangle - 1) // 2) // 2
     out_d = torch.empty(n, dtype=torch.float64, device=dev)
     out_m = torch.empty(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -73,7 +79,10 @@ def main():
                 tree.set_option(k, v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            tree.distances_device(pairs.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
+            if args.triangle:
+                tree.triangle_device(li.data_ptr(), args.triangle, k_mid, n, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
+            else:
+                tree.distances_device(pairs.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
             e1.record(stream)
             torch.cuda.synchronize()
             if r == 0:

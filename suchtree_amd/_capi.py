@@ -32,11 +32,13 @@ class TreeOptions(ctypes.Structure):
     _fields_ = [("table_budget_bytes", ctypes.c_int64), ("reserved", ctypes.c_int64 * 7)]
 
 
+API_VERSION = 6      # include/suchtree_hip.h: ST_API_VERSION
+
 # every symbol include/suchtree_hip.h declares (tests check the .so exports them all)
 SYMBOLS = (
-    "st_last_error", "st_device_count", "st_tree_create", "st_tree_create_multi", "st_tree_create_ex", "st_host_table_plan", "st_tree_devices",
+    "st_api_version", "st_tree_info_get_sized", "st_last_error", "st_device_count", "st_tree_create", "st_tree_create_multi", "st_tree_create_ex", "st_host_table_plan", "st_tree_devices",
     "st_host_chunk_plan", "st_host_chunk_owner", "st_tree_destroy", "st_tree_info_get",
-    "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_distances_device_wire", "st_unpack_mrca24_device", "st_fault_check", "st_tree_set_strategy",
+    "st_distances_host", "st_distances_host_i32", "st_distances_device", "st_distances_device_f32", "st_distances_device_wire", "st_unpack_mrca24_device", "st_fault_check", "st_probe_last_choice", "st_tree_set_strategy",
     "st_tree_set_option", "st_triangle_device", "st_triangle_host", "st_grid_host", "st_knn_host",
     "st_quartets_host", "st_graph_matrices_host", "st_newick_open", "st_newick_fill", "st_newick_close",
     "st_host_depths", "st_link_sample_pairs", "st_bucket_moments", "st_device_malloc", "st_device_free", "st_memcpy_h2d", "st_memcpy_d2h",
@@ -175,6 +177,11 @@ def load():
         L.st_tree_destroy.argtypes = [vp]
         L.st_tree_destroy.restype = None
         L.st_tree_info_get.argtypes = [vp, ctypes.POINTER(TreeInfo)]
+        L.st_tree_info_get_sized.argtypes = [vp, vp, i64]
+        L.st_api_version.argtypes = []
+        if L.st_api_version() != API_VERSION:
+            raise HipBackendError("libsuchtree_hip.so speaks ABI version %d, this binding %d (include/suchtree_hip.h: ST_API_VERSION); "
+                                  "rebuild the library" % (L.st_api_version(), API_VERSION))
         L.st_distances_host.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_distances_host_i32.argtypes = [vp, vp, i64, i64, i64, vp, vp, ctypes.POINTER(i64)]
         L.st_distances_device.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
@@ -182,6 +189,7 @@ def load():
         L.st_distances_device_wire.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp]
         L.st_unpack_mrca24_device.argtypes = [i32, vp, i64, vp, vp]
         L.st_fault_check.argtypes = [vp, vp, ctypes.POINTER(i64)]
+        L.st_probe_last_choice.argtypes = [vp, vp, ctypes.POINTER(i32)]
         L.st_tree_set_strategy.argtypes = [vp, i32]
         L.st_tree_set_option.argtypes = [vp, ctypes.c_char_p, i64]
         L.st_triangle_device.argtypes = [vp, vp, i64, i64, i64, i64, vp, vp, vp]
@@ -500,7 +508,7 @@ class DeviceTree:
 
     def info(self):
         ti = TreeInfo()
-        check(self._lib.st_tree_info_get(self.handle, ctypes.byref(ti)))
+        check(self._lib.st_tree_info_get_sized(self.handle, ctypes.byref(ti), ctypes.sizeof(ti)))
         return ti.as_dict()
 
     def set_strategy(self, strategy):
@@ -649,6 +657,12 @@ class DeviceTree:
     def unpack_mrca24_device(self, d_packed, n, d_out_mrca, stream=0):
         check(self._lib.st_unpack_mrca24_device(int(self.devices[0]), ctypes.c_void_p(d_packed), int(n), ctypes.c_void_p(d_out_mrca),
                                                 ctypes.c_void_p(stream or None)))
+
+    def probe_last_choice(self, stream=0):
+        """0 / 1: the batch probe gave this handle's last probed batch to the scalar ladder / tile-sorted walk kernel; -1: none yet."""
+        c = ctypes.c_int32(-1)
+        check(self._lib.st_probe_last_choice(self.handle, ctypes.c_void_p(stream or None), ctypes.byref(c)))
+        return int(c.value)
 
     def fault_check(self, stream=0):
         bad = ctypes.c_int64(0)

@@ -230,6 +230,38 @@ __device__ __forceinline__ PairResult ladder_pair(const CanopyParams &P, const u
     return canopy_pair_finish<CAP, true>(P, lds_raw, L, sa, sb, rec_bytes, meet);
 }
 
+// The same pair with a's WHOLE side read from the lineage-sum table (tree_prep.h; round 6, the "joint form": the memory side
+// and the climb side shrink together).  rec_p of either node = {rank of its portal | its depth << 16, offset of its lineage
+// sums | record chunks << 28}: the meeting node (depth << 32 | node id) comes from the two ranks and the 64-bit sparse
+// table -- no rank, depth or canopy_id lookup (seven gathers of ladder_pair become two) --, a's side is ONE 4-byte read
+// (the reference's accumulator after a's edges up to the meeting node, bit for bit), b's record is read by the chunks that
+// hold chain slots in use, and only b's canopy edges are climbed in LDS: one climb per pair instead of two, so a wave waits
+// for the longest of 64 climbs once.  Same operands, same order as ladder_pair: the same bits.
+template <int CAP>
+__device__ __forceinline__ PairResult ladder_pair_sums(const CanopyParams &P, const unsigned char *lds_raw, long long a, long long b,
+                                                       bool parity, int rec_bytes)
+{
+    const long long sa = record_slot(a, parity, P.n_leaves), sb = record_slot(b, parity, P.n_leaves);
+    const uint2 va = reinterpret_cast<const uint2 *>(P.rec_p)[sa];
+    const uint2 vb = reinterpret_cast<const uint2 *>(P.rec_p)[sb];
+    const uint32_t ra = va.x & 0xFFFFu, rb = vb.x & 0xFFFFu;
+    const uint32_t l = ra < rb ? ra : rb, r = ra < rb ? rb : ra;
+    const uint32_t k = 31u - (uint32_t)__clz((int)(r - l + 1));      // floor(log2(len))
+    const uint64_t e1 = P.rmq64[(size_t)k * (size_t)P.canopy_nodes + l];
+    const uint64_t e2 = P.rmq64[(size_t)k * (size_t)P.canopy_nodes + (r + 1 - (1u << k))];
+    PairRecs<CAP> L;
+    L.rb = P.rec_b + sb * (rec_bytes / 2);
+    load_rec_b_chunks<CAP>(L, (vb.y >> 28) + 1);      // (a lane that does not load a chunk does not cost a cache lookup)
+    const uint64_t e = (e2 >> 32) < (e1 >> 32) ? e2 : e1;      // the meeting node (shared portal: the portal itself, every index below stays in range)
+    const uint32_t dm = (uint32_t)(e >> 32);
+    const float side = P.lineage[(size_t)(va.y & 0x0FFFFFFFu) + ((va.x >> 16) - dm)];
+    PairResult res;
+    res.dist = ladder_sum_b<CAP>(LdsLadder(lds_raw), (vb.x >> 16) - dm - (L.wb >> 16), side, L.wb & 0xFFFFu, L.chain(), L.wb >> 16);
+    res.mrca = (int32_t)(uint32_t)e;
+    if (ra == rb) res = canopy_pair_scalar<CAP, true>(P, lds_raw, sa, sb, rec_bytes);      // shared portal (rare): the general form
+    return res;
+}
+
 // `work`: NULL = pairs are dealt statically (workgroup b takes tiles b, b + G, ...), else eight counters (one per XCD,
 // zeroed before the launch) from which every WAVE draws chunks of kLadderChunk pairs: the kernel sorts nothing, a wave
 // is as slow as its longest lane, and with a static deal the launch ends when the unluckiest wave does.  XCD x owns
@@ -237,7 +269,7 @@ __device__ __forceinline__ PairResult ladder_pair(const CanopyParams &P, const u
 // eighth of the requests.  Pays where a pair is heavy (profiles/ladder_dynamic_r04.log, 1e7 pairs: 1e6 leaves at depth
 // 338, 1 KB records 8.45e9 -> 9.46e9 pairs/s; depth 173, 512-byte records 1.68 -> 1.77e10; nj.tree even; ml.tree
 // 2.73 -> 2.53e10: a draw's round trip is as long as its 128 pairs): launch_canopy.hip turns it on by record size.
-template <int CAP, typename Src>
+template <int CAP, typename Src, bool SUMS = false>
 __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_ladder(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, MrcaSink out_m, Fault *fault,
                                                                 unsigned long long *work, const int *choice)
@@ -258,6 +290,8 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
             src.load(i, a, b);
             if ((unsigned long long)a >= (unsigned long long)P.n_nodes || (unsigned long long)b >= (unsigned long long)P.n_nodes)
                 record_fault(fault, a, b, P.n_nodes);
+            else if constexpr (SUMS)
+                r = ladder_pair_sums<CAP>(P, lds_raw, a, b, parity, rec_bytes);
             else
                 r = ladder_pair<CAP>(P, lds_raw, a, b, parity, rec_bytes);
         }
@@ -310,7 +344,7 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
 // (launch bounds: short records on canopies of at most 80 KiB run two workgroups per CU = 8 waves per SIMD, which the
 // hardware only admits at <= 64 VGPRs and <= 80 SGPRs; see k_canopy_ladder)
 template <int CAP, int PPL, typename Src, bool A4 = false>
-__global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) void k_canopy_ilp(CanopyParams P, Src src, long long n,
+__global__ __launch_bounds__(kCanopyBlock, (((CAP <= 7 || (CAP == 15 && A4)) && PPL == 1) ? 8 : 4)) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              DistSink out_d,
                                                              MrcaSink out_m, Fault *fault)
 {
@@ -475,8 +509,8 @@ __global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) voi
                 const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
                 PairResult r;
                 if (!P.rec_i) r = same_portal_by_walk(P, sa[j], sb[j]);
-                else if constexpr (CAP <= 31) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
-                else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
+                else if constexpr (CAP <= 31 && !(CAP == 15 && A4)) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
+                else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));      // (CAP 15 with the 8-wave budget: the register form's 64 words do not fit)
                 s[j] = r.dist;
                 m[j] = r.mrca;
             }
@@ -506,7 +540,11 @@ __global__ __launch_bounds__(1024) void k_probe_shared_portal(const uint16_t *re
     const long long step = n / kProbePairs > 0 ? n / kProbePairs : 1;
     int mine = 0;
     for (int k = threadIdx.x; k < kProbePairs; k += blockDim.x) {
-        const long long i = (long long)k * step;
+        // one pair from every stretch of `step`, at a hashed offset inside it: a fixed stride aliases with batches of
+        // periodic structure (alternating near / far pairs with an even step would show only one kind)
+        uint32_t h = (uint32_t)k * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const long long i = (long long)k * step + (long long)((unsigned long long)h % (unsigned long long)step);
         if (i >= n) break;
         long long a, b;
         src.load(i, a, b);

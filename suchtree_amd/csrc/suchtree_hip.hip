@@ -381,6 +381,19 @@ try {
     return ST_OK;
 } ST_CATCH_ALL
 
+int st_api_version(void) { return ST_API_VERSION; }
+
+int st_tree_info_get_sized(const st_tree *t, void *info, int64_t info_bytes)
+try {
+    if (!t || !info) return fail(ST_ERR_ARG, "tree or info is NULL");
+    if (info_bytes < 8 || info_bytes % 4) return fail(ST_ERR_ARG, "info_bytes must be a multiple of 4, at least 8");
+    st_tree_info full;
+    const int rc = st_tree_info_get(t, &full);
+    if (rc != ST_OK) return rc;
+    std::memcpy(info, &full, (size_t)std::min<int64_t>(info_bytes, (int64_t)sizeof full));
+    return ST_OK;
+} ST_CATCH_ALL
+
 int st_tree_devices(const st_tree *t, int *devices, int capacity, int *n_devices)
 try {
     if (!t) return fail(ST_ERR_ARG, "tree is NULL");
@@ -514,6 +527,11 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
         t->lineage_sums = (int)value;
         return ST_OK;
     }
+    if (std::strcmp(name, "ladder_sums") == 0) {
+        if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_sums must be 0 or 1");
+        t->ladder_sums = (int)value;
+        return ST_OK;
+    }
     if (std::strcmp(name, "small_batch_path") == 0) {
         t->small_batch_path = value != 0;
         return ST_OK;
@@ -588,6 +606,18 @@ try {
     const int rc = fetch_fault(t->d_fault, reinterpret_cast<hipStream_t>(stream), f);
     if (rc != ST_OK) return rc;
     return report_fault(t->n_nodes, f, bad_id);
+} ST_CATCH_ALL
+
+int st_probe_last_choice(st_tree *t, void *stream, int *choice)
+try {
+    if (!t || !choice) return fail(ST_ERR_ARG, "tree or choice is NULL");
+    *choice = -1;
+    const unsigned issued = t->choice_next.load(std::memory_order_relaxed);
+    if (!t->d_choice || issued == 0) return ST_OK;
+    ST_DEVICE(t->device);
+    ST_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    ST_HIP(hipMemcpy(choice, t->d_choice + (issued - 1) % kWorkSlots, sizeof(int), hipMemcpyDeviceToHost));
+    return ST_OK;
 } ST_CATCH_ALL
 
 }  // extern "C"

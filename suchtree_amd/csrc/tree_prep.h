@@ -236,6 +236,8 @@ bool prepare_leaf_blocks(TreeTables &T, int max_blocks = 8192);
 
 // rec_c and the cherry bits of leaf_block_portal (see TreeTables); false (rec_c left empty, no bit set) otherwise.
 constexpr uint16_t kLeafBlockCherries = 0x8000u, kLeafBlockPortalMask = 0x3FFFu, kLeafBlockMixed = 0xFFFFu;
+static_assert(kMaxCanopyNodes <= (int)kLeafBlockPortalMask + 1,
+              "a block-table entry keeps its portal in 14 bits (k_canopy_ilp masks every entry with kLeafBlockPortalMask)");
 bool prepare_cherries(TreeTables &T);
 
 // rec_r and canopy_rmq64 (see TreeTables) for trees with a canopy and in-order ids; false otherwise.

@@ -35,6 +35,7 @@ class CpuBackend:
         self.rank = rank
         self.hang_rank = hang_rank
         self._ms = 0.0
+        self._resets = 0
         self.calls = []
 
     def info(self):
@@ -64,7 +65,9 @@ class CpuBackend:
 
     def kernel_clock_reset(self):
         self._ms = 0.0
-        self.calls.clear()
+        if not self._resets:      # (the warmup's calls go; the gather sweep's later resets keep the timed region's)
+            self.calls.clear()
+        self._resets += 1
 
     def kernel_ms_total(self):
         return self._ms
@@ -77,6 +80,11 @@ class CpuBackend:
 
     def kernel_rate(self, pairs, m):
         return 2.0e6 * (self.rank + 1)       # every rank a different figure: rank 0's must be the one used
+
+
+def ShardPlanShare(sharding, n, world, chunks, share):
+    lo, hi = sharding.ShardPlan(n, world, 0, chunks=chunks, root_share=share, align=4).bounds(0)
+    return (hi - lo) / n
 
 
 def _worker(rank, world, port, argv, q, hang_rank=None):
@@ -106,7 +114,8 @@ def _run(world, argv, hang_rank=None, timeout=180):
 
 
 @pytest.mark.parametrize("world,share,chunks,n,wire", [(2, "auto", 4, 30011, 7), (3, "auto", 4, 30011, 7), (4, "even", 1, 1003, 7),
-                                                        (4, "0.5", 3, 30011, 8), (3, "0.9", 2, 7, 7), (2, "auto", 3, 30013, 8)])
+                                                        (4, "0.5", 3, 30011, 8), (3, "0.9", 2, 7, 7), (2, "auto", 3, 30013, 8),
+                                                        (8, "auto", 2, 30011, 7)])
 def test_bench_job_line_on_gloo(world, share, chunks, n, wire):
     """wire = 7: float32 + 24-bit MRCA ids travel (packed by the compute step, unpacked on the root piece by piece);
     8: --wire-int32."""
@@ -131,11 +140,25 @@ def test_bench_job_line_on_gloo(world, share, chunks, n, wire):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches_per_step"] == chunks
+    # at N > 1 the block speaks for the slowest rank's kernels: its kernel time and its pairs
+    slow = int(np.argmax(d["per_rank"]["kernel_ms"]))
+    assert r["rank"] == slow and r["kernel_ms"] == d["per_rank"]["kernel_ms"][slow]
+    assert r["pairs_per_launch"] == d["per_rank"]["pairs"][slow] // chunks
+    assert d["cpu_baseline"]["host_cpus"] >= d["cpu_baseline"]["cores"]
+    gm = d["gather_modes"]
+    assert set(gm) == {"root", "allgather", "none"}
+    for v in gm.values():      # one run separates kernel scaling from link limits: kernels alone and what each mode's transfers add
+        assert v["kernel_ms_slowest_rank"] > 0 and v["gather_ms"] >= 0 and 0 < v["root_share"] <= 1
+    assert abs(gm["root"]["root_share"] - d["root_share"]) < 1e-12
     # every rank computed exactly its slice, in `chunks` pieces per step, for the 2 timed steps
     if share == "auto":
         cal = d["root_share_calibration"]
         assert cal["kernel_pairs_per_s"] == 2.0e6 and cal["link_GBps_into_root_per_peer"] > 0
+        assert abs(cal["projected_root_share_at_60GBps_per_link"] - sharding.balanced_root_share(world, 2.0e6, 60e9, wire)) < 1e-12
+        assert abs(cal["calibrated_speedup"] * cal["root_share"] - 1.0) < 1e-9
         expect = min(0.95, max(1.0 / world, sharding.balanced_root_share(world, 2.0e6, cal["link_GBps_into_root_per_peer"] * 1e9, wire)))
+        assert abs(expect - cal["root_share"]) < 1e-9      # (the line's own figure is used below: GB/s and back costs the last bit)
+        expect = cal["root_share"]
     else:
         expect = None if share == "even" else float(share)
     covered = []
@@ -153,7 +176,8 @@ def test_bench_job_line_on_gloo(world, share, chunks, n, wire):
 
 
 @pytest.mark.parametrize("world,mode,chunks,n,wire", [(2, "allgather", 3, 30011, 7), (3, "allgather", 4, 30013, 8), (4, "allgather", 1, 1003, 7),
-                                                     (2, "none", 2, 30011, 7), (3, "none", 1, 30013, 7), (4, "none", 4, 1003, 8)])
+                                                     (2, "none", 2, 30011, 7), (3, "none", 1, 30013, 7), (4, "none", 4, 1003, 8),
+                                                     (8, "allgather", 2, 30011, 7)])
 def test_bench_gather_modes_on_gloo(world, mode, chunks, n, wire):
     """--gather allgather (the result assembled on every rank by grouped send/recv between all pairs of ranks) and
     --gather none (every rank keeps its slice; assembled once, untimed, for the parity check): even slices, the same line."""
@@ -174,7 +198,11 @@ def test_bench_gather_modes_on_gloo(world, mode, chunks, n, wire):
     assert d["parity_across_slices"]["distances_bit_exact"] and d["parity_across_slices"]["mrca_bit_exact"]
     assert d["process_group"] == {"backend": "gloo", "world_size": world, "what": d["process_group"]["what"]}
     assert len(d["per_rank"]["kernel_ms"]) == world and sum(d["per_rank"]["pairs"]) == n
-    assert abs(d["root_share"] - (sharding.shard_bounds(n, world, 0)[1]) / n) < 1e-12 and "root_share_calibration" not in d
+    assert abs(d["root_share"] - (sharding.shard_bounds(n, world, 0)[1]) / n) < 1e-12
+    # the sweep's root mode runs with the calibrated root share (the balanced gather of the default run), and says which
+    cal = d["root_share_calibration"]
+    assert abs(gm["root"]["root_share"] - ShardPlanShare(sharding, n, world, chunks, cal["root_share"])) < 1e-12
+    assert abs(gm[mode]["root_share"] - d["root_share"]) < 1e-12
     assert d["gather_bytes_into_root"] == (0 if mode == "none" else wire * (n - sharding.shard_bounds(n, world, 0)[1]))
     covered = []
     for rank, _, calls in res:

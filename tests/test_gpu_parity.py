@@ -1002,8 +1002,21 @@ def test_batch_probe_keeps_the_bits(which, ml_arrays, nj_arrays):
             dev.fault_check()
             assert_bits_equal(out_d.cpu().numpy(), want_d, "%s probe=%d" % (name, probe))
             assert np.array_equal(out_m[:200_000].cpu().numpy(), want_m), name
+    # which kernel a batch got: near -> walk (1), uniform -> ladder (0); and a batch of PERIODIC structure -- one pair in
+    # eight is a near one, at the positions a fixed-stride sample of 4096 would land on -- is not mistaken for a near batch
+    dev.set_option("batch_probe", 1)
+    periodic = np.where((np.arange(n) % 8 == 0)[:, None], near, uniform)
+    assert (n // 4096) % 4 == 0      # (292: every 4th multiple of the old stride is a multiple of 8; with n = 2^k * 4096 all are)
+    for name, batch, want in (("near", near, 1), ("uniform", uniform, 0), ("periodic", periodic, 0)):
+        t = torch.from_numpy(batch).cuda()
+        dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
+        assert dev.probe_last_choice() == want, name
+    n2 = 1 << 20      # stride 256: every old sample position is one of the near pairs
+    t = torch.from_numpy(np.ascontiguousarray(periodic[:n2])).cuda()
+    dev.distances_device(t.data_ptr(), n2, out_d.data_ptr(), out_m.data_ptr())
+    assert dev.probe_last_choice() == 0
     bad = near.copy()
-    bad[::4096, 1] = len(parent) + 5      # exactly the probe's own sample positions hold an id out of range
+    bad[::4096, 1] = len(parent) + 5      # ids out of range scattered through the batch: the probe skips them, the kernels report them
     t = torch.from_numpy(bad).cuda()
     dev.set_option("batch_probe", 1)
     dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
