@@ -336,6 +336,7 @@ def config2(be, name, n=10_000_000, sample=400_000):
                         "x_cpu_one_thread": n / (ms * 1e-3) / cpu["single_thread_value"],
                         "roofline": leg_roofline(be, "%s%s" % ("" if key == "default" else "walk_", name), kernel, n / (ms * 1e-3), ms, n,
                                                  28 + 8 * out["mean_path_edges"], tree.info()["device_bytes"],
+                                                 ladder_sums=tree.info().get("ladder_sums") if key == "default" else None,
                                                  why=None if key == "default" else
                                                  "SURVEY 8d's 28 + 8*h bytes are the reference's walk; the walk family reads a's side from "
                                                  "lineage sums and b's as a stream of lineage lengths, three edges per gather elsewhere")}
@@ -387,19 +388,23 @@ def leg_cpu_baseline(O, pairs_host, what, seconds=2.5):
             "single_thread_value": r1, "single_thread_sample": "first %d pairs, one thread" % n1}, d
 
 
-def traffic_matches(traffic, kernel, pairs_per_launch=None):
+def traffic_matches(traffic, kernel, pairs_per_launch=None, ladder_sums=None):
     """A committed PMC summary speaks for a launch only if it was taken on the same kernel (name as the handle reports
-    it: "canopy_ladder" -> "k_canopy_ladder<") and, where given, the same batch size."""
+    it: "canopy_ladder" -> "k_canopy_ladder<"; ladder_sums: and on the same form of it -- the joint form's template
+    argument list ends in "true>") and, where given, the same batch size."""
     if not traffic or not traffic.get("hbm_bytes_per_launch") or not traffic.get("pairs_per_launch"):
         return False
     full = str(traffic.get("kernel_full_name") or traffic.get("kernel") or "")
     want = "k_walk" if str(kernel).startswith("walk") else "k_%s<" % kernel      # (walk family: k_walk / k_walk_sorted by batch and source)
     if kernel and want not in full:
         return False
+    if kernel == "canopy_ladder" and ladder_sums is not None and bool(ladder_sums) != ("SrcContig, true>" in full):
+        return False
     return pairs_per_launch is None or abs(traffic["pairs_per_launch"] - pairs_per_launch) <= 0.01 * pairs_per_launch
 
 
-def leg_roofline(be, tag, kernel, pairs_per_s, kernel_ms, pairs_per_launch, algorithmic_bytes_per_pair, table_bytes, why=None):
+def leg_roofline(be, tag, kernel, pairs_per_s, kernel_ms, pairs_per_launch, algorithmic_bytes_per_pair, table_bytes, why=None,
+                 ladder_sums=None):
     """A side leg's `roofline` block, in the shape of the headline's: bound hbm, `achieved` = fabric bytes per pair by
     counters (profiles/traffic_<tag>_rNN.json: committed rocprofv3 --pmc passes of this leg's own launch; used only when
     the profiled kernel and batch size are this leg's) x this run's pairs per second of kernel time, `frac` = achieved /
@@ -407,7 +412,7 @@ def leg_roofline(be, tag, kernel, pairs_per_s, kernel_ms, pairs_per_launch, algo
     sub-block `algorithmic` (these kernels climb in LDS and read pre-summed records: the fraction exceeds 1 and is not a
     bandwidth claim).  `request_rate` / `l2_request_rate`: what the time of a gather kernel actually follows."""
     traffic, traffic_file = load_traffic(tag)
-    ok = traffic_matches(traffic, kernel, pairs_per_launch)
+    ok = traffic_matches(traffic, kernel, pairs_per_launch, ladder_sums)
     ceiling = None
     lib = _micro() if not getattr(be, "no_microbench", False) else None
     if lib is not None and ok:
@@ -417,7 +422,8 @@ def leg_roofline(be, tag, kernel, pairs_per_s, kernel_ms, pairs_per_launch, algo
     alg["exceeds_peak"] = bool(alg["frac_of_hbm_peak"] > 1.0)
     alg["why"] = why or ("SURVEY 8d's 28 + 8*h bytes are the reference's walk; this kernel climbs the canopy in LDS and reads "
                          "understories as pre-summed records, so those bytes never cross the fabric (results are bit-exact all the same)")
-    roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernel": "k_" + kernel if kernel else None,
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "kernel": ("k_" + kernel + (" (a's side from the lineage sums)" if kernel == "canopy_ladder" and ladder_sums else "")) if kernel else None,
             "kernel_ms": kernel_ms, "pairs_per_launch": pairs_per_launch}
     if ok:
         ct = three["counter_traffic"]
@@ -475,7 +481,8 @@ def shape_tree_leg(be, skew, what, tag, n_leaves=1_000_000, n=10_000_000, sample
             alg = 28 + 8 * h
             r = {"kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok), "sample_pairs": sample,
                  "x_cpu_all_cores": n / (ms * 1e-3) / cpu["value"], "x_cpu_one_thread": n / (ms * 1e-3) / cpu["single_thread_value"],
-                 "roofline": leg_roofline(be, tag_, kernel, n / (ms * 1e-3), ms, n, alg, info["device_bytes"])}
+                 "roofline": leg_roofline(be, tag_, kernel, n / (ms * 1e-3), ms, n, alg, info["device_bytes"],
+                                          ladder_sums=info.get("ladder_sums") if kernel == "canopy_ladder" else None)}
             return r, h
 
         main, h_mean = run(tag, info["big_batch_kernel"])

@@ -37,7 +37,8 @@ extern "C" {
  * ABI version: bumped whenever an exported struct grows, or an export, option or constant goes away.  A caller built against
  * an older header must not be handed a larger st_tree_info: compare ST_API_VERSION with st_api_version() at load (the ctypes
  * binding does) and use st_tree_info_get_sized, which writes at most the bytes the caller says it has.
- *   6 (round 6): st_api_version, st_tree_info_get_sized added.
+ *   6 (round 6): st_api_version, st_tree_info_get_sized, st_probe_last_choice, option "ladder_sums" added; st_tree_info.reserved0
+ *                is now ladder_sums.
  *   5 (round 5): st_tree_info grew by 8 bytes (b_table_bytes_per_leaf, reserved0); st_host_alloc / st_host_free,
  *                ST_KERNEL_CANOPY_SCALAR, the options pairs_per_lane and ladder_dynamic = 2 removed.
  */
@@ -82,7 +83,8 @@ typedef struct st_tree_info {
     int64_t table_budget_bytes;   /* the budget this handle was built under (0 = none) */
     int32_t b_table_bytes_per_leaf;   /* canopy family: bytes per leaf of the table the second node of a leaf pair gathers from:
                                          record_bytes / 2, or record_bytes / 4 where sibling leaves share a cherry record */
-    int32_t reserved0;
+    int32_t ladder_sums;      /* (was reserved0 until version 6) 1 = the scalar ladder kernel reads the first node's whole side from the
+                                 lineage sums (option "ladder_sums", set by timing when a deep tree is created), 0 = it climbs both sides */
 } st_tree_info;
 
 /* st_tree_info.dropped_tables, in the order in which a table budget (st_tree_options.table_budget_bytes, else
@@ -351,6 +353,11 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * uniform random leaf pairs: a caller whose batches are all close relatives -- every pair within a few leaves, short
  * paths -- does better with "ladder_scalar" 0 and "prefer_walk_sorted" 1: the walk family's cost follows the path
  * length; nj.tree, leaves within 8 of each other: 1.4e10 -> 1.9e10 pairs/s, ml.tree 1.7e10 -> 2.0e10).
+ * "ladder_sums": 1 = that kernel reads the first node's whole side of a pair from the lineage sums (one 4-byte read in place of
+ * its understory entry and its climb in LDS; the meeting node from the 64-bit sparse table by the two portal ranks, the second
+ * node's record by the 16-byte chunks that hold chain slots in use) and climbs the second node's canopy edges only; 0 = both
+ * sides are climbed.  Needs the lineage sums ("lineage_sums" 1, table built); the default is set by timing when a deep tree is
+ * created (nj.tree: 1, +17 %; ml.tree: 0 -- the extra fabric read costs more than its second workgroup's climbs).
  * "ladder_dynamic": 1 (default) = on records of 512 bytes and more, batches of 2^22 pairs and more (2^21 on 1 KB
  * records) of that kernel draw their work from per-XCD counters instead of a static deal; 0 = never.
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.

@@ -68,7 +68,7 @@ class TreeInfo(ctypes.Structure):
         ("dropped_tables", ctypes.c_int32),
         ("table_budget_bytes", ctypes.c_int64),
         ("b_table_bytes_per_leaf", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("ladder_sums", ctypes.c_int32),
     ]
 
     def as_dict(self):

@@ -70,21 +70,21 @@ static std::string tune_cache_path(const st_tree *t, const TreeTables &T, const 
     return dir + name;
 }
 
-static bool tune_cache_read(const std::string &path, int &tile_sort, int &walk, int &ladder, long long &ladder_min)
+static bool tune_cache_read(const std::string &path, int &tile_sort, int &walk, int &ladder, long long &ladder_min, int &ladder_sums)
 {
     if (path.empty()) return false;
     FILE *f = std::fopen(path.c_str(), "r");
     if (!f) return false;
-    int a = -1, c = -1, d = -1;
+    int a = -1, c = -1, d = -1, g = -1;
     long long e = -1;
-    const int got = std::fscanf(f, "%d %d %d %lld", &a, &c, &d, &e);
+    const int got = std::fscanf(f, "%d %d %d %lld %d", &a, &c, &d, &e, &g);
     std::fclose(f);
-    if (got != 4 || (a != 0 && a != 1) || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0) return false;
-    tile_sort = a; walk = c; ladder = d; ladder_min = e;
+    if (got != 5 || (a != 0 && a != 1) || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0 || (g != 0 && g != 1)) return false;
+    tile_sort = a; walk = c; ladder = d; ladder_min = e; ladder_sums = g;
     return true;
 }
 
-static void tune_cache_write(const std::string &path, int tile_sort, int walk, int ladder, long long ladder_min)
+static void tune_cache_write(const std::string &path, int tile_sort, int walk, int ladder, long long ladder_min, int ladder_sums)
 {
     if (path.empty()) return;
     const size_t slash = path.rfind('/');
@@ -94,7 +94,7 @@ static void tune_cache_write(const std::string &path, int tile_sort, int walk, i
     const std::string tmp = path + ".tmp." + std::to_string((long long)::getpid());
     FILE *f = std::fopen(tmp.c_str(), "w");
     if (!f) return;
-    std::fprintf(f, "%d %d %d %lld\n", tile_sort, walk, ladder, ladder_min);
+    std::fprintf(f, "%d %d %d %lld %d\n", tile_sort, walk, ladder, ladder_min, ladder_sums);
     std::fclose(f);
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
@@ -109,6 +109,7 @@ static void copy_tuned_settings(st_tree *to, const st_tree *from)
     to->prefer_walk_sorted = from->prefer_walk_sorted;
     to->ladder_scalar = from->ladder_scalar;
     to->ladder_min_pairs = from->ladder_min_pairs;
+    to->ladder_sums = from->ladder_sums;
     to->info.tuned = from->info.tuned;
 }
 
@@ -119,14 +120,15 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         if (env[0] == '0') return;
     const std::string cache = tune_cache_path(t, T, device_name);
     {
-        int a, c, d;
+        int a, c, d, g;
         long long e;
-        if (tune_cache_read(cache, a, c, d, e)) {
+        if (tune_cache_read(cache, a, c, d, e, g)) {
             // (a recorded choice the handle cannot serve -- other table budget, other options -- is ignored)
             const int keep_sort = t->tile_sort, keep_walk = t->prefer_walk_sorted, keep_ladder = t->ladder_scalar;
             t->tile_sort = a; t->prefer_walk_sorted = c; t->ladder_scalar = 0;
-            const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_tables_ready(t));
-            if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->info.tuned = 2; return; }
+            const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_tables_ready(t)) &&
+                            (!g || ladder_sums_ready(t));
+            if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->ladder_sums = g; t->info.tuned = 2; return; }
             t->tile_sort = keep_sort; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = keep_ladder;
         }
     }
@@ -190,6 +192,16 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         struct Cand { int sort, walk, ladder; float ms, ms_small; };
         const int64_t n_small = n / 4;
         std::vector<Cand> cands;
+        // The scalar ladder kernel has two forms (kernels_canopy.h): both sides climbed, or a's side read from the lineage sums
+        // (one fabric read more, one LDS climb less: nj.tree +17 %, ml.tree -13 %, profiles/ladder_joint_r06.log).  The faster
+        // one -- the joint form only when it is ahead by the margin -- is what the ladder candidate below runs.
+        t->ladder_sums = 0;
+        if (ladder_sums_ready(t)) {
+            const float ms_climb = time_settings(0, 0, 1, n);
+            t->ladder_sums = 1;
+            const float ms_sums = time_settings(0, 0, 1, n);
+            t->ladder_sums = (ms_climb > 0.0f && ms_sums > 0.0f && ms_sums < kTuneMargin * ms_climb) ? 1 : 0;
+        }
         t->ladder_scalar = 0;
         if (sorted_q(t) > 0) cands.push_back({1, 0, 0, -1.0f, -1.0f});
         cands.push_back({0, 0, 0, -1.0f, -1.0f});
@@ -237,12 +249,13 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
             }
             if (t->rec_bytes > kMaxRecordBytes) t->ladder_scalar = 1;      // (1 KB records: the family's other kernels read them through a pointer, far slower)
             t->info.tuned = 1;
-            tune_cache_write(cache, t->tile_sort, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs);
+            tune_cache_write(cache, t->tile_sort, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs, t->ladder_sums);
         } else {
             t->tile_sort = rule_sort;
             t->prefer_walk_sorted = rule_walk;
             t->ladder_scalar = rule_ladder;
             t->ladder_min_pairs = 0;
+            t->ladder_sums = 0;
         }
     } else {
         rule_for_deep_tree(t);

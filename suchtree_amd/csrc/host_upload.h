@@ -148,8 +148,7 @@ static int build_tables_impl(const int32_t *parent, const float *distance, int64
 {
     std::string err;
     if (!prepare_basic(parent, distance, n_nodes, B.T, err)) return fail(ST_ERR_TREE, err);
-    int max_canopy = 0;      // (prepare_canopy: the LDS limit)
-    if (const char *env = std::getenv("SUCHTREE_AMD_MAX_CANOPY_NODES")) max_canopy = std::max(0, std::atoi(env));      // experiment (round 6): a smaller image, two workgroups per CU
+    const int max_canopy = 0;      // (prepare_canopy: the LDS limit)
     if (B.budget > 0) {
         // (tables beyond the floor: the whole-tree sparse table prepare_basic may have built is the first thing to go
         // when the records would not fit beside it)

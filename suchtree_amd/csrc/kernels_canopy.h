@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_la
 // (launch bounds: short records on canopies of at most 80 KiB run two workgroups per CU = 8 waves per SIMD, which the
 // hardware only admits at <= 64 VGPRs and <= 80 SGPRs; see k_canopy_ladder)
 template <int CAP, int PPL, typename Src, bool A4 = false>
-__global__ __launch_bounds__(kCanopyBlock, (((CAP <= 7 || (CAP == 15 && A4)) && PPL == 1) ? 8 : 4)) void k_canopy_ilp(CanopyParams P, Src src, long long n,
+__global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) void k_canopy_ilp(CanopyParams P, Src src, long long n,
                                                              DistSink out_d,
                                                              MrcaSink out_m, Fault *fault)
 {
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(kCanopyBlock, (((CAP <= 7 || (CAP == 15 && A4)) && 
                 const RecTables R{P.rec_a, P.rec_b, P.rec_i, rec_bytes / 2};
                 PairResult r;
                 if (!P.rec_i) r = same_portal_by_walk(P, sa[j], sb[j]);
-                else if constexpr (CAP <= 31 && !(CAP == 15 && A4)) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
-                else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));      // (CAP 15 with the 8-wave budget: the register form's 64 words do not fit)
+                else if constexpr (CAP <= 31) r = pair_same_portal_regs<CAP>(P.canopy_id, R, sa[j], sb[j]);
+                else r = pair_canopy_same_portal(P.canopy_id, rec_view(R, sa[j]), rec_view(R, sb[j]));
                 s[j] = r.dist;
                 m[j] = r.mrca;
             }

@@ -53,7 +53,7 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
     const size_t lds = ladder_kernel_lds_bytes(t->canopy_nodes);      // (image + the kernel's eight "counter ran dry" flags)
     if (lds > kLdsBytesPerCu) return hipErrorInvalidValue;            // (launch_policy.h::ladder_tables_ready keeps such trees away)
     // a's side from the lineage sums (kernels_canopy.h: ladder_pair_sums) where the handle has the tables and chose the form
-    const bool sums = t->ladder_sums && P.rec_p && P.rmq64 && P.lineage && t->lineage_sums;
+    const bool sums = t->ladder_sums && ladder_sums_ready(t);
     auto kern = sums ? k_canopy_ladder<CAP, Src, true> : k_canopy_ladder<CAP, Src, false>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -89,6 +89,11 @@ static inline bool ladder_tables_ready(const st_tree *t)
     return t->strategy == ST_STRATEGY_CANOPY && t->d_ladder && (t->rec_cap == 15 || t->rec_cap == 31 || t->rec_cap >= 63) &&
            ladder_kernel_lds_bytes(t->canopy_nodes) <= kLdsBytesPerCu;      // (the flags behind the image count too)
 }
+// the joint form of that kernel (kernels_canopy.h: ladder_pair_sums) needs the lineage sums, rec_p and the 64-bit sparse table
+static inline bool ladder_sums_ready(const st_tree *t)
+{
+    return ladder_tables_ready(t) && t->d_rec_p && t->d_rmq64 && t->d_lineage && t->lineage_sums;
+}
 static inline bool ladder_applies(const st_tree *t, int64_t n)
 {
     return t->ladder_scalar && n >= std::max<int64_t>(t->ladder_min_pairs, kLadderMinPairs) && ladder_tables_ready(t);

@@ -529,7 +529,7 @@ bool prepare_lineage_sums(TreeTables &T, int64_t max_entries, bool with_lens)
         uint32_t w0a;
         std::memcpy(&w0a, T.rec_a.data() + slot * 8, 4);
         const uint32_t chain = w0a >> 16;                                 // nodes of x's understory chain
-        const uint32_t chunks = T.record_cap <= 31 ? (chain + 1 + 3) / 4 : 1;   // word0 + chain floats, 16 bytes at a time
+        const uint32_t chunks = T.record_cap <= 63 ? (chain + 1 + 3) / 4 : 1;   // word0 + chain floats, 16 bytes at a time (a 4-bit field: up to 63 slots; longer chains are read through a pointer)
         const uint32_t off32 = (uint32_t)off | ((chunks - 1) << 28);
         uint32_t w0;
         std::memcpy(&w0, T.rec_a.data() + slot * 8, 4);

@@ -201,7 +201,7 @@ int emu_distances(const int32_t *parent, const float *distance, int64_t n_nodes,
                         const uint32_t dm = (uint32_t)(m64 >> 32);
                         const uint32_t k_a = (wpa >> 16) - dm, kb_total = (wpb >> 16) - dm;
                         const uint32_t chunks_b = (yb >> 28) + 1;       // 16-byte chunks of b's record the kernel loads
-                        if (T.record_cap <= 31 && 4 * chunks_b < B.nb + 1) {
+                        if (T.record_cap <= 63 && 4 * chunks_b < B.nb + 1) {
                             g_err = "rec_p: chunk count does not cover b's chain";
                             return 9;
                         }

@@ -10,7 +10,7 @@ from suchtree_amd import _capi, synth
 from conftest import oracle_both
 from test_tables_emulated import _general_tree
 
-OPTS = {"tile_sort": (0, 1), "ladder_scalar": (0, 1), "ladder_dynamic": (0, 1), "batch_probe": (0, 1), "cherries": (0, 1),
+OPTS = {"tile_sort": (0, 1), "ladder_scalar": (0, 1), "ladder_sums": (0, 1), "ladder_dynamic": (0, 1), "batch_probe": (0, 1), "cherries": (0, 1),
         "ladder_min_pairs": (0, 131072), "tree_rmq": (0, 1), "mrca_ranks": (0, 1), "rec_a4": (0, 1), "walk_ladder": (0, 1),
         "prefer_walk_sorted": (0, 1), "walk_crown": (0, 1), "walk_sort": (0, 1), "lineage_lens": (0, 1),
         "lineage_sums": (0, 1), "small_batch_path": (0, 1), "wire24": (0, 1), "wire48": (0, 1)}

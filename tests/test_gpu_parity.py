@@ -678,6 +678,75 @@ def test_every_candidate_kernel_on_nj_tree(nj_arrays):
     dev.close()
 
 
+@pytest.mark.parametrize("which", ["ml", "nj", "cap63", "cap127"])
+def test_ladder_kernel_joint_form_keeps_the_bits(which, ml_arrays, nj_arrays):
+    """The scalar ladder kernel's joint form (option ladder_sums: a's whole side from the lineage sums, the meeting node from
+    rec_p + the 64-bit sparse table, b's record by chunks, one LDS climb per pair) against the oracle and against the form
+    that climbs both sides: 15-, 31-, 63-slot chains in registers and 127-slot chains through a pointer; every kind of
+    node (leaves, internal nodes, canopy nodes, the root), equal nodes, ancestor / descendant pairs, neighbours under one
+    portal; static and dynamic deal; device-resident and through the host path's wire formats."""
+    import torch
+    rng = np.random.default_rng(61)
+    if which == "ml":
+        parent, dist = ml_arrays[0], ml_arrays[1]
+    elif which == "nj":
+        parent, dist = nj_arrays[0], nj_arrays[1]
+    elif which == "cap63":
+        parent, dist = _random_shape_tree(rng, 54_000, 0.95)
+    else:
+        parent, dist = _random_shape_tree(np.random.default_rng(5), 1_000_000, 0.9)      # (bench.py's walk_only_tree leg: 1 KB records)
+    n = len(parent)
+    scale = 5 if which == "cap127" else 1      # (the oracle's visited-list scan is O(depth^2) per pair: fewer pairs on the deepest tree)
+    pairs = rng.integers(0, n, (700_000 // scale, 2))
+    a = rng.integers(0, n - 70, 60_000 // scale)
+    near = np.stack([a, a + rng.integers(0, 70, a.size)], 1)
+    same = np.stack([a[:3000], a[:3000]], 1)
+    root = int(np.flatnonzero(parent < 0)[0])
+    up = a[:20_000 // scale].copy()
+    for _ in range(3):      # a node and its great-grandparent (the root where the lineage is shorter)
+        up = np.where(parent[up] >= 0, parent[up], root)
+    anc = np.stack([a[:up.size], up], 1)
+    with_root = np.stack([np.full(2000, root), a[:2000]], 1)
+    allp = np.concatenate([pairs, near, same, anc, anc[:, ::-1], with_root, with_root[:, ::-1]]).astype(np.int64)
+    want_d, want_m = oracle_both(parent, dist, allp)
+    dev = _capi.DeviceTree(parent, dist, strategy="canopy")
+    info = dev.info()
+    assert info["record_bytes"] == {"ml": 128, "nj": 256, "cap63": 512}.get(which, info["record_bytes"])
+    if which == "cap127" and info["record_bytes"] != 1024:
+        pytest.skip("this shape did not need 1 KB records (record_bytes %d)" % info["record_bytes"])
+    t = torch.from_numpy(allp).cuda()
+    out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+    out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+    for k, v in (("tile_sort", 0), ("ladder_scalar", 1), ("ladder_min_pairs", 0), ("prefer_walk_sorted", 0), ("batch_probe", 0)):
+        dev.set_option(k, v)
+    assert dev.info()["big_batch_kernel"] == "canopy_ladder"
+    for sums in (1, 0):
+        for dynamic in (0, 1):
+            dev.set_option("ladder_sums", sums)
+            dev.set_option("ladder_dynamic", dynamic)
+            if which != "cap127":      # (the 1e6-leaf tree's lineage sums exceed the canopy family's limit: the option is a wish there, the climbing form runs)
+                assert dev.info()["ladder_sums"] == sums
+            out_d.fill_(-1.0)
+            out_m.fill_(-7)
+            dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+            dev.fault_check()
+            assert_bits_equal(out_d.cpu().numpy(), want_d, "%s sums=%d dynamic=%d" % (which, sums, dynamic))
+            assert np.array_equal(out_m.cpu().numpy(), want_m), (which, sums, dynamic)
+        d, m = dev.distances_host(allp, True, True)      # (float32 + 24-bit ids over the link)
+        assert_bits_equal(d, want_d, "%s host path sums=%d" % (which, sums))
+        assert np.array_equal(m, want_m), (which, sums)
+        d, _ = dev.distances_host(allp, True, False)
+        assert_bits_equal(d, want_d, "%s host path, distances alone, sums=%d" % (which, sums))
+    # without the lineage sums the option is a wish the handle cannot grant: the climbing form runs, the info says so
+    dev.set_option("lineage_sums", 0)
+    dev.set_option("ladder_sums", 1)
+    assert dev.info()["ladder_sums"] == 0
+    dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+    dev.fault_check()
+    assert_bits_equal(out_d.cpu().numpy(), want_d, which + " no lineage sums")
+    dev.close()
+
+
 def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
     """Deep trees: the handle times its candidate kernels when it is created and makes the fastest its default
     (st_tree_info.tuned / big_batch_kernel); every candidate, forced by options, gives the same bits.  512-byte
