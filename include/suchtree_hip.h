@@ -38,7 +38,7 @@ extern "C" {
  * an older header must not be handed a larger st_tree_info: compare ST_API_VERSION with st_api_version() at load (the ctypes
  * binding does) and use st_tree_info_get_sized, which writes at most the bytes the caller says it has.
  *   6 (round 6): st_api_version, st_tree_info_get_sized, st_probe_last_choice, option "ladder_sums" added; st_tree_info.reserved0
- *                is now ladder_sums.
+ *                is now ladder_sums; option "tile_sort" selects nothing on records of 128 bytes and more (kernel forms removed).
  *   5 (round 5): st_tree_info grew by 8 bytes (b_table_bytes_per_leaf, reserved0); st_host_alloc / st_host_free,
  *                ST_KERNEL_CANOPY_SCALAR, the options pairs_per_lane and ladder_dynamic = 2 removed.
  */
@@ -109,7 +109,7 @@ typedef struct st_tree_options {
 /* st_tree_info.big_batch_kernel */
 #define ST_KERNEL_WALK            0   /* k_walk / k_walk_sorted: trees the canopy family does not serve */
 #define ST_KERNEL_CANOPY          1   /* predicated canopy kernel (one pair per lane, chain in registers); 2: unused since round 5 */
-#define ST_KERNEL_CANOPY_SORTED   3   /* tile-sorted canopy kernel (ladder form of the canopy in LDS) */
+#define ST_KERNEL_CANOPY_SORTED   3   /* tile-sorted canopy kernel (ladder form of the canopy in LDS; chains of at most seven slots) */
 #define ST_KERNEL_WALK_SORTED     4   /* tile-sorted walk kernel on a tree that also has canopy tables */
 #define ST_KERNEL_CANOPY_LADDER   5   /* scalar canopy kernel over the ladder form (long records in registers, read once) */
 
@@ -319,9 +319,11 @@ int st_graph_matrices_host(int device, int64_t n, int64_t n_edges, const int32_t
 int st_tree_set_strategy(st_tree *tree, int strategy);
 
 /* Tuning knobs (benchmarking / tests).
- * "tile_sort": 1 = every workgroup sorts its tile of pairs by expected climb length so that a wave's lanes
- * finish together (deep canopies: the default where it measured fastest when the tree was created, see
- * "prefer_walk_sorted" below); 0 = pairs in input order.
+ * "tile_sort": 1 = on deep canopies whose records hold at most seven chain slots (16- to 64-byte records: small deep trees, a
+ * few thousand leaves) every workgroup sorts its tile of pairs by expected climb length so that a wave's lanes finish together
+ * (the default where it measured fastest when the tree was created, see "prefer_walk_sorted" below); 0 = pairs in input order.
+ * On longer records the option selects nothing since version 6: the tile-sorted canopy kernel's 15- / 31-slot and pointer forms
+ * won no cell of profiles/kernel_win_matrix_r06.json against the scalar ladder kernel ("ladder_scalar") and were removed.
  * "tree_rmq": 1 (default) = the walk family takes the meeting node from the whole-tree sparse table
  * where the tree has one (in-order ids; up to 64 MB, more -- within SUCHTREE_AMD_WALK_TABLE_MB -- when
  * the canopy family is not available); 0 = it searches it by climbing both lineages.
@@ -357,7 +359,9 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * its understory entry and its climb in LDS; the meeting node from the 64-bit sparse table by the two portal ranks, the second
  * node's record by the 16-byte chunks that hold chain slots in use) and climbs the second node's canopy edges only; 0 = both
  * sides are climbed.  Needs the lineage sums ("lineage_sums" 1, table built); the default is set by timing when a deep tree is
- * created (nj.tree: 1, +17 %; ml.tree: 0 -- the extra fabric read costs more than its second workgroup's climbs).
+ * created, possibly for batches up to a size only (nj.tree: 1, +17 %; ml.tree: 1 for batches below 2^20 pairs, where it leads
+ * by 8-13 %, 0 above -- there the extra fabric read costs more than its second workgroup's climbs save); setting the option by
+ * hand applies it to every batch size.
  * "ladder_dynamic": 1 (default) = on records of 512 bytes and more, batches of 2^22 pairs and more (2^21 on 1 KB
  * records) of that kernel draw their work from per-XCD counters instead of a static deal; 0 = never.
  * "walk_sort_min": smallest batch (pairs) that kernel takes; 0 (default) = 262144.

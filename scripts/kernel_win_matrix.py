@@ -1,7 +1,8 @@
 """Kernel x tree x batch size (GPU box, round 6): every kernel family of the library forced by options on the trees of
 the verdict's list, device-resident uniform random leaf pairs, batch sizes 2^17 ... 2^24; per cell the median of 5 launches,
 the winner and its margin over the runner-up -> profiles/kernel_win_matrix_<round>.json.  What wins no cell by more than 5 %
-is a candidate for removal.
+is a candidate for removal.  (Round 6 ran it three times -- large batches, small batches, small deep trees -- and merged the
+three files with the decision into profiles/kernel_win_matrix_r06.json.)
     python scripts/kernel_win_matrix.py r06 [tree ...]
 trees: ml nj 1e6@173 (1e6 leaves, skew 0.8) 1e6@338 (skew 0.9) 1e5@423 (1e5 leaves, skew 0.95) 2^20 (balanced)"""
 import json

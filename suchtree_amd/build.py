@@ -14,16 +14,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsuchtree_hip.so")
-# Four HIP translation units (each kernel family with its launch functions + the C ABI and host side) and two
-# host-only C++ files: compiled to objects in parallel, then linked.
+# Four HIP translation units (each kernel family with its launch functions + the C ABI and host side; launch_canopy.hip in three
+# parts) and two host-only C++ files: compiled to objects in parallel, then linked.
 HIP_SOURCES = [os.path.join(CSRC, f) for f in ("suchtree_hip.hip", "launch_walk.hip", "launch_canopy.hip",
                                                "launch_canopy_sorted.hip")]
 CPP_SOURCES = [os.path.join(CSRC, "tree_prep.cpp"), os.path.join(CSRC, "newick_parse.cpp")]
 SOURCES = HIP_SOURCES + CPP_SOURCES
-# (source, extra flags, object name): launch_canopy_sorted.hip holds the slowest instantiations and is compiled
-# in three parts, two pair sources each
-UNITS = [(src, [], os.path.basename(src) + ".o") for src in SOURCES if not src.endswith("launch_canopy_sorted.hip")]
-UNITS = [(os.path.join(CSRC, "launch_canopy_sorted.hip"), ["-DST_SORTED_PART=%d" % k], "launch_canopy_sorted.%d.o" % k)
+# (source, extra flags, object name): launch_canopy.hip holds the slowest instantiations (the scalar ladder kernel's two forms, the
+# predicated kernel's long-chain forms) and is compiled in three parts, two pair sources each
+UNITS = [(src, [], os.path.basename(src) + ".o") for src in SOURCES if not src.endswith("launch_canopy.hip")]
+UNITS = [(os.path.join(CSRC, "launch_canopy.hip"), ["-DST_CANOPY_PART=%d" % k], "launch_canopy.%d.o" % k)
          for k in range(3)] + UNITS
 OBJ_DIR = os.path.join(HERE, "build")
 MICRO_LIB = os.path.join(HERE, "libst_microbench.so")      # measurement helpers for bench.py, not the product

@@ -35,7 +35,11 @@ static void rule_for_deep_tree(st_tree *t)
     // 63-slot chains: the tile-sorted canopy kernel reads them through a pointer and never won a measurement
     if (t->rec_cap > 31 || sorted_q(t) <= 0) t->tile_sort = 0;
     t->prefer_walk_sorted = walk_sorted_by_rule(t) ? 1 : 0;
-    t->ladder_scalar = t->rec_bytes > kMaxRecordBytes ? 1 : 0;      // (1 KB records: no other canopy kernel reads them well)
+    // where its image fits the scalar ladder kernel has won every tree measured (profiles/kernel_win_matrix_r06.json; 1 KB
+    // records: no other canopy kernel reads them well); its joint form is a matter of timing -- not by rule
+    t->ladder_scalar = ladder_tables_ready(t) ? 1 : 0;
+    t->ladder_sums = 0;
+    t->ladder_sums_max_pairs = 0;
 }
 
 // ---- persistent record of what a tree measured -------------------------------------------------------------
@@ -70,21 +74,23 @@ static std::string tune_cache_path(const st_tree *t, const TreeTables &T, const 
     return dir + name;
 }
 
-static bool tune_cache_read(const std::string &path, int &tile_sort, int &walk, int &ladder, long long &ladder_min, int &ladder_sums)
+static bool tune_cache_read(const std::string &path, int &tile_sort, int &walk, int &ladder, long long &ladder_min, int &ladder_sums,
+                            long long &ladder_sums_max)
 {
     if (path.empty()) return false;
     FILE *f = std::fopen(path.c_str(), "r");
     if (!f) return false;
     int a = -1, c = -1, d = -1, g = -1;
-    long long e = -1;
-    const int got = std::fscanf(f, "%d %d %d %lld %d", &a, &c, &d, &e, &g);
+    long long e = -1, h = -1;
+    const int got = std::fscanf(f, "%d %d %d %lld %d %lld", &a, &c, &d, &e, &g, &h);
     std::fclose(f);
-    if (got != 5 || (a != 0 && a != 1) || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0 || (g != 0 && g != 1)) return false;
-    tile_sort = a; walk = c; ladder = d; ladder_min = e; ladder_sums = g;
+    if (got != 6 || (a != 0 && a != 1) || (c != 0 && c != 1) || (d != 0 && d != 1) || e < 0 || (g != 0 && g != 1) || h < 0) return false;
+    tile_sort = a; walk = c; ladder = d; ladder_min = e; ladder_sums = g; ladder_sums_max = h;
     return true;
 }
 
-static void tune_cache_write(const std::string &path, int tile_sort, int walk, int ladder, long long ladder_min, int ladder_sums)
+static void tune_cache_write(const std::string &path, int tile_sort, int walk, int ladder, long long ladder_min, int ladder_sums,
+                             long long ladder_sums_max)
 {
     if (path.empty()) return;
     const size_t slash = path.rfind('/');
@@ -94,7 +100,7 @@ static void tune_cache_write(const std::string &path, int tile_sort, int walk, i
     const std::string tmp = path + ".tmp." + std::to_string((long long)::getpid());
     FILE *f = std::fopen(tmp.c_str(), "w");
     if (!f) return;
-    std::fprintf(f, "%d %d %d %lld %d\n", tile_sort, walk, ladder, ladder_min, ladder_sums);
+    std::fprintf(f, "%d %d %d %lld %d %lld\n", tile_sort, walk, ladder, ladder_min, ladder_sums, ladder_sums_max);
     std::fclose(f);
     if (std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
@@ -110,6 +116,7 @@ static void copy_tuned_settings(st_tree *to, const st_tree *from)
     to->ladder_scalar = from->ladder_scalar;
     to->ladder_min_pairs = from->ladder_min_pairs;
     to->ladder_sums = from->ladder_sums;
+    to->ladder_sums_max_pairs = from->ladder_sums_max_pairs;
     to->info.tuned = from->info.tuned;
 }
 
@@ -121,14 +128,14 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
     const std::string cache = tune_cache_path(t, T, device_name);
     {
         int a, c, d, g;
-        long long e;
-        if (tune_cache_read(cache, a, c, d, e, g)) {
+        long long e, h;
+        if (tune_cache_read(cache, a, c, d, e, g, h)) {
             // (a recorded choice the handle cannot serve -- other table budget, other options -- is ignored)
             const int keep_sort = t->tile_sort, keep_walk = t->prefer_walk_sorted, keep_ladder = t->ladder_scalar;
             t->tile_sort = a; t->prefer_walk_sorted = c; t->ladder_scalar = 0;
             const bool ok = (!a || sorted_q(t) > 0) && (!c || prefers_walk_sorted(t, kTunePairs, true)) && (!d || ladder_tables_ready(t)) &&
                             (!g || ladder_sums_ready(t));
-            if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->ladder_sums = g; t->info.tuned = 2; return; }
+            if (ok) { t->ladder_scalar = d; t->ladder_min_pairs = e; t->ladder_sums = g; t->ladder_sums_max_pairs = h; t->info.tuned = 2; return; }
             t->tile_sort = keep_sort; t->prefer_walk_sorted = keep_walk; t->ladder_scalar = keep_ladder;
         }
     }
@@ -195,12 +202,19 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         // The scalar ladder kernel has two forms (kernels_canopy.h): both sides climbed, or a's side read from the lineage sums
         // (one fabric read more, one LDS climb less: nj.tree +17 %, ml.tree -13 %, profiles/ladder_joint_r06.log).  The faster
         // one -- the joint form only when it is ahead by the margin -- is what the ladder candidate below runs.
+        // Timed at the whole sample and at a sixteenth of it: on ml.tree the joint form leads below 2^20 pairs (where the
+        // tile-sorted kernel used to serve, 8-13 % ahead of the climbing form) and trails above -- it then takes the batches
+        // up to an eighth of the sample only.
         t->ladder_sums = 0;
+        t->ladder_sums_max_pairs = 0;
         if (ladder_sums_ready(t)) {
-            const float ms_climb = time_settings(0, 0, 1, n);
+            const float climb_big = time_settings(0, 0, 1, n), climb_small = time_settings(0, 0, 1, n / 16);
             t->ladder_sums = 1;
-            const float ms_sums = time_settings(0, 0, 1, n);
-            t->ladder_sums = (ms_climb > 0.0f && ms_sums > 0.0f && ms_sums < kTuneMargin * ms_climb) ? 1 : 0;
+            const float sums_big = time_settings(0, 0, 1, n), sums_small = time_settings(0, 0, 1, n / 16);
+            const bool big = climb_big > 0.0f && sums_big > 0.0f && sums_big < kTuneMargin * climb_big;
+            const bool small = climb_small > 0.0f && sums_small > 0.0f && sums_small < kTuneMargin * climb_small;
+            t->ladder_sums = (big || small) ? 1 : 0;
+            t->ladder_sums_max_pairs = (!big && small) ? n / 8 : 0;
         }
         t->ladder_scalar = 0;
         if (sorted_q(t) > 0) cands.push_back({1, 0, 0, -1.0f, -1.0f});
@@ -249,13 +263,15 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
             }
             if (t->rec_bytes > kMaxRecordBytes) t->ladder_scalar = 1;      // (1 KB records: the family's other kernels read them through a pointer, far slower)
             t->info.tuned = 1;
-            tune_cache_write(cache, t->tile_sort, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs, t->ladder_sums);
+            tune_cache_write(cache, t->tile_sort, t->prefer_walk_sorted, t->ladder_scalar, (long long)t->ladder_min_pairs, t->ladder_sums,
+                             (long long)t->ladder_sums_max_pairs);
         } else {
             t->tile_sort = rule_sort;
             t->prefer_walk_sorted = rule_walk;
             t->ladder_scalar = rule_ladder;
             t->ladder_min_pairs = 0;
             t->ladder_sums = 0;
+            t->ladder_sums_max_pairs = 0;
         }
     } else {
         rule_for_deep_tree(t);

@@ -206,7 +206,9 @@ __device__ __forceinline__ void load_rec_b_lazy(PairRecs<CAP> &L)
 // the two.  Forms that shrank one side only were bit-exact and no faster: two pairs per lane, climbs dealt again among
 // the workgroup's lanes, a software pipeline over the passes (profiles/ladder_*_r04.log); lane-granular refill, K climbs
 // per lane in lock step, fewer lookups, fewer dependent round trips, a block form of the meeting-node query
-// (profiles/ladder_refill_r05.log, ladder_ablation_r05.log).
+// (profiles/ladder_refill_r05.log, ladder_ablation_r05.log).  Round 6 shrank both sides in one form -- SUMS, ladder_pair_sums
+// below: nj.tree +17 %, chosen per tree and batch size by the handle's timing -- and measured two more forms on top of it, K pairs
+// per lane level by level and the K climbs of a lane in one loop: slower (profiles/ladder_joint_r06.log).
 // (launch bounds: two 1024-lane workgroups per CU = 8 waves per SIMD need at most 64 VGPRs AND at most 80 SGPRs --
 // the hardware admits floor(800 / (sgprs rounded up to 16 + 16)) waves per SIMD -- so the short-record form, whose
 // ladder image can leave room for two workgroups (ml.tree: 74 KiB), is compiled for 8; at 92 SGPRs it ran one
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) voi
 // Batch probe: which kernel a large batch of explicit pairs gets on a deep tree is decided per batch, on the device.  The
 // handle's timing (host_tune.h) uses uniform random pairs, where the scalar ladder kernel leads; batches of close
 // relatives -- both nodes under one portal, short paths -- run 20-35 % faster on the tile-sorted walk kernel, whose cost
-// follows the path length (profiles/near_pairs_r0{4,5}.log).  One workgroup looks at 4096 evenly spaced pairs of the
+// follows the path length (profiles/near_pairs_r0{4,5}.log).  One workgroup looks at 4096 pairs spread over the
 // batch: *choice = 1 (walk kernel) when at least a quarter of them share their portal (uniform pairs: 0.1 %, leaves
 // within 1024 of each other: 2-3 %, within 64: a third, within 8: 70-80 %), else 0.  Both kernels are then launched and
 // the one not chosen returns at once: no host round trip, the call stays asynchronous.

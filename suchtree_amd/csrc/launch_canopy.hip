@@ -53,7 +53,7 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
     const size_t lds = ladder_kernel_lds_bytes(t->canopy_nodes);      // (image + the kernel's eight "counter ran dry" flags)
     if (lds > kLdsBytesPerCu) return hipErrorInvalidValue;            // (launch_policy.h::ladder_tables_ready keeps such trees away)
     // a's side from the lineage sums (kernels_canopy.h: ladder_pair_sums) where the handle has the tables and chose the form
-    const bool sums = t->ladder_sums && ladder_sums_ready(t);
+    const bool sums = ladder_sums_applies(t, n);
     auto kern = sums ? k_canopy_ladder<CAP, Src, true> : k_canopy_ladder<CAP, Src, false>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -93,9 +93,10 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
             return launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream, choice);
     }
     if (choice) return hipErrorInvalidValue;      // (a probed batch is one the scalar ladder kernel takes: host_launch.h)
-    // tile-sorted kernel: the default of deep canopies, when its scratch fits next to the canopy image
-    if (t->tile_sort && sorted_q(t) > 0)
-        return launch_canopy_sorted<(CAP == 63 ? 0 : CAP)>(t, P, src, n, out_d, out_m, fault, stream);      // (63-slot chains: through a pointer there)
+    // tile-sorted kernel: deep canopies with chains of at most seven slots, when its scratch fits next to the canopy image
+    if constexpr (CAP == 1 || CAP == 3 || CAP == 7) {
+        if (t->tile_sort && sorted_q(t) > 0) return launch_canopy_sorted<CAP>(t, P, src, n, out_d, out_m, fault, stream);
+    }
     if constexpr (CAP == 0) {
         // 1 KB records exist for the scalar ladder kernel alone (host_upload.h builds them with a canopy that fits its image)
         return ladder_tables_ready(t) ? launch_canopy_ladder<CAP>(t, P, src, n, out_d, out_m, fault, stream) : hipErrorInvalidValue;
@@ -165,11 +166,6 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
         }
         return hipGetLastError();
     }
-    // 31-slot chains are register resident only in the tile-sorted kernel when it runs one
-    // workgroup per CU (128 VGPRs per lane); everywhere else they are read through a pointer
-    if (t->rec_cap == 31 && t->tile_sort && sorted_q(t) > 0 && !(out_d.any() && ladder_applies(t, n)) &&
-        ladder_image_bytes(t->canopy_nodes) + sort_scratch_bytes(sorted_q(t), sorted_shape(t).rmq, sorted_shape(t).sums) > 80 * 1024)
-        return launch_canopy_sorted<31>(t, P, src, n, out_d, out_m, fault, stream);
     switch (t->rec_cap) {
         case 1: return launch_canopy_t<1>(t, P, src, n, out_d, out_m, fault, stream, choice);
         case 3: return launch_canopy_t<3>(t, P, src, n, out_d, out_m, fault, stream, choice);
@@ -185,6 +181,19 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
 #define ST_INSTANTIATE_CANOPY(S) \
     template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *); \
     template hipError_t launch_probe<S>(const st_tree *, const S &, int64_t, int *, hipStream_t);
-ST_FOR_EACH_SRC(ST_INSTANTIATE_CANOPY)
+// The instantiations are the slowest part of the build since round 6 (the scalar ladder kernel has two forms): the file is compiled
+// three times, -DST_CANOPY_PART=0 / 1 / 2, each part with two of the six pair sources (build.py).
+#ifndef ST_CANOPY_PART
+ST_FOR_EACH_SRC(ST_INSTANTIATE_CANOPY)      // (one piece: a plain `hipcc -c` of this file still works)
+#elif ST_CANOPY_PART == 0
+ST_INSTANTIATE_CANOPY(SrcContig)
+ST_INSTANTIATE_CANOPY(SrcContig32)
+#elif ST_CANOPY_PART == 1
+ST_INSTANTIATE_CANOPY(SrcStrided)
+ST_INSTANTIATE_CANOPY(SrcTriangle)
+#else
+ST_INSTANTIATE_CANOPY(SrcGrid)
+ST_INSTANTIATE_CANOPY(SrcQuartet)
+#endif
 
 }  // namespace st

@@ -10,12 +10,9 @@ hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const S
 
 #ifndef ST_SORTED_UNIT
 #define ST_EXTERN_SORTED(S)                                                                                                                   \
-    extern template hipError_t launch_canopy_sorted<0, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
     extern template hipError_t launch_canopy_sorted<1, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
     extern template hipError_t launch_canopy_sorted<3, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
-    extern template hipError_t launch_canopy_sorted<7, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
-    extern template hipError_t launch_canopy_sorted<15, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t); \
-    extern template hipError_t launch_canopy_sorted<31, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
+    extern template hipError_t launch_canopy_sorted<7, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
 ST_FOR_EACH_SRC(ST_EXTERN_SORTED)
 #undef ST_EXTERN_SORTED
 #endif

@@ -1,4 +1,5 @@
-// launch_canopy_sorted.hip -- translation unit of k_canopy_sorted (the tile-sorted ladder kernel of deep canopies):
+// launch_canopy_sorted.hip -- translation unit of k_canopy_sorted (the tile-sorted ladder kernel of deep canopies with chains
+// of at most seven slots; the 15- / 31-slot and pointer forms won no cell of profiles/kernel_win_matrix_r06.json and are gone):
 // every record size x tile size x mode x pair source it is launched with is compiled here, in parallel
 // with the other units of libsuchtree_hip.so.  Built for gfx950 only: hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <hip/hip_runtime.h>
@@ -57,25 +58,9 @@ hipError_t launch_canopy_sorted(const st_tree *t, const CanopyParams &P, const S
 
 
 #define ST_INSTANTIATE_SORTED(S)                                                                                                       \
-    template hipError_t launch_canopy_sorted<0, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
     template hipError_t launch_canopy_sorted<1, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
     template hipError_t launch_canopy_sorted<3, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
-    template hipError_t launch_canopy_sorted<7, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);  \
-    template hipError_t launch_canopy_sorted<15, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t); \
-    template hipError_t launch_canopy_sorted<31, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
-// The instantiations are the slowest part of the build (~50 s in one piece): the file is compiled three times,
-// -DST_SORTED_PART=0 / 1 / 2, each part with two of the six pair sources (build.py).
-#ifndef ST_SORTED_PART
-ST_FOR_EACH_SRC(ST_INSTANTIATE_SORTED)      // (one piece: a plain `hipcc -c` of this file still works)
-#elif ST_SORTED_PART == 0
-ST_INSTANTIATE_SORTED(SrcContig)
-ST_INSTANTIATE_SORTED(SrcContig32)
-#elif ST_SORTED_PART == 1
-ST_INSTANTIATE_SORTED(SrcStrided)
-ST_INSTANTIATE_SORTED(SrcTriangle)
-#else
-ST_INSTANTIATE_SORTED(SrcGrid)
-ST_INSTANTIATE_SORTED(SrcQuartet)
-#endif
+    template hipError_t launch_canopy_sorted<7, S>(const st_tree *, const CanopyParams &, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t);
+ST_FOR_EACH_SRC(ST_INSTANTIATE_SORTED)
 
 }  // namespace st

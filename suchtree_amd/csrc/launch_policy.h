@@ -26,7 +26,11 @@ struct SortedShape {
 
 static inline SortedShape sorted_shape(const st_tree *t)
 {
-    if (t->rec_bytes > 512) return {0, false, false};      // (1 KB records: the scalar ladder kernel alone)
+    // chains of at most seven slots only (round 6): on records of 128 bytes and more the scalar ladder kernel has the same
+    // image in LDS, reads every record once and won every cell of profiles/kernel_win_matrix_r06.json -- the tile-sorted
+    // kernel's 15- / 31-slot and pointer forms are gone; on 16- to 64-byte records (small deep trees: a 2048-leaf
+    // caterpillar, 3000 leaves at depth 292) it leads the walk family by 20-30 % and stays
+    if (t->rec_cap > 7) return {0, false, false};
     const size_t image = ladder_image_bytes(t->canopy_nodes);
     const bool table = t->d_rmq != nullptr;
     const bool lineage = table && t->d_lineage != nullptr && t->d_rec_p != nullptr && t->lineage_sums;      // (rec_p: the canopy family's offsets into the table)
@@ -93,6 +97,11 @@ static inline bool ladder_tables_ready(const st_tree *t)
 static inline bool ladder_sums_ready(const st_tree *t)
 {
     return ladder_tables_ready(t) && t->d_rec_p && t->d_rmq64 && t->d_lineage && t->lineage_sums;
+}
+// ... and the handle may have found it ahead on batches up to a size only (host_tune.h: ml.tree below 2^20 pairs)
+static inline bool ladder_sums_applies(const st_tree *t, int64_t n)
+{
+    return t->ladder_sums && (t->ladder_sums_max_pairs <= 0 || n <= t->ladder_sums_max_pairs) && ladder_sums_ready(t);
 }
 static inline bool ladder_applies(const st_tree *t, int64_t n)
 {

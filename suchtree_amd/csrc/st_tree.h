@@ -84,6 +84,7 @@ struct st_tree {
     int walk_sort = 1;        // tuning: 0 = the walk family never uses its tile-sorted kernel (k_walk_sorted)
     int lineage_lens = 1;     // tuning: 0 = the walk family climbs b's lineage through the stride-3 image even when the lineage-length table exists
     int lineage_sums = 1;     // tuning: 0 = the tile-sorted kernel climbs a's canopy lineage even when the lineage-sum table exists
+    int64_t ladder_sums_max_pairs = 0;   // largest batch of that form; 0 = every batch (set with ladder_sums when the tree is created)
     int ladder_sums = 0;      // 1 = the scalar ladder kernel reads a's whole side from the lineage sums too (kernels_canopy.h: ladder_pair_sums)
     LadderEntry *d_ladder = nullptr;
     uint16_t *d_cdepth = nullptr;

@@ -376,7 +376,7 @@ try {
     info->big_batch_kernel = big_batch_kernel_of(t);      // (follows the handle's current options)
     info->a_side_bytes = t->has_canopy ? ((t->rec_a4 && t->d_rec_a4 && t->d_leaf_blocks) ? 4 : 8) : 0;
     info->b_table_bytes_per_leaf = t->has_canopy ? ((t->rec_a4 && t->cherries && t->d_rec_c && t->d_leaf_blocks) ? t->rec_bytes / 4 : t->rec_bytes / 2) : 0;
-    info->ladder_sums = (t->ladder_sums && ladder_sums_ready(t)) ? 1 : 0;
+    info->ladder_sums = (t->ladder_sums && ladder_sums_ready(t)) ? 1 : 0;      // (for batches of up to ladder_sums_max_pairs, if that is set)
     info->host_wire_bytes_in = t->wire48 && t->n_nodes <= 0xFFFFFF ? 6 : 8;
     info->host_wire_bytes_out = t->wire24 && t->n_nodes <= 0xFFFFFF ? 7 : 8;
     return ST_OK;
@@ -531,6 +531,7 @@ static int set_option_one(st_tree *t, const char *name, int64_t value)
     if (std::strcmp(name, "ladder_sums") == 0) {
         if (value != 0 && value != 1) return fail(ST_ERR_ARG, "ladder_sums must be 0 or 1");
         t->ladder_sums = (int)value;
+        t->ladder_sums_max_pairs = 0;      // (an explicit setting holds for every batch size)
         return ST_OK;
     }
     if (std::strcmp(name, "small_batch_path") == 0) {

@@ -58,6 +58,25 @@ def test_argument_errors(lib):
     lib.st_tree_destroy(None)   # no-op
 
 
+def test_abi_version_marker_and_sized_info(lib):
+    """The header's ST_API_VERSION is what the library answers and what the ctypes binding expects; the sized info getter and
+    the probe diagnostic refuse bad arguments (no GPU needed for that)."""
+    import re
+    from conftest import ROOT
+    header = open(os.path.join(ROOT, "include", "suchtree_hip.h")).read()
+    declared = int(re.search(r"#define\s+ST_API_VERSION\s+(\d+)", header).group(1))
+    assert lib.st_api_version() == declared == _capi.API_VERSION
+    buf = ctypes.create_string_buffer(256)
+    assert lib.st_tree_info_get_sized(None, buf, 256) == _capi.ST_ERR_ARG
+    assert lib.st_probe_last_choice(None, None, None) == _capi.ST_ERR_ARG
+    # the binding's struct is the header's: same fields, same order (a reordered or missing field would shift every value)
+    body = re.search(r"typedef struct st_tree_info \{(.*?)\} st_tree_info;", header, re.S).group(1)
+    fields = re.findall(r"\b(?:int32_t|int64_t)\s+(\w+);", body)
+    assert fields == [name for name, _ in _capi.TreeInfo._fields_], (fields, [n for n, _ in _capi.TreeInfo._fields_])
+    sizes = {"int32_t": 4, "int64_t": 8}
+    assert ctypes.sizeof(_capi.TreeInfo) == sum(sizes[t] for t in re.findall(r"\b(int32_t|int64_t)\s+\w+;", body))
+
+
 def test_without_gpu_create_fails_cleanly(lib):
     if _capi.device_count() > 0:
         pytest.skip("a GPU is present")

@@ -75,7 +75,28 @@ def test_bench_line_contract():
         c = oc[key]
         assert c["default"]["bit_exact_on_sample"] and c["walk"]["bit_exact_on_sample"] and c["host_path"]["bit_exact_on_sample"]
         assert c["default"]["pairs_per_s"] > 1e9 and c["walk"]["pairs_per_s"] > 1e9 and c["algorithmic_bytes_per_pair"] > 500
+    # every leg is measured to the headline's standard (round 6): the CPU column -- the oracle on the leg's own pairs, one thread
+    # and all host cores -- and a roofline block whose frac is counter bytes / kernel time / 8 TB/s wherever a committed PMC summary
+    # of THIS kernel at THIS batch size exists (SURVEY 8d's algorithmic bytes ride along, flagged where they exceed the peak)
+    def leg_blocks(where, cpu, roofs):
+        assert cpu["kind"] == "port" and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"], (where, cpu)
+        for r in roofs:
+            assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12, (where, r)
+            a = r["algorithmic"]
+            assert a["exceeds_peak"] == (a["frac_of_hbm_peak"] > 1) and a["why"], (where, a)
+            if r["traffic"] is not None:
+                assert 0 < r["frac"] < 1 and r["traffic_source"].startswith("profiles/traffic_") and r["counters_kernel"], (where, r)
+                assert abs(r["traffic"] - r["traffic_bytes_per_pair"] * r["pairs_per_launch"]) < 1e-6 * r["traffic"], (where, r)
+    for key in ("config2_ml_tree", "config2_nj_tree"):
+        c = oc[key]
+        assert c["cpu_baseline"]["single_thread_value"] > 0 and c["default"]["x_cpu_all_cores"] > 10 and c["default"]["x_cpu_one_thread"] > 100, c
+        leg_blocks(key, c["cpu_baseline"], [c["default"]["roofline"], c["walk"]["roofline"]])
+        assert c["default"]["roofline"]["traffic"] is not None, c["default"]["roofline"]      # (the round's profiles cover the kernel the handle picks)
     t = oc["config4_triangle_100k"]
+    leg_blocks("config4", t["cpu_baseline"], [t["canopy"]["roofline"], t["walk"]["roofline"]])
+    for key in ("walk_only_tree", "deep_long_record_tree"):
+        leg_blocks(key, oc[key]["cpu_baseline"], [oc[key]["roofline"]])
+    leg_blocks("config5", oc["config5_fish_worm"]["cpu_baseline"], [])
     assert t["pairs"] == 4_999_950_000 and t["bit_exact_on_sample"] and t["canopy"]["pairs_per_s"] > 1e10
     assert t["streamed_to_host"]["pairs"] == 1 << 30 and t["streamed_to_host"]["pairs_per_s"] > 1e9
     for key in ("walk_only_tree", "deep_long_record_tree"):

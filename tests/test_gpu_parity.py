@@ -561,13 +561,26 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
     the table on and off."""
     import torch
     rng = np.random.default_rng(404)
-    trees = [_random_shape_tree(rng, 30000, 0.97), _random_shape_tree(rng, 9000, 0.995), (ml_arrays[0], ml_arrays[1])]
+    # (since round 6 the tile-sorted kernel serves chains of at most seven slots -- small deep trees: 16-, 32- and 64-byte records
+    # below; on longer records the same options run the scalar ladder kernel, whose joint form reads the same table)
+    trees = [_random_shape_tree(rng, 30000, 0.97), _random_shape_tree(rng, 9000, 0.995), _random_shape_tree(rng, 12000, 0.9),
+             _random_shape_tree(rng, 16000, 0.9), (ml_arrays[0], ml_arrays[1])]
+    sorted_records = set()
     for parent, dist in trees:
         n = len(parent)
         O = OracleTree(parent, dist)
         dev = _capi.DeviceTree(parent, dist)
         info = dev.info()
         assert info["strategy"] == "canopy" and info["lineage_entries"] > n, info
+        dev.set_option("tile_sort", 1)
+        dev.set_option("ladder_scalar", 0)
+        dev.set_option("prefer_walk_sorted", 0)
+        if dev.info()["big_batch_kernel"] == "canopy_sorted":
+            sorted_records.add(info["record_bytes"])
+        elif info["record_bytes"] >= 128:
+            dev.set_option("ladder_scalar", 1)
+            assert dev.info()["big_batch_kernel"] == "canopy_ladder", dev.info()
+        # (else: short records under a canopy image that leaves the tile-sorted kernel no scratch -- the predicated kernel runs)
         pairs = rng.integers(0, n, (200_000, 2))
         a = rng.integers(0, n - 12, 50_000)
         near = np.stack([a, a + rng.integers(0, 12, a.size)], 1)           # mostly one portal
@@ -637,6 +650,7 @@ def test_lineage_sum_mode_of_the_deep_kernel(ml_arrays):
                 dev.distances_host(bad, True, True)
             assert err.value.node_id == n + 5
         dev.close()
+    assert len(sorted_records) >= 2 and max(sorted_records) <= 64, sorted_records
 
 
 def test_every_candidate_kernel_on_nj_tree(nj_arrays):
@@ -670,7 +684,7 @@ def test_every_candidate_kernel_on_nj_tree(nj_arrays):
         d, m = dev.distances_host(allp, True, True)      # (packed ids on the way back)
         assert_bits_equal(d, want_d, "host path, " + kernel)
         assert np.array_equal(m, want_m), kernel
-    assert seen == {"canopy_sorted", "canopy", "walk_sorted", "canopy_ladder"}, seen
+    assert seen == {"canopy", "walk_sorted", "canopy_ladder"}, seen      # (tile_sort = 1 selects nothing on 31-slot chains since round 6: the predicated kernel runs)
     out_m.fill_(-1)
     dev.distances_device(t.data_ptr(), len(allp), 0, out_m.data_ptr())      # k_mrca_ranks<31>
     dev.fault_check()
@@ -779,7 +793,7 @@ def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
     dev = _capi.DeviceTree(parent, dist)
     info = dev.info()
     assert info["strategy"] == "canopy" and info["record_bytes"] == 512 and info["lineage_entries"] > 0, info
-    assert info["tuned"] == 1 and info["big_batch_kernel"] in ("canopy", "canopy_sorted", "walk_sorted", "canopy_ladder"), info
+    assert info["tuned"] == 1 and info["big_batch_kernel"] in ("canopy", "walk_sorted", "canopy_ladder"), info
     assert len(list((tmp_path / "tune").glob("tune-*.txt"))) == 1
     again = _capi.DeviceTree(parent, dist)
     assert again.info()["tuned"] == 2 and again.info()["big_batch_kernel"] == info["big_batch_kernel"], again.info()
@@ -801,12 +815,12 @@ def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
         d, m = dev.distances_host(allp[:300_000], True, True)
         assert_bits_equal(d, want_d[:300_000], "host path, " + kernel)
         assert np.array_equal(m, want_m[:300_000])
-    assert seen == {"canopy_sorted", "canopy", "walk_sorted", "canopy_ladder"}, seen
+    assert seen == {"canopy", "walk_sorted", "canopy_ladder"}, seen
     dev.close()
     monkeypatch.setenv("SUCHTREE_AMD_AUTOTUNE", "0")
     dev = _capi.DeviceTree(parent, dist)
     info = dev.info()
-    assert info["tuned"] == 0 and info["big_batch_kernel"] in ("canopy", "walk_sorted"), info      # (the fixed rule)
+    assert info["tuned"] == 0 and info["big_batch_kernel"] == "canopy_ladder" and info["ladder_sums"] == 0, info      # (the fixed rule: the ladder kernel where its image fits)
     run(dev, "rule (%s)" % info["big_batch_kernel"])
     dev.close()
 
@@ -850,7 +864,7 @@ def test_deep_canopy_tree_with_walk_form_lineage_tables(ml_arrays, monkeypatch):
         assert np.array_equal(m, want_m[:300_000])
         d, m = dev.distances_host(allp[:2_000], True, True)
         assert_bits_equal(d, want_d[:2_000], "mailbox, " + kernel)
-    assert seen == {"canopy_sorted", "canopy", "walk_sorted"}, seen
+    assert seen == {"canopy", "walk_sorted"}, seen      # (15-slot chains: no tile-sorted canopy kernel since round 6)
     dev.set_strategy("walk")
     dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
     assert_bits_equal(out_d.cpu().numpy(), want_d, "walk family")
