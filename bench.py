@@ -377,6 +377,22 @@ class HipBackend:
                         "ceiling_source": "suchtree_amd/csrc/microbench.hip run in this process: random 32-byte reads, one per 64-byte "
                                           "sector, from a table of the kernel's own gather footprint; best of a sweep over unroll and "
                                           "grid shape; requests per pair: rocprofv3 TCC_EA0_RDREQ_sum in %s" % traffic_file}
+                    # The same comparison in the unit the CU's miss path counts in (round 6, profiles/counters_headline_r06.txt: TA busy 93 %
+                    # of the launch, the L1 stalled on pending misses 85 %): L1-miss requests per second -- fabric reads PLUS the L2 hits
+                    # (rec_a4 entries, a quarter of the kernel's misses), which occupy a miss slot without becoming a fabric read -- against
+                    # the microbenchmark's lane reads per second, each of which is one L1-miss request (ceiling_counters_rNN.json).
+                    l1 = (traffic or {}).get("counters_mean_per_launch", {}).get("TCP_TCC_READ_REQ_sum")
+                    if l1 and traffic.get("pairs_per_launch"):
+                        per_pair = l1 / traffic["pairs_per_launch"]
+                        cc = bench_legs.committed_ceiling_counters()
+                        roof["secondary_ceiling"]["l1_miss_requests"] = {
+                            "per_pair": per_pair, "Greq_per_s": per_pair * pairs_per_s / 1e9,
+                            "frac_of_ceiling_lane_reads": per_pair * pairs_per_s / 1e9 / rr["ceiling_Greads_per_s"],
+                            "ceiling_l1_miss_requests_per_lane_read": (cc or {}).get("l1_per_read"),
+                            "ceiling_fabric_requests_per_lane_read": (cc or {}).get("fabric_per_read"),
+                            "ceiling_counters_from": (cc or {}).get("source"),
+                            "why": "the microbenchmark's G reads/s are lane reads = L1-miss requests; the kernel's request_rate counts fabric "
+                                   "reads only, so `frac` understates how close the CU's miss path is to its ceiling"}
         line["mrca_ids_only"] = bench_legs.mrca_ids_only(self, pairs, out_m)
         if not args.no_host_path:
             line["end_to_end_host_path"] = bench_legs.host_path_leg(self, pairs, out_d, out_m)

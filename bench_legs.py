@@ -147,6 +147,23 @@ def committed_sector_ceiling(footprint_bytes):
             "Greads_per_s": v["table"]["Greads_per_s"], "stream_copy_GBps": v.get("stream_copy_GBps")}
 
 
+def committed_ceiling_counters():
+    """profiles/ceiling_counters_rNN.json (scripts/sector_ceiling_counters.sh): what one lane read of the random-sector
+    microbenchmark costs in L1-miss requests and in fabric requests at the headline kernel's footprint."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "ceiling_counters_r[0-9][0-9].json")))
+    if not files:
+        return None
+    try:
+        b = json.load(open(files[-1])).get("best") or {}
+    except Exception:      # noqa: BLE001
+        return None
+    per = b.get("per_lane_read", {})
+    return {"source": os.path.relpath(files[-1], ROOT), "l1_per_read": per.get("TCP_TCC_READ_REQ_sum"), "fabric_per_read": per.get("TCC_EA0_RDREQ_sum"),
+            "Greads_per_s_under_counters": b.get("Greads_per_s")}
+
+
 def load_traffic(tag):
     """profiles/traffic_<tag>_rNN.json of the latest round that has one (committed PMC passes of a leg's kernel)."""
     import glob
@@ -292,6 +309,12 @@ def _device_rate(be, tree, pairs_t, reps=5):
     return float(np.median(ms)), out_d, out_m
 
 
+def ladder_form(info, n):
+    """1 when the handle's scalar ladder kernel runs its joint form on a batch of n pairs (st_tree_info.ladder_sums, for batches
+    up to ladder_sums_max_pairs where that is set), else 0."""
+    return int(bool(info.get("ladder_sums")) and (not info.get("ladder_sums_max_pairs") or n <= info["ladder_sums_max_pairs"]))
+
+
 def _mean_path_edges(be, parent, pairs_t, out_m):
     from suchtree_amd.newick import node_depths
     torch = be.torch
@@ -336,7 +359,7 @@ def config2(be, name, n=10_000_000, sample=400_000):
                         "x_cpu_one_thread": n / (ms * 1e-3) / cpu["single_thread_value"],
                         "roofline": leg_roofline(be, "%s%s" % ("" if key == "default" else "walk_", name), kernel, n / (ms * 1e-3), ms, n,
                                                  28 + 8 * out["mean_path_edges"], tree.info()["device_bytes"],
-                                                 ladder_sums=tree.info().get("ladder_sums") if key == "default" else None,
+                                                 ladder_sums=ladder_form(tree.info(), n) if key == "default" else None,
                                                  why=None if key == "default" else
                                                  "SURVEY 8d's 28 + 8*h bytes are the reference's walk; the walk family reads a's side from "
                                                  "lineage sums and b's as a stream of lineage lengths, three edges per gather elsewhere")}
@@ -482,7 +505,7 @@ def shape_tree_leg(be, skew, what, tag, n_leaves=1_000_000, n=10_000_000, sample
             r = {"kernel_ms": ms, "pairs_per_s": n / (ms * 1e-3), "bit_exact_on_sample": bool(ok), "sample_pairs": sample,
                  "x_cpu_all_cores": n / (ms * 1e-3) / cpu["value"], "x_cpu_one_thread": n / (ms * 1e-3) / cpu["single_thread_value"],
                  "roofline": leg_roofline(be, tag_, kernel, n / (ms * 1e-3), ms, n, alg, info["device_bytes"],
-                                          ladder_sums=info.get("ladder_sums") if kernel == "canopy_ladder" else None)}
+                                          ladder_sums=ladder_form(info, n) if kernel == "canopy_ladder" else None)}
             return r, h
 
         main, h_mean = run(tag, info["big_batch_kernel"])
@@ -548,7 +571,7 @@ def config4(be, m=100_000, host_pairs=1 << 30):
                 best = min(best, time.perf_counter() - t0)
             tree.fault_check(stream.cuda_stream)
             n_tiles = (total + tile - 1) // tile
-            kernel = {"canopy": "canopy_ilp", "walk": "walk_sorted"}[strategy]
+            kernel = {"canopy": "canopy_ilp", "walk": "walk"}[strategy]      # (generated pairs: the walk family's plain kernel)
             out[strategy] = {"seconds_whole_triangle": best, "pairs_per_s": total / best, "kernel": kernel,
                              "launches": n_tiles, "pairs_per_launch": tile,
                              "roofline": leg_roofline(be, "tri" if strategy == "canopy" else "walk_tri", kernel, total / best,

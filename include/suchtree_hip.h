@@ -38,7 +38,7 @@ extern "C" {
  * an older header must not be handed a larger st_tree_info: compare ST_API_VERSION with st_api_version() at load (the ctypes
  * binding does) and use st_tree_info_get_sized, which writes at most the bytes the caller says it has.
  *   6 (round 6): st_api_version, st_tree_info_get_sized, st_probe_last_choice, option "ladder_sums" added; st_tree_info.reserved0
- *                is now ladder_sums; option "tile_sort" selects nothing on records of 128 bytes and more (kernel forms removed).
+ *                is now ladder_sums, reserved1 and ladder_sums_max_pairs appended (12 bytes); option "tile_sort" selects nothing on records of 128 bytes and more (kernel forms removed).
  *   5 (round 5): st_tree_info grew by 8 bytes (b_table_bytes_per_leaf, reserved0); st_host_alloc / st_host_free,
  *                ST_KERNEL_CANOPY_SCALAR, the options pairs_per_lane and ladder_dynamic = 2 removed.
  */
@@ -85,6 +85,9 @@ typedef struct st_tree_info {
                                          record_bytes / 2, or record_bytes / 4 where sibling leaves share a cherry record */
     int32_t ladder_sums;      /* (was reserved0 until version 6) 1 = the scalar ladder kernel reads the first node's whole side from the
                                  lineage sums (option "ladder_sums", set by timing when a deep tree is created), 0 = it climbs both sides */
+    int32_t reserved1;
+    int64_t ladder_sums_max_pairs;   /* largest batch the joint form takes when ladder_sums is 1; 0 = every batch (ml.tree: 2^20 -- beyond it the
+                                        climbing form runs) */
 } st_tree_info;
 
 /* st_tree_info.dropped_tables, in the order in which a table budget (st_tree_options.table_budget_bytes, else

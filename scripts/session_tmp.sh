@@ -1,4 +1,4 @@
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/tests_r06c.log
-bash scripts/profile_round.sh r06 2>&1 | tee gpurun_out/profile_round_r06.log
-COUNTERS="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES;SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS;TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum;SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR;TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE;TA_BUSY_avr TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" PMC_TIMEOUT=200 bash scripts/profile_pmc.sh headline_r06 --levels 20 --pairs 100000000 --rounds 3 2>&1 | tee gpurun_out/counters_headline_r06.txt
-bash scripts/gpu_session.sh bench --steps 20 --warmup 5 > gpurun_out/bench_r06_b.txt
+bash scripts/sector_ceiling_counters.sh 20 r06 2>&1 | tee gpurun_out/ceiling_counters_r06.log
+bash scripts/profile_gpu.sh r06 2>&1 | tail -4
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/tests_r06d.log
+bash scripts/gpu_session.sh bench --steps 20 --warmup 5 > gpurun_out/bench_r06_c.txt
