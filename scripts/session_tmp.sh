@@ -1,4 +1,3 @@
-bash scripts/sector_ceiling_counters.sh 20 r06 2>&1 | tee gpurun_out/ceiling_counters_r06.log
-bash scripts/profile_gpu.sh r06 2>&1 | tail -4
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/tests_r06d.log
-bash scripts/gpu_session.sh bench --steps 20 --warmup 5 > gpurun_out/bench_r06_c.txt
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -60 | tee gpurun_out/tests_r06e.log
+timeout 600 python tests/fuzz_parity.py 300 6001 2>&1 | tail -5 | tee gpurun_out/fuzz_r06.log
+timeout 600 python tests/fuzz_parity.py 240 6002 big 2>&1 | tail -5 | tee -a gpurun_out/fuzz_r06.log
