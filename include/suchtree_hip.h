@@ -38,7 +38,7 @@ extern "C" {
  * an older header must not be handed a larger st_tree_info: compare ST_API_VERSION with st_api_version() at load (the ctypes
  * binding does) and use st_tree_info_get_sized, which writes at most the bytes the caller says it has.
  *   6 (round 6): st_api_version, st_tree_info_get_sized, st_probe_last_choice, option "ladder_sums" added; st_tree_info.reserved0
- *                is now ladder_sums, reserved1 and ladder_sums_max_pairs appended (12 bytes); option "tile_sort" selects nothing on records of 128 bytes and more (kernel forms removed).
+ *                is now ladder_sums, ladder_sums_max_pairs appended (8 bytes); option "tile_sort" selects nothing on records of 128 bytes and more (kernel forms removed).
  *   5 (round 5): st_tree_info grew by 8 bytes (b_table_bytes_per_leaf, reserved0); st_host_alloc / st_host_free,
  *                ST_KERNEL_CANOPY_SCALAR, the options pairs_per_lane and ladder_dynamic = 2 removed.
  */
@@ -85,7 +85,6 @@ typedef struct st_tree_info {
                                          record_bytes / 2, or record_bytes / 4 where sibling leaves share a cherry record */
     int32_t ladder_sums;      /* (was reserved0 until version 6) 1 = the scalar ladder kernel reads the first node's whole side from the
                                  lineage sums (option "ladder_sums", set by timing when a deep tree is created), 0 = it climbs both sides */
-    int32_t reserved1;
     int64_t ladder_sums_max_pairs;   /* largest batch the joint form takes when ladder_sums is 1; 0 = every batch (ml.tree: 2^20 -- beyond it the
                                         climbing form runs) */
 } st_tree_info;
@@ -388,9 +387,11 @@ int st_tree_set_strategy(st_tree *tree, int strategy);
  * device-mapped mailbox (one launch; completion is polled in host memory), 0 = through the
  * staged pipe.
  * "batch_probe": 1 (default) = on deep trees whose handle sends large distance batches to the scalar ladder kernel and
- * whose tile-sorted walk kernel is ready as well, every device-resident batch of >= 524288 explicit pairs is sampled on
- * the device (4096 pairs: do both nodes share their portal?) and goes to the walk kernel when a quarter of the sample
- * does -- batches of close relatives -- else to the ladder kernel; no host round trip; 0 = always the handle's choice.
+ * whose tile-sorted walk kernel is ready as well, every device-resident batch of >= 2^22 explicit pairs is sampled on the device
+ * (1024 pairs, one from every 1024th of the batch at a hashed offset: do both nodes share their portal?) and goes to the walk
+ * kernel when a quarter of the sample does -- batches of close relatives -- else to the ladder kernel.  Both kernels are enqueued
+ * and every workgroup of either takes the sample itself; the kernel it does not choose returns at once: no probe launch, no host
+ * round trip, 8-10 us per batch (version 5's separate probe kernel, from 524288 pairs: 20 us).  0 = always the handle's choice.
  * "measure" (default 0; MEASUREMENT ONLY): bits 1 = one line per host-path call on stderr with the host thread's time by
  * phase, 2 = the host path skips its pack / unpack passes, 4 = it launches nothing.  A call made with bit 2 or 4 set
  * returns ST_ERR_MEASURE_ONLY, never ST_OK: its result arrays are not valid. */

@@ -1,3 +1,3 @@
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -60 | tee gpurun_out/tests_r06e.log
-timeout 600 python tests/fuzz_parity.py 300 6001 2>&1 | tail -5 | tee gpurun_out/fuzz_r06.log
-timeout 600 python tests/fuzz_parity.py 240 6002 big 2>&1 | tail -5 | tee -a gpurun_out/fuzz_r06.log
+timeout 1500 python scripts/default_vs_matrix.py 2>&1 | grep -v Warning | tee gpurun_out/default_vs_matrix_r06c.log | grep "behind\|==\|worst"
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 | tee gpurun_out/tests_r06f.log
+bash scripts/gpu_session.sh bench --steps 20 --warmup 5 > gpurun_out/bench_r06_d.txt

@@ -69,7 +69,6 @@ class TreeInfo(ctypes.Structure):
         ("table_budget_bytes", ctypes.c_int64),
         ("b_table_bytes_per_leaf", ctypes.c_int32),
         ("ladder_sums", ctypes.c_int32),
-        ("reserved1", ctypes.c_int32),
         ("ladder_sums_max_pairs", ctypes.c_int64),
     ]
 

@@ -27,19 +27,20 @@ static int enqueue_src(st_tree *t, const Src &src, int64_t n, DistSink d_out, Mr
                          (allow_sorted || !(t->tile_sort && sorted_q(t) > 0) || sorted_zero_copy(t)) &&
                          !prefers_walk_sorted(t, n, d_out.any()));
     // Large batches of explicit pairs that the scalar ladder kernel would take, on a tree whose tile-sorted walk kernel is
-    // ready as well: the batch itself decides (kernels_canopy.h: k_probe_shared_portal) -- both kernels are enqueued, the
-    // one the probe did not choose returns at once.  Pair generators (triangle, grid, quartets) keep the handle's choice:
-    // clade triangles run fastest on the ladder kernel (profiles/clade_triangles_r04.log).
+    // ready as well: the batch itself decides (pair_math.h: probe_says_walk) -- both kernels are enqueued, every workgroup
+    // of either samples the batch, the kernel the sample does not choose returns at once.  From kProbeMinPairs pairs: the empty
+    // dispatch and the sampling cost 8-10 us per batch (round 5's separate probe kernel: 20; profiles/default_vs_matrix_r06.log).
+    // Pair generators (triangle, grid, quartets) keep the handle's choice: clade triangles run fastest on the ladder kernel
+    // (profiles/clade_triangles_r04.log).
     constexpr bool explicit_pairs = std::is_same<Src, SrcContig>::value || std::is_same<Src, SrcContig32>::value || std::is_same<Src, SrcStrided>::value;
     if (explicit_pairs && canopy && !ranks_only && allow_sorted && t->batch_probe && t->d_choice && d_out.any() && ladder_applies(t, n) &&
-        n >= std::max<int64_t>(walk_sorted_min_pairs(t), 524288) && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t)) {
+        n >= std::max<int64_t>(walk_sorted_min_pairs(t), kProbeMinPairs) && t->walk_ladder && t->d_crown_ladder && t->walk_crown && walk_sorted_ready(t)) {
+        // (the word only reports the verdict -- st_probe_last_choice --, nothing waits on it: a ring of slots so that launches in
+        // flight on several streams do not write the one a reader is about to fetch)
         const unsigned slot = t->choice_next.fetch_add(1, std::memory_order_relaxed) % kWorkSlots;
         int *choice = t->d_choice + slot;
-        hipError_t e = hipStreamWaitEvent(stream, t->choice_done[slot], 0);      // (the word's last readers, whatever their stream)
-        if (e == hipSuccess) e = launch_probe(t, src, n, choice, stream);
-        if (e == hipSuccess) e = launch_canopy(t, src, n, d_out, d_mrca, fault, stream, choice);
+        hipError_t e = launch_canopy(t, src, n, d_out, d_mrca, fault, stream, choice);
         if (e == hipSuccess) e = launch_walk(t, src, n, d_out, d_mrca, fault, stream, choice);
-        if (e == hipSuccess) e = hipEventRecord(t->choice_done[slot], stream);
         if (e != hipSuccess) return fail(ST_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
         return ST_OK;
     }

@@ -191,6 +191,8 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
         }
         return best;
     };
+    const int keep_probe = t->batch_probe;
+    t->batch_probe = 0;      // (the candidates are timed bare: the probe's fixed cost is the same for whichever kernel the handle keeps, and it would decide the mid-size comparisons)
     if (ok) {
         const int rule_sort = t->tile_sort, rule_walk = t->prefer_walk_sorted, rule_ladder = t->ladder_scalar;
         // Two batch sizes: the whole sample (what bulk callers send) and a quarter of it.  The scalar ladder kernel sorts
@@ -276,6 +278,7 @@ static void tune_deep_tree(st_tree *t, const TreeTables &T, const char *device_n
     } else {
         rule_for_deep_tree(t);
     }
+    t->batch_probe = keep_probe;
     (void)hipGetLastError();
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

@@ -393,12 +393,9 @@ static int upload_tree(BuiltTables &B, int device, st_tree **out, bool tune = tr
                 }
             }
             // words of the batch probe (host_launch.h::enqueue_src): optional as well
-            bool ok = t->d_rec_r && hipMalloc(reinterpret_cast<void **>(&t->d_choice), kWorkSlots * sizeof(int)) == hipSuccess;
-            for (unsigned k = 0; ok && k < kWorkSlots; k++) ok = hipEventCreateWithFlags(&t->choice_done[k], hipEventDisableTiming) == hipSuccess;
+            const bool ok = t->d_rec_r && hipMalloc(reinterpret_cast<void **>(&t->d_choice), kWorkSlots * sizeof(int)) == hipSuccess;
             if (!ok) {
                 (void)hipGetLastError();
-                for (hipEvent_t &ev : t->choice_done) { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
-                (void)hipFree(t->d_choice);
                 t->d_choice = nullptr;
             } else {
                 bytes += (int64_t)kWorkSlots * 4;

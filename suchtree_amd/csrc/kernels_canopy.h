@@ -274,11 +274,15 @@ __device__ __forceinline__ PairResult ladder_pair_sums(const CanopyParams &P, co
 template <int CAP, typename Src, bool SUMS = false>
 __global__ __launch_bounds__(kCanopyBlock, (CAP == 15 ? 8 : 4)) void k_canopy_ladder(CanopyParams P, Src src, long long n,
                                                                 DistSink out_d, MrcaSink out_m, Fault *fault,
-                                                                unsigned long long *work, const int *choice)
+                                                                unsigned long long *work, int *choice)
 {
     static_assert(CAP == 0 || CAP == 15 || CAP == 31 || CAP == 63, "long chains in registers, or (0) through a pointer");
-    if (choice && *choice != 0) return;      // (the batch probe chose the tile-sorted walk kernel, launched beside this one)
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    if (choice) {      // a probed batch (pair_math.h: probe_says_walk): the tile-sorted walk kernel, launched beside this one, reaches the same verdict
+        const bool walk = probe_says_walk(P.rec_r, src, n, P.n_nodes, P.n_leaves, P.parity != 0, reinterpret_cast<int *>(lds_raw));
+        if (blockIdx.x == 0 && threadIdx.x == 0) *choice = walk ? 1 : 0;      // (diagnostic: st_probe_last_choice)
+        if (walk) return;
+    }
     stage_ladder(P, lds_raw);
     const int rec_bytes = CAP > 0 ? 8 * (CAP + 1) : P.rec_bytes;
     const bool parity = P.parity != 0;
@@ -522,40 +526,6 @@ __global__ __launch_bounds__(kCanopyBlock, ((CAP <= 7 && PPL == 1) ? 8 : 4)) voi
             store_result_wave(out_d, out_m, base + (long long)j * blockDim.x + threadIdx.x, valid[j] ? s[j] : __builtin_nanf(""),
                               valid[j] ? m[j] : -1, live[j]);
     }
-}
-
-// Batch probe: which kernel a large batch of explicit pairs gets on a deep tree is decided per batch, on the device.  The
-// handle's timing (host_tune.h) uses uniform random pairs, where the scalar ladder kernel leads; batches of close
-// relatives -- both nodes under one portal, short paths -- run 20-35 % faster on the tile-sorted walk kernel, whose cost
-// follows the path length (profiles/near_pairs_r0{4,5}.log).  One workgroup looks at 4096 pairs spread over the
-// batch: *choice = 1 (walk kernel) when at least a quarter of them share their portal (uniform pairs: 0.1 %, leaves
-// within 1024 of each other: 2-3 %, within 64: a third, within 8: 70-80 %), else 0.  Both kernels are then launched and
-// the one not chosen returns at once: no host round trip, the call stays asynchronous.
-constexpr int kProbePairs = 4096;
-template <typename Src>
-__global__ __launch_bounds__(1024) void k_probe_shared_portal(const uint16_t *rec_r, Src src, long long n, long long n_nodes,
-                                                              long long n_leaves, int parity, int *choice)
-{
-    __shared__ int shared_count;
-    if (threadIdx.x == 0) shared_count = 0;
-    __syncthreads();
-    const long long step = n / kProbePairs > 0 ? n / kProbePairs : 1;
-    int mine = 0;
-    for (int k = threadIdx.x; k < kProbePairs; k += blockDim.x) {
-        // one pair from every stretch of `step`, at a hashed offset inside it: a fixed stride aliases with batches of
-        // periodic structure (alternating near / far pairs with an even step would show only one kind)
-        uint32_t h = (uint32_t)k * 2654435761u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        const long long i = (long long)k * step + (long long)((unsigned long long)h % (unsigned long long)step);
-        if (i >= n) break;
-        long long a, b;
-        src.load(i, a, b);
-        if ((unsigned long long)a < (unsigned long long)n_nodes && (unsigned long long)b < (unsigned long long)n_nodes)
-            mine += rec_r[record_slot(a, parity != 0, n_leaves)] == rec_r[record_slot(b, parity != 0, n_leaves)];
-    }
-    atomicAdd(&shared_count, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) *choice = shared_count * 4 >= kProbePairs ? 1 : 0;
 }
 
 // MRCA ids only (common_ancestors_bulk, the six pairs of a quartet), trees with in-order ids: the

@@ -16,6 +16,9 @@ struct WalkParams {
     long long n_nodes;
     LineageView lineage;     // a's side in one read (deep trees with lineage sums), else empty
     const LadderEntry *crown_ladder;   // ladder form of the crown by rank (k_walk_sorted stages it into LDS), or NULL
+    const uint16_t *probe_rec_r;       // batch probe (pair_math.h: probe_says_walk): portal ranks by record slot, leaves, layout
+    long long probe_n_leaves;
+    int probe_parity;
 };
 
 template <typename Src>
@@ -66,12 +69,12 @@ __global__ __launch_bounds__(256) void k_walk(WalkParams P, Src src, long long n
 // read; only the nodes below the portal are streamed from global memory.
 template <int Q, bool LADDER, typename Src>
 __global__ __launch_bounds__(kWalkSortBlock) void k_walk_sorted(WalkParams P, Src src, long long n, DistSink out_d,
-                                                                 MrcaSink out_m, Fault *fault, int key_shift, const int *choice)
+                                                                 MrcaSink out_m, Fault *fault, int key_shift, int *choice)
 {
-    // `choice` (or NULL): a word the batch probe wrote on this stream (kernels_canopy.h: k_probe_shared_portal); this
-    // kernel is the batch's kernel when it is 1, the scalar ladder kernel, launched beside it, when it is 0
-    if (choice && *choice == 0) return;
     extern __shared__ __align__(16) unsigned char walk_lds_all[];
+    // `choice` (or NULL): a probed batch (pair_math.h: probe_says_walk) -- this kernel is the batch's kernel when the sample says
+    // "close relatives", the scalar ladder kernel, launched beside it and looking at the same sample, when it does not
+    if (choice && !probe_says_walk(P.probe_rec_r, src, n, P.n_nodes, P.probe_n_leaves, P.probe_parity != 0, reinterpret_cast<int *>(walk_lds_all))) return;
     const LdsLadder LAD(walk_lds_all);
     unsigned char *walk_lds = walk_lds_all + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
     if (LADDER) {

@@ -48,7 +48,7 @@ static hipError_t launch_canopy_k(Kern kern, int ppl, const st_tree *t, const Ca
 constexpr int64_t kLadderDynamicMin = (int64_t)1 << 22;      // (records of 512 bytes and more; 1 KB records: half of it)
 template <int CAP, typename Src>
 static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice = nullptr)
+                                       DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream, int *choice = nullptr)
 {
     const size_t lds = ladder_kernel_lds_bytes(t->canopy_nodes);      // (image + the kernel's eight "counter ran dry" flags)
     if (lds > kLdsBytesPerCu) return hipErrorInvalidValue;            // (launch_policy.h::ladder_tables_ready keeps such trees away)
@@ -84,7 +84,7 @@ static hipError_t launch_canopy_ladder(const st_tree *t, const CanopyParams &P, 
 
 template <int CAP, typename Src>
 static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const Src &src, int64_t n,
-                                  DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
+                                  DistSink out_d, MrcaSink out_m, Fault *fault, hipStream_t stream, int *choice)
 {
     // the scalar ladder kernel: large distance batches of handles that chose it (launch_policy.h: ladder_applies;
     // records of more than 512 bytes: every batch the family takes -- nothing else reads them well)
@@ -116,16 +116,8 @@ static hipError_t launch_canopy_t(const st_tree *t, const CanopyParams &P, const
 }
 
 template <typename Src>
-hipError_t launch_probe(const st_tree *t, const Src &src, int64_t n, int *choice, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_probe_shared_portal<Src>, dim3(1), dim3(1024), 0, stream, t->d_rec_r, src, (long long)n, (long long)t->n_nodes,
-                       (long long)t->n_leaves, t->parity, choice);
-    return hipGetLastError();
-}
-
-template <typename Src>
 hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                                MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
+                                MrcaSink out_m, Fault *fault, hipStream_t stream, int *choice)
 {
     CanopyParams P;
     P.canopy = t->d_canopy;
@@ -179,8 +171,7 @@ hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink o
 
 
 #define ST_INSTANTIATE_CANOPY(S) \
-    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *); \
-    template hipError_t launch_probe<S>(const st_tree *, const S &, int64_t, int *, hipStream_t);
+    template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, int *);
 // The instantiations are the slowest part of the build since round 6 (the scalar ladder kernel has two forms): the file is compiled
 // three times, -DST_CANOPY_PART=0 / 1 / 2, each part with two of the six pair sources (build.py).
 #ifndef ST_CANOPY_PART

@@ -12,25 +12,22 @@
 namespace st {
 
 // canopy family (launch_canopy.hip; k_canopy_sorted behind it in launch_canopy_sorted.hip)
-// `choice` (or NULL): the batch probe's word (launch_probe below): the scalar ladder kernel runs when it holds 0, the
-// tile-sorted walk kernel when it holds 1; callers that pass it launch both
+// `choice` (or NULL): a probed batch (pair_math.h: probe_says_walk) -- callers that pass it launch the scalar ladder kernel AND the
+// tile-sorted walk kernel; every workgroup of either samples the batch itself, the kernel the sample does not choose returns at
+// once; *choice receives the verdict (0 ladder, 1 walk) for st_probe_last_choice
 template <typename Src>
 hipError_t launch_canopy(const st_tree *t, const Src &src, int64_t n, DistSink out_d, MrcaSink out_m, Fault *fault,
-                         hipStream_t stream, const int *choice = nullptr);
-// the batch probe (launch_canopy.hip: k_probe_shared_portal): *choice <- 1 if the batch's pairs mostly share portals
-template <typename Src>
-hipError_t launch_probe(const st_tree *t, const Src &src, int64_t n, int *choice, hipStream_t stream);
+                         hipStream_t stream, int *choice = nullptr);
 // walk family (launch_walk.hip): k_walk or, for large batches on trees with the tables, k_walk_sorted
 template <typename Src>
 hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d, MrcaSink out_m, Fault *fault,
-                       hipStream_t stream, const int *choice = nullptr);
+                       hipStream_t stream, int *choice = nullptr);
 
 #define ST_FOR_EACH_SRC(X) X(SrcContig) X(SrcContig32) X(SrcStrided) X(SrcTriangle) X(SrcGrid) X(SrcQuartet)
 #ifndef ST_LAUNCH_UNIT
 #define ST_EXTERN_LAUNCH(S)                                                                                              \
-    extern template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *); \
-    extern template hipError_t launch_probe<S>(const st_tree *, const S &, int64_t, int *, hipStream_t); \
-    extern template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *);
+    extern template hipError_t launch_canopy<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, int *); \
+    extern template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, int *);
 ST_FOR_EACH_SRC(ST_EXTERN_LAUNCH)
 #undef ST_EXTERN_LAUNCH
 #endif

@@ -117,7 +117,19 @@ static inline int64_t canopy_min_pairs(const st_tree *t)
     const bool walk_is_quick = t->d_lineage && t->d_lineage_node_rec && t->lineage_sums;
     const bool sorted = t->tile_sort && t->d_rec_p && sorted_q(t) > 0;
     const bool ladder = t->ladder_scalar && ladder_tables_ready(t);
-    return walk_is_quick && (sorted || ladder) ? kSortedMinPairs : kCanopyMinPairs;
+    // (deep canopies without either -- an image beyond the ladder's 10238 nodes: 3e5 leaves at depth 311 -- leave the predicated
+    // kernel a 120+ KiB image to stage per workgroup and a climb of hundreds of rounds: 38 us for ANY batch up to 65536 pairs where
+    // k_walk takes 15, profiles/default_vs_matrix_r06.log)
+    const bool deep = t->canopy_depth > kShallowCanopyDepth;
+    // (... and where the ladder kernel is the only canopy kernel fit for a deep canopy -- records of 128 bytes and more, since
+    // round 6 -- the walk family also serves the batches below the ladder kernel's smallest: the predicated kernel there was 2-3x
+    // behind k_walk / k_walk_sorted on every such tree of the matrix)
+    if (walk_is_quick && deep && ladder && !sorted) return std::max<int64_t>(kSortedMinPairs, std::max<int64_t>(t->ladder_min_pairs, kLadderMinPairs));
+    // (... and a deep canopy with neither leaves the predicated kernel, which the walk family beats up to ~4e5 pairs on every such tree
+    // measured -- 3e5 leaves at depth 311: 0.047 against 0.034 ms at 2^17 pairs, 1e5 leaves at depth 423: 0.067 against 0.026 --;
+    // from 524288 pairs the handle's timed choice between it and the tile-sorted walk kernel applies)
+    if (walk_is_quick && deep && !ladder && !sorted) return 524288;
+    return walk_is_quick && (sorted || ladder || deep) ? kSortedMinPairs : kCanopyMinPairs;
 }
 
 static inline bool mrca_ranks_ready(const st_tree *t)
@@ -134,6 +146,7 @@ static inline bool mrca_ranks_ready(const st_tree *t)
 // right size anyway).
 static inline bool walk_sorted_ready(const st_tree *t);
 constexpr int64_t kWalkSortedMinPairs = 262144;
+constexpr int64_t kProbeMinPairs = (int64_t)1 << 22;      // smallest batch the batch probe looks at (host_launch.h): its 8-10 us are 5 % of such a batch on nj.tree
 static inline int64_t walk_sorted_min_pairs(const st_tree *t) { return t->walk_sort_min > 0 ? t->walk_sort_min : kWalkSortedMinPairs; }
 static inline bool prefers_walk_sorted(const st_tree *t, int64_t n, bool want_dist)
 {

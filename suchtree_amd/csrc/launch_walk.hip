@@ -27,6 +27,9 @@ static WalkParams walk_params(const st_tree *t)
     P.rmq = t->tree_rmq ? t->d_tree_rmq : nullptr;
     P.n_nodes = t->n_nodes;
     P.crown_ladder = nullptr;
+    P.probe_rec_r = t->d_rec_r;
+    P.probe_n_leaves = t->n_leaves;
+    P.probe_parity = t->parity;
     if (t->d_lineage && t->d_lineage_node_rec && t->lineage_sums) {
         P.lineage.node_rec = t->d_lineage_node_rec;
         P.lineage.sums = t->d_lineage;
@@ -43,7 +46,7 @@ static WalkParams walk_params(const st_tree *t)
 
 template <int Q, bool LADDER, typename Src>
 static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, const Src &src, int64_t n, DistSink out_d,
-                                     MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
+                                     MrcaSink out_m, Fault *fault, hipStream_t stream, int *choice)
 {
     constexpr int64_t tile = (int64_t)Q * kWalkSortBlock;
     const size_t lds = walk_sort_scratch_bytes(Q) + (LADDER ? (size_t)P.lineage.crown_nodes * 16 : 0);
@@ -62,7 +65,7 @@ static hipError_t launch_walk_sorted(const st_tree *t, const WalkParams &P, cons
 
 template <typename Src>
 hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out_d,
-                              MrcaSink out_m, Fault *fault, hipStream_t stream, const int *choice)
+                              MrcaSink out_m, Fault *fault, hipStream_t stream, int *choice)
 {
     const WalkParams P = walk_params(t);
     if (out_d.any() && n >= walk_sorted_min_pairs(t) && walk_sorted_ready(t)) {
@@ -94,7 +97,7 @@ hipError_t launch_walk(const st_tree *t, const Src &src, int64_t n, DistSink out
 
 
 #define ST_INSTANTIATE_WALK(S) \
-    template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, const int *);
+    template hipError_t launch_walk<S>(const st_tree *, const S &, int64_t, DistSink, MrcaSink, Fault *, hipStream_t, int *);
 ST_FOR_EACH_SRC(ST_INSTANTIATE_WALK)
 
 hipError_t launch_walk_mailbox(const st_tree *t, const long long *d_pairs, int n, double *d_dist, int *d_mrca,

@@ -199,6 +199,48 @@ __device__ __forceinline__ void stage_ladder_image(unsigned char *lds_image, con
 }
 #endif
 
+#if defined(__HIPCC__)
+// Batch probe (round 6: folded into the two kernels it chooses between).  Which kernel a large batch of explicit pairs gets on a
+// deep tree is decided per batch, on the device: the handle's timing uses uniform random pairs, where the scalar ladder kernel
+// leads; batches of close relatives -- both nodes under one portal, short paths -- run 20-35 % faster on the tile-sorted walk
+// kernel, whose cost follows the path length (profiles/near_pairs_r0{4,5}.log).  Both kernels are launched; EVERY workgroup of
+// either looks at the same kProbePairs pairs of the batch -- one from every stretch of n / kProbePairs, at a hashed offset inside it
+// (a fixed stride aliases with batches of periodic structure) -- and reaches the same verdict: the walk kernel when at least a quarter
+// of them share their portal (uniform pairs: 0.1 %, leaves within 1024 of each other: 2-3 %, within 64: a third, within 8: 70-80 %).
+// The kernel that is not chosen returns before it stages anything.  No probe launch, no host round trip, no word shared between the
+// two kernels (round 5's separate probe kernel, its events and the third dispatch cost 20 us per batch; this form costs the empty
+// dispatch and two dependent reads per workgroup).  Called by all lanes of a 1024-lane workgroup BEFORE it uses its dynamic LDS:
+// `lds_word` is four bytes of it.  rec_r: rank of every node's portal by record slot.
+constexpr int kProbePairs = 1024;
+template <typename Src>
+__device__ __forceinline__ bool probe_says_walk(const uint16_t *__restrict__ rec_r, const Src &src, long long n, long long n_nodes,
+                                                long long n_leaves, bool parity, int *lds_word)
+{
+    if (threadIdx.x == 0) *lds_word = 0;
+    __syncthreads();
+    const long long step = n / kProbePairs > 0 ? n / kProbePairs : 1;
+    bool shared = false;
+    if ((int)threadIdx.x < kProbePairs) {
+        uint32_t h = (uint32_t)threadIdx.x * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const long long i = (long long)threadIdx.x * step + (long long)((unsigned long long)h % (unsigned long long)step);
+        if (i < n) {
+            long long a, b;
+            src.load(i, a, b);
+            if ((unsigned long long)a < (unsigned long long)n_nodes && (unsigned long long)b < (unsigned long long)n_nodes)
+                shared = rec_r[record_slot(a, parity, n_leaves)] == rec_r[record_slot(b, parity, n_leaves)];
+        }
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(shared);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(lds_word, (int)__builtin_popcountll(m));
+    __syncthreads();
+    const bool walk = *lds_word * 4 >= kProbePairs;
+    __syncthreads();      // (the word belongs to the caller's LDS again)
+    return walk;
+}
+
+#endif
+
 // k edges of a lineage from the entry at `at`, added onto s in lineage order, three per 16-byte read; the climb counts
 // its edges (any numbering of the image).
 template <typename Lad>

@@ -68,9 +68,8 @@ struct st_tree {
     unsigned long long *d_work = nullptr;          // kWorkSlots x 64 counters (eight used per launch, 64 bytes apart)
     mutable std::atomic<unsigned> work_next{0};
     hipEvent_t work_done[kWorkSlots] = {};         // recorded behind the launch that used slot k: the next user's memset waits for it, whatever its stream
-    int *d_choice = nullptr;                       // kWorkSlots words of the batch probe (kernels_canopy.h: k_probe_shared_portal), or NULL
+    int *d_choice = nullptr;                       // kWorkSlots words that receive the batch probe's verdicts (pair_math.h: probe_says_walk; st_probe_last_choice), or NULL
     mutable std::atomic<unsigned> choice_next{0};
-    hipEvent_t choice_done[kWorkSlots] = {};       // recorded behind the kernels that read word k
     int batch_probe = 1;      // tuning: 0 = large explicit batches of a deep tree always go to the kernel the handle chose when it was created
     int64_t ladder_min_pairs = 0;   // smallest batch of that kernel; 0 = kLadderMinPairs (set when the tree is created: timed at two batch sizes)
     int prefer_walk_sorted = 0;   // large distance batches of a canopy-strategy tree go to k_walk_sorted (set when the tree is created: timed, or by rule)

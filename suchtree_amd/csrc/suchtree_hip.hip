@@ -357,8 +357,6 @@ void st_tree_destroy(st_tree *t)
         for (hipEvent_t ev : t->work_done)
             if (ev) (void)hipEventDestroy(ev);
         (void)hipFree(t->d_choice);
-        for (hipEvent_t ev : t->choice_done)
-            if (ev) (void)hipEventDestroy(ev);
         (void)hipFree(t->q_tmp);
         if (t->mb_host) (void)hipHostFree(t->mb_host);
         (void)hipFree(t->d_fault_mb);
@@ -377,7 +375,6 @@ try {
     info->a_side_bytes = t->has_canopy ? ((t->rec_a4 && t->d_rec_a4 && t->d_leaf_blocks) ? 4 : 8) : 0;
     info->b_table_bytes_per_leaf = t->has_canopy ? ((t->rec_a4 && t->cherries && t->d_rec_c && t->d_leaf_blocks) ? t->rec_bytes / 4 : t->rec_bytes / 2) : 0;
     info->ladder_sums = (t->ladder_sums && ladder_sums_ready(t)) ? 1 : 0;      // (for batches of up to ladder_sums_max_pairs, if that is set)
-    info->reserved1 = 0;
     info->ladder_sums_max_pairs = info->ladder_sums ? t->ladder_sums_max_pairs : 0;
     info->host_wire_bytes_in = t->wire48 && t->n_nodes <= 0xFFFFFF ? 6 : 8;
     info->host_wire_bytes_out = t->wire24 && t->n_nodes <= 0xFFFFFF ? 7 : 8;

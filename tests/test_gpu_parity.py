@@ -1056,13 +1056,14 @@ def test_batch_sizes_around_kernel_tile_boundaries(ml_arrays):
 
 @pytest.mark.parametrize("which", ["ml", "nj"])
 def test_batch_probe_keeps_the_bits(which, ml_arrays, nj_arrays):
-    """Large explicit batches on a deep tree are dealt by the batch probe (k_probe_shared_portal): pairs of nearby leaves
+    """Large explicit batches on a deep tree are dealt by the batch probe (pair_math.h: probe_says_walk, run by every workgroup of the
+    two kernels it chooses between): pairs of nearby leaves
     go to the tile-sorted walk kernel, uniform pairs to the scalar ladder kernel, a half-and-half batch to whichever the
     sample says -- the results are the oracle's bits every time, and the same with the probe switched off."""
     import torch
     parent, dist, leaf_ids = ml_arrays if which == "ml" else nj_arrays
     rng = np.random.default_rng(31)
-    n = 1_200_000
+    n = 4_400_000      # (the probe looks at batches of 2^22 pairs and more)
     ia = rng.integers(0, len(leaf_ids), n)
     near = np.stack([leaf_ids[ia], leaf_ids[np.clip(ia + rng.integers(-8, 9, n), 0, len(leaf_ids) - 1)]], 1).astype(np.int64)
     uniform = rng.choice(leaf_ids, size=(n, 2)).astype(np.int64)
@@ -1090,17 +1091,19 @@ def test_batch_probe_keeps_the_bits(which, ml_arrays, nj_arrays):
     # eight is a near one, at the positions a fixed-stride sample of 4096 would land on -- is not mistaken for a near batch
     dev.set_option("batch_probe", 1)
     periodic = np.where((np.arange(n) % 8 == 0)[:, None], near, uniform)
-    assert (n // 4096) % 4 == 0      # (292: every 4th multiple of the old stride is a multiple of 8; with n = 2^k * 4096 all are)
     for name, batch, want in (("near", near, 1), ("uniform", uniform, 0), ("periodic", periodic, 0)):
         t = torch.from_numpy(batch).cuda()
         dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
         assert dev.probe_last_choice() == want, name
-    n2 = 1 << 20      # stride 256: every old sample position is one of the near pairs
+    n2 = 1 << 22      # 1024 samples, one per 4096 pairs: at a FIXED stride every sample position would be one of the near pairs
     t = torch.from_numpy(np.ascontiguousarray(periodic[:n2])).cuda()
     dev.distances_device(t.data_ptr(), n2, out_d.data_ptr(), out_m.data_ptr())
     assert dev.probe_last_choice() == 0
+    before = dev.probe_last_choice()
+    dev.distances_device(t.data_ptr(), n2 - 1, out_d.data_ptr(), out_m.data_ptr())      # below the probe's smallest batch: the handle's kernel, no verdict
+    assert dev.probe_last_choice() == before
     bad = near.copy()
-    bad[::4096, 1] = len(parent) + 5      # ids out of range scattered through the batch: the probe skips them, the kernels report them
+    bad[::2048, 1] = len(parent) + 5      # ids out of range scattered through the batch: the probe skips them, the kernels report them
     t = torch.from_numpy(bad).cuda()
     dev.set_option("batch_probe", 1)
     dev.distances_device(t.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr())
@@ -1110,8 +1113,9 @@ def test_batch_probe_keeps_the_bits(which, ml_arrays, nj_arrays):
 
 
 def test_counter_and_probe_slots_survive_many_launches_on_several_streams():
-    """The scalar ladder kernel's work counters and the batch probe's words are rings of 64 slots on the handle; a slot's
-    reuse is ordered behind its last user by an event, whatever stream that was on.  200 launches of 2^22 pairs (the
+    """The scalar ladder kernel's work counters are a ring of 64 slots on the handle; a slot's reuse is ordered behind its last
+    user by an event, whatever stream that was on (the batch probe's words only report its verdict since round 6: every workgroup
+    samples the batch itself).  200 launches of 2^22 pairs (the
     size at which 512-byte records draw their work dynamically) dealt round-robin over three streams without any host
     synchronisation in between: every launch must produce the whole, correct result."""
     import torch
