@@ -182,8 +182,15 @@ def cpu_baseline(parent, dist, pairs_host, gpu_dist, gpu_mrca, seconds):
     """Oracle (CPU port of the reference algorithm) on a bounded sample of the same
     pairs, all host cores, fork-pool-style contiguous chunks.  Also the parity check
     of the timed GPU results on that sample."""
-    from oracle.oracle import OracleTree
-    O = OracleTree(parent, dist)
+    from oracle import oracle as orc
+    O = orc.OracleTree(parent, dist)
+    port = O
+    kind, what = "port", "oracle/suchtree_oracle.c (visited-list MRCA, 20-byte AoS)"
+    if orc.ref_lib() is not None:
+        # the reference's OWN compiled _distances / _mrca (oracle/_ref/libref_hotpath.so: SuchTree/MuchTree.c as shipped, through
+        # oracle/ref_harness.c) is the timed baseline and the parity checker wherever the file travelled with the snapshot
+        O = orc.RefTree(parent, dist, depth=port.depth)
+        kind, what = "reference", "the reference's compiled SuchTree._distances (SuchTree/MuchTree.c as shipped, oracle/ref_harness.c)"
     cores = len(os.sched_getaffinity(0))
     probe = min(len(pairs_host), 200_000 * cores)
     t0 = time.perf_counter()
@@ -202,14 +209,16 @@ def cpu_baseline(parent, dist, pairs_host, gpu_dist, gpu_mrca, seconds):
     mrca_exact = bool(np.array_equal(m, gpu_mrca[:m_n]))
     max_rel = float(np.max(np.abs(d - gpu_dist[:n]) / np.maximum(np.abs(d), 1e-300))) if n else 0.0
     return {
-        "value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "value": n / dt, "unit": "pairs/s", "cores": cores, "kind": kind,
         # cores = the threads used = this process's affinity mask (a launcher may narrow it per rank); the host has host_cpus
         "host_cpus": os.cpu_count(),
-        "sample": "first %d pairs of the batch, oracle/suchtree_oracle.c (visited-list MRCA, 20-byte AoS), "
-                  "%d pthreads on contiguous chunks" % (n, cores),
+        "sample": "first %d pairs of the batch, %s, %d pthreads on contiguous chunks" % (n, what, cores),
         "single_thread_value": rate_1,
     }, {"distances_bit_exact": bit_exact, "mrca_bit_exact": mrca_exact, "max_rel_err": max_rel,
-        "checked_pairs": n}
+        "checked_pairs": n, "checked_against": kind,
+        # (the restatement itself against the reference's code on a slice of the same pairs, where both are there)
+        "oracle_equals_reference": bool(np.array_equal(port.distances(pairs_host[:200_000]).view(np.int64),
+                                                       O.distances(pairs_host[:200_000]).view(np.int64))) if kind == "reference" else None}
 
 
 def spread_parity(parent, dist, pairs_t, out_d, out_m, plan, per_edge=500, strided=1_000_000):

@@ -387,6 +387,11 @@ def leg_cpu_baseline(O, pairs_host, what, seconds=2.5):
     deep trees) on a bounded prefix of the LEG'S OWN pairs -- one thread (the reference as shipped: one thread, GIL held)
     and all host cores on contiguous chunks (the reference under a fork pool).  Returns (block, distances of the
     all-cores sample) so that the same sample serves as the parity check."""
+    from oracle import oracle as orc
+    kind, what_code = "port", "oracle/suchtree_oracle.c (visited-list MRCA, 20-byte AoS)"
+    if orc.ref_lib() is not None and hasattr(O, "nodes"):      # the reference's own compiled code where it travelled with the snapshot
+        O = orc.RefTree(O.nodes["parent"], O.nodes["distance"], depth=O.depth)
+        kind, what_code = "reference", "the reference's compiled SuchTree._distances (SuchTree/MuchTree.c as shipped, oracle/ref_harness.c)"
     cores = len(os.sched_getaffinity(0))
     n = len(pairs_host)
     k = min(n, 20_000)
@@ -405,9 +410,8 @@ def leg_cpu_baseline(O, pairs_host, what, seconds=2.5):
     t0 = time.perf_counter()
     d = O.distances_mt(pairs_host[:nm], cores)
     rm = nm / max(time.perf_counter() - t0, 1e-9)
-    return {"value": rm, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "first %d pairs of %s, oracle/suchtree_oracle.c (visited-list MRCA, 20-byte AoS), %d pthreads on "
-                      "contiguous chunks" % (nm, what, cores),
+    return {"value": rm, "unit": "pairs/s", "cores": cores, "kind": kind,
+            "sample": "first %d pairs of %s, %s, %d pthreads on contiguous chunks" % (nm, what, what_code, cores),
             "single_thread_value": r1, "single_thread_sample": "first %d pairs, one thread" % n1}, d
 
 
@@ -638,12 +642,16 @@ def config5(be):
     ids_a, ids_b = orc.linked_pairs(SLT.linklist)
     OA = orc.OracleTree(A._flat.parent, A._flat.distance)
     OB = orc.OracleTree(B._flat.parent, B._flat.distance)
-    # CPU column: the oracle's _distances on the same two id arrays, one thread (18,145 pairs per tree: what the reference runs)
+    # CPU column: _distances on the same two id arrays, one thread (18,145 pairs per tree: what the reference runs) -- the reference's
+    # own compiled code where oracle/_ref/libref_hotpath.so travelled with the snapshot, else the oracle's restatement
+    CA, CB, cpu_kind = OA, OB, "port"
+    if orc.ref_lib() is not None:
+        CA, CB, cpu_kind = orc.RefTree(A._flat.parent, A._flat.distance, depth=OA.depth), orc.RefTree(B._flat.parent, B._flat.distance, depth=OB.depth), "reference"
     t_cpu = 1e30
     for _ in range(5):
         t0 = time.perf_counter()
-        OA.distances(ids_a)
-        OB.distances(ids_b)
+        CA.distances(ids_a)
+        CB.distances(ids_b)
         t_cpu = min(t_cpu, time.perf_counter() - t0)
     ok = bool(np.array_equal(np.asarray(r["TreeA"]).view(np.int64), OA.distances(ids_a).view(np.int64))
               and np.array_equal(np.asarray(r["TreeB"]).view(np.int64), OB.distances(ids_b).view(np.int64)))
@@ -658,8 +666,8 @@ def config5(be):
     lap_ok = bool(np.array_equal(lap.view(np.int64), orc.linked_laplacian(aj_o).view(np.int64)))
     return {"workload": "fish-worm: host 21 leaves / guest 191 leaves, 191 links -> 18,145 link pairs on each tree",
             "pairs": 2 * len(ids_a), "seconds_linked_distances": best, "pairs_per_s": 2 * len(ids_a) / best,
-            "cpu_baseline": {"value": 2 * len(ids_a) / t_cpu, "unit": "pairs/s", "cores": 1, "kind": "port",
-                             "sample": "all %d link pairs of both trees, oracle/suchtree_oracle.c, one thread (the id arrays given: the "
+            "cpu_baseline": {"value": 2 * len(ids_a) / t_cpu, "unit": "pairs/s", "cores": 1, "kind": cpu_kind,
+                             "sample": "all %d link pairs of both trees, _distances on one thread (the id arrays given: the "
                                        "reference's Python-loop enumeration of pyx:2918-2925 is not timed)" % (2 * len(ids_a))},
             "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None,
                          "achieved": 2 * len(ids_a) * (28 + 8 * 10) / best / 1e9, "frac": 2 * len(ids_a) * (28 + 8 * 10) / best / 1e9 / HBM_PEAK_GBPS,

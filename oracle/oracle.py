@@ -6,7 +6,9 @@ never from ``suchtree_amd``.
 
 Also carries ``py_mrca`` / ``py_distances``: a pure-Python restatement of the
 same reference lines (MuchTree.pyx:911-943, 999-1030) used on tiny inputs to
-cross-check the C file itself.
+cross-check the C file itself, and ``RefTree``: the REFERENCE's own compiled
+``_distances`` / ``_mrca`` (oracle/_ref/libref_hotpath.so, see ref_harness.c),
+against which the restatement is checked bit for bit (tests/test_oracle_ref.py).
 """
 import ctypes
 import os
@@ -143,6 +145,93 @@ class OracleTree:
                                        s0, s1, _p(out), int(n_threads))
         if rc != 0:
             raise RuntimeError("oracle_distances_mt failed rc=%d" % rc)
+        return out
+
+
+# ---- the reference's own compiled hot path (oracle/_ref/libref_hotpath.so: oracle/ref_harness.c, `make -C oracle ref`) ----
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_hotpath.so")
+_REFERENCE_C = "/root/reference/SuchTree/MuchTree.c"
+_ref = None
+
+
+def build_ref(force=False):
+    """Compile oracle/_ref/libref_hotpath.so from the reference's generated C where it lies (needs /root/reference: this
+    container only; the GPU box uses the prebuilt file).  Returns its path, or None when it neither exists nor can be built."""
+    if os.path.exists(_REFERENCE_C) and (force or not os.path.exists(_REF_PATH) or
+                                         os.path.getmtime(_REF_PATH) < os.path.getmtime(os.path.join(_HERE, "ref_harness.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return _REF_PATH if os.path.exists(_REF_PATH) else None
+
+
+def ref_lib():
+    """The library, or None when it is not there (nothing under /root/reference and no prebuilt file)."""
+    global _ref
+    if _ref is None:
+        try:
+            path = build_ref()
+            if path is None:
+                return None
+            L = ctypes.CDLL(path)
+        except (OSError, subprocess.CalledProcessError):      # (unbuildable or unloadable here: callers fall back to the restatement)
+            return None
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+        L.ref_hotpath_distances.argtypes = [vp, vp, i64, i32, vp, i64, i64, i64, vp, ctypes.c_int]
+        L.ref_hotpath_mrca.argtypes = [vp, vp, i64, i32, vp, i64, i64, i64, vp]
+        L.ref_hotpath_quartets.argtypes = [vp, vp, i64, i32, vp, i64, vp]
+        _ref = L
+    return _ref
+
+
+class RefTree:
+    """The REFERENCE's compiled ``SuchTree._distances`` / ``_mrca`` (MuchTree.c as shipped, see ref_harness.c) on flat
+    arrays: the same method names as OracleTree, so that either can check the other or the GPU.  ``depth`` is the
+    reference's (nodes on the longest leaf-to-root path, MuchTree.pyx:218-225): it sizes the ``visited`` scratch."""
+
+    def __init__(self, parent, distance, depth=None):
+        if ref_lib() is None:
+            raise RuntimeError("oracle/_ref/libref_hotpath.so is not available (make -C oracle ref needs /root/reference)")
+        self.parent = np.ascontiguousarray(parent, dtype=np.int32)
+        self.distance = np.ascontiguousarray(distance, dtype=np.float32)
+        self.size = self.parent.shape[0]
+        self.depth = int(depth) if depth is not None else OracleTree(self.parent, self.distance).depth
+
+    def distances(self, pairs, n_threads=1):
+        ids = np.asarray(pairs)
+        if ids.dtype != np.int64:
+            ids = ids.astype(np.int64)
+        assert ids.ndim == 2 and ids.shape[1] == 2 and ids.strides[0] >= 0 and ids.strides[1] >= 0
+        out = np.zeros(ids.shape[0], dtype=np.float64)
+        if ids.shape[0]:
+            rc = ref_lib().ref_hotpath_distances(_p(self.parent), _p(self.distance), self.size, self.depth, _p(ids), ids.shape[0],
+                                                 ids.strides[0], ids.strides[1], _p(out), int(n_threads))
+            if rc != 0:
+                raise RuntimeError("ref_hotpath_distances failed rc=%d" % rc)
+        return out
+
+    def distances_mt(self, pairs, n_threads):
+        return self.distances(pairs, n_threads)
+
+    def quartets(self, quartets):
+        q = np.ascontiguousarray(quartets, dtype=np.int64)
+        assert q.ndim == 2 and q.shape[1] == 4
+        out = np.zeros_like(q)
+        if q.shape[0]:
+            rc = ref_lib().ref_hotpath_quartets(_p(self.parent), _p(self.distance), self.size, self.depth, _p(q), q.shape[0], _p(out))
+            if rc != 0:
+                raise RuntimeError("ref_hotpath_quartets failed rc=%d" % rc)
+        return out
+
+    def mrca_bulk(self, pairs):
+        ids = np.asarray(pairs)
+        if ids.dtype != np.int64:
+            ids = ids.astype(np.int64)
+        assert ids.ndim == 2 and ids.shape[1] == 2 and ids.strides[0] >= 0 and ids.strides[1] >= 0
+        out = np.zeros(ids.shape[0], dtype=np.int32)
+        if ids.shape[0]:
+            rc = ref_lib().ref_hotpath_mrca(_p(self.parent), _p(self.distance), self.size, self.depth, _p(ids), ids.shape[0],
+                                            ids.strides[0], ids.strides[1], _p(out))
+            if rc != 0:
+                raise RuntimeError("ref_hotpath_mrca failed rc=%d" % rc)
         return out
 
 

@@ -27,12 +27,17 @@
  * `__pyx_v_d = (__pyx_v_d + data[n].distance)` statements in path order (:32435 a-side,
  * :32475 b-side) and a widening store into the double result (:32496).
  *
- * Pinning: the reference extension cannot be imported in the build
+ * Pinning: the reference's Python module cannot be imported in the build
  * container (hard `import dendropy` at MuchTree.pyx:3; dendropy is not
- * installed and no stand-in is written for it).  The oracle is therefore
- * pinned against the reference's own known answers: SuchTree/tests/test.matrix
- * (225 distances), the values printed in docs/examples/SuchTree_examples.md
- * and the dendropy-printed leaf ids there.  See tests/test_oracle_golden.py.
+ * installed and no stand-in is written for it) -- but the C that Cython
+ * generated from _distances / _mrca ships in the reference's repository and
+ * contains no Python API call: oracle/ref_harness.c compiles it where it lies
+ * into oracle/_ref/libref_hotpath.so, and tests/test_oracle_ref.py checks this
+ * restatement against the reference's own compiled code BIT FOR BIT on
+ * arbitrary inputs (round 6).  The callers around the path and the ingest stay
+ * pinned by the reference's known answers: SuchTree/tests/test.matrix (225
+ * distances), the values printed in docs/examples/SuchTree_examples.md and the
+ * dendropy-printed leaf ids there.  See tests/test_oracle_golden.py.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; x86-64 SSE float
  * adds, i.e. the same arithmetic gcc emits for the Cython-generated C).

@@ -73,6 +73,8 @@ def main():
                         dev.set_option("ladder_scalar", int(rng.integers(0, 2)))
                         dev.set_option("ladder_min_pairs", int(rng.choice([0, 0, 300000])))
                         dev.set_option("ladder_dynamic", int(rng.choice([0, 1])))
+                        dev.set_option("ladder_sums", int(rng.choice([0, 1])))      # (the joint form, round 6)
+                        dev.set_option("batch_probe", int(rng.choice([0, 1])))
                     if k in (0, 4):
                         for name in ("walk_sort", "walk_ladder", "walk_crown", "lineage_lens"):
                             dev.set_option(name, int(rng.random() < 0.8))

@@ -137,7 +137,7 @@ def test_bench_job_line_on_gloo(world, share, chunks, n, wire):
     assert d["parity"]["distances_bit_exact"] and d["parity"]["mrca_bit_exact"]
     assert d["parity_across_slices"]["distances_bit_exact"] and d["parity_across_slices"]["mrca_bit_exact"]
     assert d["parity_across_slices"]["checked_pairs"] >= min(n, 1000)
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches_per_step"] == chunks
     # at N > 1 the block speaks for the slowest rank's kernels: its kernel time and its pairs

@@ -54,7 +54,7 @@ def test_leg_cpu_baseline_on_the_oracle():
     pairs = synth.random_leaf_pairs(1 << 10, 60_000, seed=5)
     O = OracleTree(parent, dist)
     cpu, d = bench_legs.leg_cpu_baseline(O, pairs, "a test batch", seconds=0.2)
-    assert cpu["kind"] == "port" and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["single_thread_value"] > 0
+    assert cpu["kind"] in ("port", "reference") and cpu["unit"] == "pairs/s" and cpu["value"] > 0 and cpu["single_thread_value"] > 0
     assert cpu["cores"] == len(os.sched_getaffinity(0)) and "a test batch" in cpu["sample"]
     assert 0 < len(d) <= len(pairs) and np.array_equal(d.view(np.int64), O.distances(pairs[:len(d)]).view(np.int64))
 

@@ -762,6 +762,54 @@ def test_ladder_kernel_joint_form_keeps_the_bits(which, ml_arrays, nj_arrays):
     dev.close()
 
 
+@pytest.mark.parametrize("which", ["ml", "nj", "balanced17", "deep63"])
+def test_gpu_against_the_reference_s_own_compiled_hot_path(which, ml_arrays, nj_arrays):
+    """The HIP path against the REFERENCE's compiled SuchTree._distances / _mrca (oracle/_ref/libref_hotpath.so: MuchTree.c as shipped,
+    compiled where it lies, oracle/ref_harness.c -- the file travels with the snapshot), not through the oracle's restatement:
+    distances bit for bit (float32 ordered sums widened to float64), MRCA ids exactly; device-resident pairs through the C ABI and
+    numpy pairs through the host path; every kind of node pair."""
+    import torch
+    from oracle import oracle as orc
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref/libref_hotpath.so did not travel with this snapshot")
+    rng = np.random.default_rng(97)
+    if which == "ml":
+        parent, dist = ml_arrays[0], ml_arrays[1]
+    elif which == "nj":
+        parent, dist = nj_arrays[0], nj_arrays[1]
+    elif which == "balanced17":
+        parent, dist = synth.balanced_tree(17)
+    else:
+        parent, dist = _random_shape_tree(rng, 54_000, 0.95)
+    n = len(parent)
+    root = int(np.flatnonzero(parent < 0)[0])
+    a = rng.integers(0, n, 60_000)
+    up = a.copy()
+    for _ in range(int(rng.integers(1, 30))):
+        up = np.where(parent[up] >= 0, parent[up], root)
+    allp = np.concatenate([rng.integers(0, n, (500_000, 2)), np.stack([a, np.clip(a + rng.integers(-30, 31, a.size), 0, n - 1)], 1),
+                           np.stack([a[:5000], a[:5000]], 1), np.stack([a, up], 1), np.stack([up, a], 1)]).astype(np.int64)
+    R = orc.RefTree(parent, dist)
+    cores = len(os.sched_getaffinity(0))
+    want_d, want_m = R.distances(allp, cores), R.mrca_bulk(allp[:250_000])
+    dev = _capi.DeviceTree(parent, dist)
+    t = torch.from_numpy(allp).cuda()
+    out_d = torch.empty(len(allp), dtype=torch.float64, device="cuda")
+    out_m = torch.empty(len(allp), dtype=torch.int32, device="cuda")
+    dev.distances_device(t.data_ptr(), len(allp), out_d.data_ptr(), out_m.data_ptr())
+    dev.fault_check()
+    assert_bits_equal(out_d.cpu().numpy(), want_d, which + ": device path vs the reference's code")
+    assert np.array_equal(out_m[:250_000].cpu().numpy(), want_m), which
+    d, m = dev.distances_host(allp, True, True)
+    assert_bits_equal(d, want_d, which + ": host path vs the reference's code")
+    assert np.array_equal(m[:250_000], want_m), which
+    dev.set_strategy("walk")
+    d, m = dev.distances_host(allp[:300_000], True, True)
+    assert_bits_equal(d, want_d[:300_000], which + ": walk family vs the reference's code")
+    assert np.array_equal(m[:250_000], want_m), which
+    dev.close()
+
+
 def test_kernel_of_large_batches_is_timed_at_creation(monkeypatch, tmp_path):
     """Deep trees: the handle times its candidate kernels when it is created and makes the fastest its default
     (st_tree_info.tuned / big_batch_kernel); every candidate, forced by options, gives the same bits.  512-byte
