@@ -762,6 +762,24 @@ def test_ladder_kernel_joint_form_keeps_the_bits(which, ml_arrays, nj_arrays):
     dev.close()
 
 
+@pytest.mark.parametrize("which", ["gopher", "ml", "nj"])
+def test_gpu_against_the_committed_vectors_of_the_reference_s_compiled_hot_path(which, gopher_flat, ml_arrays, nj_arrays):
+    """tests/golden/ref_hotpath_vectors.npz (outputs of the reference's own compiled _distances / _mrca / _quartet_topologies on
+    seeded inputs, scripts/make_ref_golden.py): the HIP path reproduces them bit for bit -- data, no library needed."""
+    z = np.load(golden_path("ref_hotpath_vectors.npz"))
+    parent, dist = {"gopher": (gopher_flat.parent, gopher_flat.distance), "ml": ml_arrays[:2], "nj": nj_arrays[:2]}[which]
+    pairs = z[which + "_pairs"].astype(np.int64)
+    want_d, want_m = z[which + "_dist"].astype(np.float64), z[which + "_mrca"]
+    dev = _capi.DeviceTree(parent, dist)
+    for name, (d, m) in _both(dev, pairs).items():
+        assert_bits_equal(d, want_d, which + " " + name)
+        assert np.array_equal(m, want_m), (which, name)
+    dev.close()
+    from suchtree_amd import SuchTree
+    T = SuchTree((np.asarray(parent), np.asarray(dist)), device=0)
+    assert np.array_equal(np.asarray(T.quartet_topologies_bulk(z[which + "_quartets"].astype(np.int64))), z[which + "_topologies"].astype(np.int64))
+
+
 @pytest.mark.parametrize("which", ["ml", "nj", "balanced17", "deep63"])
 def test_gpu_against_the_reference_s_own_compiled_hot_path(which, ml_arrays, nj_arrays):
     """The HIP path against the REFERENCE's compiled SuchTree._distances / _mrca (oracle/_ref/libref_hotpath.so: MuchTree.c as shipped,

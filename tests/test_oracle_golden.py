@@ -215,3 +215,19 @@ def test_docs_correlations_between_ml_and_nj_tree(ml_arrays, nj_arrays):
     assert abs(spearmanr(D1, D2)[0] - 0.961) < 0.0015
     assert abs(kendalltau(D1, D2)[0] - 0.824) < 0.0015
     assert abs(pearsonr(D1, D2)[0] - 0.969) < 0.0015
+
+
+@pytest.mark.parametrize("which", ["gopher", "ml", "nj"])
+def test_oracle_reproduces_the_reference_s_compiled_hot_path_vectors(which, gopher_flat, ml_arrays, nj_arrays):
+    """tests/golden/ref_hotpath_vectors.npz: seeded inputs and the outputs of the reference's OWN compiled _distances / _mrca /
+    _quartet_topologies (scripts/make_ref_golden.py, run where /root/reference and oracle/_ref/libref_hotpath.so exist) -- data, so
+    the pin at full precision (last-ulp summation order, every MRCA id) holds wherever the library itself is not available."""
+    from oracle.oracle import OracleTree
+    z = np.load(golden_path("ref_hotpath_vectors.npz"))
+    parent, dist = {"gopher": (gopher_flat.parent, gopher_flat.distance), "ml": ml_arrays[:2], "nj": nj_arrays[:2]}[which]
+    O = OracleTree(parent, dist)
+    assert O.depth == int(z[which + "_depth"])
+    pairs = z[which + "_pairs"].astype(np.int64)
+    assert np.array_equal(O.distances(pairs).view(np.int64), z[which + "_dist"].astype(np.float64).view(np.int64))
+    assert np.array_equal(O.mrca_bulk(pairs), z[which + "_mrca"])
+    assert np.array_equal(O.quartets(z[which + "_quartets"].astype(np.int64)), z[which + "_topologies"].astype(np.int64))
