@@ -1,0 +1,63 @@
+"""Which kernel a default handle picks, checked by the clock (GPU box): on the reference's two big trees a handle with DEFAULT options
+(kernels and forms chosen by its own timing at creation, batch probe on) must stay within 1.5x of the fastest kernel forced by options at
+mid and large batch sizes.  Round 6's first run of scripts/default_vs_matrix.py found 2-3x cliffs there (the predicated kernel as fallback
+below the ladder kernel's smallest batch, a 20 us probe per batch) that no parity test could see: results were identical, only slow."""
+import numpy as np
+import pytest
+
+from suchtree_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+FORCED = {
+    "ladder, both sides climbed": ("canopy", {"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "prefer_walk_sorted": 0, "ladder_sums": 0, "batch_probe": 0}),
+    "ladder, joint form": ("canopy", {"tile_sort": 0, "ladder_scalar": 1, "ladder_min_pairs": 0, "prefer_walk_sorted": 0, "ladder_sums": 1, "batch_probe": 0}),
+    "walk family": ("walk", {}),
+}
+
+
+def _median_ms(tree, pairs, n, out_d, out_m, stream, torch):
+    ms = []
+    for r in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        tree.distances_device(pairs.data_ptr(), n, out_d.data_ptr(), out_m.data_ptr(), stream=stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        if r:
+            ms.append(e0.elapsed_time(e1))
+    return float(np.median(ms))
+
+
+@pytest.mark.parametrize("which", ["ml", "nj"])
+def test_default_handle_is_near_the_fastest_forced_kernel(which, ml_arrays, nj_arrays, monkeypatch):
+    import torch
+    monkeypatch.setenv("SUCHTREE_AMD_TUNE_CACHE", "0")      # (time now: no record of another build or box)
+    parent, dist, leaf_ids = ml_arrays if which == "ml" else nj_arrays
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    sizes = (1 << 17, 1 << 20, 1 << 22)
+    li = torch.from_numpy(leaf_ids.astype(np.int64)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    pairs = li[torch.randint(0, len(leaf_ids), (sizes[-1], 2), generator=g, device=dev)]
+    out_d = torch.empty(sizes[-1], dtype=torch.float64, device=dev)
+    out_m = torch.empty(sizes[-1], dtype=torch.int32, device=dev)
+    default = _capi.DeviceTree(parent, dist)
+    forced = _capi.DeviceTree(parent, dist)
+    assert default.info()["tuned"] == 1 and default.info()["big_batch_kernel"] == "canopy_ladder", default.info()
+    for n in sizes:
+        t_default = _median_ms(default, pairs, n, out_d, out_m, stream, torch)
+        ref_sum = float(out_d[:n].sum().item())
+        best = None
+        for name, (strategy, opts) in FORCED.items():
+            forced.set_strategy(strategy)
+            for k, v in opts.items():
+                forced.set_option(k, v)
+            t = _median_ms(forced, pairs, n, out_d, out_m, stream, torch)
+            assert float(out_d[:n].sum().item()) == ref_sum, (which, n, name)      # (the same bits whichever kernel ran)
+            if best is None or t < best[0]:
+                best = (t, name)
+        assert t_default <= 1.5 * best[0] + 0.005, "%s, %d pairs: default %.4f ms, %s %.4f ms" % (which, n, t_default, best[1], best[0])
+    default.fault_check(stream.cuda_stream)
+    default.close()
+    forced.close()
