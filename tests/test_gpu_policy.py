@@ -1,5 +1,5 @@
 """Which kernel a default handle picks, checked by the clock (GPU box): on the reference's two big trees a handle with DEFAULT options
-(kernels and forms chosen by its own timing at creation, batch probe on) must stay within 1.5x of the fastest kernel forced by options at
+(kernels and forms chosen by its own timing at creation, batch probe on) must stay within 1.8x of the fastest kernel forced by options at
 mid and large batch sizes.  Round 6's first run of scripts/default_vs_matrix.py found 2-3x cliffs there (the predicated kernel as fallback
 below the ladder kernel's smallest batch, a 20 us probe per batch) that no parity test could see: results were identical, only slow."""
 import numpy as np
@@ -57,7 +57,8 @@ def test_default_handle_is_near_the_fastest_forced_kernel(which, ml_arrays, nj_a
             assert float(out_d[:n].sum().item()) == ref_sum, (which, n, name)      # (the same bits whichever kernel ran)
             if best is None or t < best[0]:
                 best = (t, name)
-        assert t_default <= 1.5 * best[0] + 0.005, "%s, %d pairs: default %.4f ms, %s %.4f ms" % (which, n, t_default, best[1], best[0])
+        assert t_default <= 1.8 * best[0] + 0.008,      # (generous: the cliffs this guards against were 2-3.2x; a busy box must not trip it)
+             "%s, %d pairs: default %.4f ms, %s %.4f ms" % (which, n, t_default, best[1], best[0])
     default.fault_check(stream.cuda_stream)
     default.close()
     forced.close()
